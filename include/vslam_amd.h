@@ -1,0 +1,173 @@
+/*
+ * vslam_amd.h — C ABI of the MI355X (gfx950) front-end: keypoint extraction + rBRIEF,
+ * Hamming k=2 matching, RANSAC fundamental matrix, 2-D k-d tree build / radius query.
+ *
+ * This is the drop-in boundary for the per-frame hot path of rahulaggarwal965/vslam.
+ * The reference has no FFI: its consumers include Frame.h / KDTree.h / RansacFilter.h and link
+ * the objects (src/vslam.cpp:6-10).  The header-only adapters under include/vslam/ re-present
+ * those C++ surfaces and call the entry points below; INTEGRATION.md shows the binding.
+ * Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  `d_` parameters are DEVICE pointers (HBM), `h_` are host.
+ *   - Batched layout: item b of a batch lives at base + b * stride elements, with a per-item
+ *     count array (device, int32).  "kp_stride" = keypoint slots per frame.
+ *   - All device entry points are asynchronous on the context's stream and return a status;
+ *     VSLAM_OK == 0.  There is NO CPU fallback: without a HIP device every call fails.
+ *   - Descriptors are 32 bytes per keypoint (cv::ORB default), points are (x, y) float pairs
+ *     (cv::Point2f), index pairs are (queryIdx, trainIdx) int32.
+ */
+#ifndef VSLAM_AMD_H
+#define VSLAM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSLAM_OK 0
+#define VSLAM_ERR_INVALID (-1)   /* bad argument (null pointer, size out of range)           */
+#define VSLAM_ERR_HIP (-2)       /* a HIP runtime call failed; see vslam_last_error()         */
+#define VSLAM_ERR_NO_DEVICE (-3) /* no gfx950 device visible                                 */
+#define VSLAM_ERR_CAPACITY (-4)  /* a size exceeds what the kernels were built for           */
+#define VSLAM_ERR_DEGENERATE (-5)/* input the reference leaves undefined (<2 train rows, <8 matches) */
+
+#define VSLAM_DESC_BYTES 32
+#define VSLAM_SET_SIZE 8         /* RansacFilter draws 8-subsets: src/RansacFilter.cpp:17    */
+#define VSLAM_MAX_KP 16384       /* keypoint slots per frame the match key packing supports  */
+
+typedef struct vslam_ctx vslam_ctx;
+
+/* ------------------------------------------------------------------ context */
+int vslam_ctx_create(int device, vslam_ctx **out);
+int vslam_ctx_destroy(vslam_ctx *ctx);
+/* Borrow a caller-owned hipStream_t (e.g. torch's current stream).  NULL = own stream.      */
+int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream);
+int vslam_ctx_synchronize(vslam_ctx *ctx);
+const char *vslam_last_error(vslam_ctx *ctx);
+const char *vslam_version(void);
+
+/* device memory + copies for hosts that have no other allocator (the C++ adapters) */
+int vslam_dev_alloc(vslam_ctx *ctx, size_t bytes, void **d_out);
+int vslam_dev_free(vslam_ctx *ctx, void *d_ptr);
+int vslam_copy_h2d(vslam_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int vslam_copy_d2h(vslam_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* per-kernel timing with HIP events on the context's stream (bench.py's roofline leg) */
+int vslam_prof_enable(vslam_ctx *ctx, int on);
+int vslam_prof_reset(vslam_ctx *ctx);
+int vslam_prof_count(vslam_ctx *ctx);   /* synchronises, folds pending events, returns #kernels */
+int vslam_prof_get(vslam_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *launches);
+
+/* ----------------------------------------------------------------- matching */
+/* Replaces match_features' front half, src/Frame.cpp:83-94:
+ *   BFMatcher(NORM_HAMMING)->knnMatch(desc1, desc2, k=2) + `m[0].distance < m[1].distance*0.7`.
+ * d_desc1/d_desc2: [batch][kp_stride][32] u8; d_n1/d_n2: [batch] int32.
+ * d_pairs: [batch][kp_stride][2] int32 (queryIdx, trainIdx) in query order; d_m: [batch].
+ * Optional d_knn (may be NULL): [batch][kp_stride][4] int32 = idx0, dist0, idx1, dist1.
+ * Items with fewer than 2 train rows produce m = 0 (the reference reads m[1] regardless).    */
+int vslam_match_knn2_ratio(vslam_ctx *ctx, const uint8_t *d_desc1, const int32_t *d_n1,
+                           const uint8_t *d_desc2, const int32_t *d_n2, int batch, int kp_stride,
+                           int32_t *d_pairs, int32_t *d_m, int32_t *d_knn);
+
+/* ------------------------------------------------------------------- RANSAC */
+/* Replaces RansacFilter::initialize_sets, src/RansacFilter.cpp:6-34, with the seed injected
+ * (std::mt19937(seed) + libstdc++ uniform_int_distribution, draws without replacement).
+ * d_seeds: [batch] u32; d_m: [batch] matches per item; d_sets: [batch][hyp][8] int32.
+ * d_draw_scratch: [batch][hyp*8] u32 workspace.  Items with m < 8 get all-zero sets.          */
+int vslam_ransac_sets(vslam_ctx *ctx, const uint32_t *d_seeds, const int32_t *d_m, int batch,
+                      int hyp, int32_t *d_sets, uint32_t *d_draw_scratch);
+
+/* Replaces RansacFilter::find_fundamental (+ compute_fundamental, compute_fundamental_residual),
+ * src/RansacFilter.cpp:36-140, for pre-drawn sets, and match_features' back half
+ * (src/Frame.cpp:96-102: keep the winner's inlier matches).
+ * d_xy1/d_xy2: [batch][kp_stride][2] f32; d_pairs/d_m as produced by vslam_match_knn2_ratio.
+ * Outputs: d_F [batch][9] f32 (row-major 3x3, untouched when no hypothesis is accepted),
+ *          d_mask [batch][kp_stride] u8, d_best [batch][4] int32 = winner, count, bits(sum), n_out,
+ *          d_matches [batch][kp_stride][2] int32 compacted inlier matches (n_out of them).
+ * Workspaces: d_hypF [batch][hyp][9] f32, d_hyp_count [batch][hyp] int32, d_hyp_sum [batch][hyp] f32
+ * (also the per-hypothesis outputs the parity tests read).                                   */
+int vslam_ransac_fundamental(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2,
+                             const int32_t *d_pairs, const int32_t *d_m, const int32_t *d_sets,
+                             int batch, int kp_stride, int hyp, float threshold, float *d_F,
+                             uint8_t *d_mask, int32_t *d_best, int32_t *d_matches, float *d_hypF,
+                             int32_t *d_hyp_count, float *d_hyp_sum);
+
+/* ------------------------------------------------------------------ k-d tree */
+/* Replaces construct_kdtree(frame_kdtree&, points), src/KDTree.cpp:107-143.  The tree is the
+ * reference's pre-order node array reduced to its pt_index column: d_nodes [batch][kp_stride].
+ * Child positions are implicit (left subtree len/2 nodes, right len - len/2 - 1).  Tie placement
+ * reproduces libstdc++'s std::nth_element (introselect) exactly.                             */
+int vslam_kdtree_build(vslam_ctx *ctx, const float *d_xy, const int32_t *d_n, int batch,
+                       int kp_stride, int32_t *d_nodes);
+/* Replaces radius_search(frame_kdtree, points, query, radius), src/KDTree.cpp:145-171.
+ * d_queries [batch][q_stride][2], d_nq [batch]; hits in the reference's visit (pre-order) order:
+ * d_hits [batch][q_stride][hit_cap] (first hit_cap only), d_counts [batch][q_stride] (true count). */
+int vslam_kdtree_radius(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_xy,
+                        const int32_t *d_n, int batch, int kp_stride, const float *d_queries,
+                        const int32_t *d_nq, int q_stride, float radius, int32_t *d_hits,
+                        int32_t *d_counts, int hit_cap);
+
+/* ---------------------------------------------------------------- extraction */
+typedef struct vslam_extract_params {
+    int32_t max_corners;     /* goodFeaturesToTrack maxCorners (3000 in src/Frame.cpp:61)      */
+    double quality;          /* 0.01                                                           */
+    double min_distance;     /* 3                                                              */
+    float cos_a, sin_a;      /* steered-BRIEF rotation; KeyPoint(p,20) has angle -1 deg        */
+    const int8_t *d_pattern; /* DEVICE [256][4] int8 (x0,y0,x1,y1): OpenCV's learned table is an
+                                input, it is not redistributable from memory                  */
+} vslam_extract_params;
+
+/* Replaces extract_features(Frame&), src/Frame.cpp:53-80, for a batch of BGR frames:
+ * cvtColor -> goodFeaturesToTrack -> ORB::compute (border filter, 7x7 blur, rBRIEF) -> kd-tree.
+ * d_bgr: [frames][height][row_stride] u8 (3 bytes per pixel).
+ * Outputs per frame: d_xy [frames][kp_stride][2], d_desc [frames][kp_stride][32],
+ * d_nodes [frames][kp_stride] (may be NULL), d_n [frames] kept keypoints, d_n_detected [frames]
+ * (the pre-filter count that sizes map_point_ids, src/Frame.cpp:73).                          */
+int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
+                           int row_stride, const vslam_extract_params *params, int kp_stride,
+                           float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                           int32_t *d_n_detected);
+
+/* stage-level entry points (parity tests; each is one step of vslam_extract_features) */
+int vslam_bgr2gray(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
+                   int row_stride, uint8_t *d_gray);
+int vslam_min_eigen(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int width, int height,
+                    float *d_eig);
+int vslam_good_features(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int width, int height,
+                        int max_corners, double quality, double min_distance, int kp_stride,
+                        float *d_xy, int32_t *d_n);
+int vslam_gaussian7(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int width, int height,
+                    uint8_t *d_out);
+int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int width, int height,
+                       const float *d_xy_in, const int32_t *d_n_in, int kp_stride, float cos_a,
+                       float sin_a, const int8_t *d_pattern, float *d_xy_out, uint8_t *d_desc,
+                       int32_t *d_n_out);
+
+/* ------------------------------------------------------------------ pipeline */
+/* match_features(frame1, frame2, rf, matches, F), src/Frame.cpp:82-105, for a batch of pairs
+ * whose features are already on the device: match -> sets -> RANSAC -> inlier matches.
+ * Workspaces are owned by the context and sized on first use.                                */
+int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_desc1,
+                         const int32_t *d_n1, const float *d_xy2, const uint8_t *d_desc2,
+                         const int32_t *d_n2, int batch, int kp_stride, const uint32_t *d_seeds,
+                         int hyp, float threshold, int32_t *d_matches, int32_t *d_best, float *d_F,
+                         int32_t *d_prelim_m);
+
+/* The whole front-end for a batch of independent frame pairs: frames [0, pairs) are the "last"
+ * frames, frames [pairs, 2*pairs) the "current" ones; pair p = (frame p, frame pairs + p).
+ * Extract all 2*pairs frames, match last->current, RANSAC.  This is what bench.py times.
+ * d_xy / d_desc / d_nodes / d_n are the per-frame outputs of vslam_extract_features for all
+ * 2*pairs frames; d_matches / d_best / d_F are per pair as in vslam_match_features.          */
+int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int width, int height,
+                         int row_stride, const vslam_extract_params *params, int kp_stride,
+                         const uint32_t *d_seeds, int hyp, float threshold,
+                         float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                         int32_t *d_matches, int32_t *d_best, float *d_F);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+"""ctypes/numpy wrapper of oracle/liboracle.so — the CPU oracle (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def load(name="liboracle.so"):
+    path = os.path.join(ORACLE_DIR, name)
+    if not os.path.exists(path):
+        build_oracle()
+    return C.CDLL(path)
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+class Oracle:
+    def __init__(self, libname="liboracle.so"):
+        self.lib = load(libname)
+        self.lib.vso_hamming256.restype = C.c_uint32
+
+    # ------------------------------------------------------------ kd tree
+    def kdtree_build_frame(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float32)
+        n = xy.shape[0]
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        assert self.lib.vso_kdtree_build_frame(_p(xy, C.c_float), n, _p(out, C.c_int32)) == 0
+        return out[:n]
+
+    def kdtree_radius_frame(self, nodes, xy, q, radius, cap=64):
+        xy = np.ascontiguousarray(xy, dtype=np.float32)
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        out = np.zeros(cap, dtype=np.int32)
+        cnt = self.lib.vso_kdtree_radius_frame(_p(nodes, C.c_int32), _p(xy, C.c_float), xy.shape[0],
+                                               C.c_float(q[0]), C.c_float(q[1]), C.c_float(radius),
+                                               _p(out, C.c_int32), cap)
+        return out[:min(cnt, cap)], cnt
+
+    # ------------------------------------------------------------ matching
+    def match_knn2(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, dtype=np.uint8); d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+        n1, n2 = d1.shape[0], d2.shape[0]
+        outs = [np.zeros(max(n1, 1), dtype=np.int32) for _ in range(4)]
+        assert self.lib.vso_match_knn2(_p(d1, C.c_uint8), n1, _p(d2, C.c_uint8), n2,
+                                       *[_p(o, C.c_int32) for o in outs]) == 0
+        return [o[:n1] for o in outs]   # idx0, dist0, idx1, dist1
+
+    def match_knn2_ratio(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, dtype=np.uint8); d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+        n1, n2 = d1.shape[0], d2.shape[0]
+        pairs = np.zeros((max(n1, 1), 2), dtype=np.int32)
+        m = C.c_int32(0)
+        rc = self.lib.vso_match_knn2_ratio(_p(d1, C.c_uint8), n1, _p(d2, C.c_uint8), n2, _p(pairs, C.c_int32), C.byref(m))
+        if rc != 0:
+            return pairs[:0], rc
+        return pairs[:m.value].copy(), 0
+
+    # ------------------------------------------------------------ ransac
+    def ransac_sets(self, seed, n_matches, H, min_items=8):
+        out = np.zeros((H, 8), dtype=np.int32)
+        rc = self.lib.vso_ransac_sets(C.c_uint32(seed & 0xFFFFFFFF), n_matches, min_items, H, _p(out, C.c_int32))
+        assert rc == 0, rc
+        return out
+
+    def svd(self, A):
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        m, n = A.shape
+        w = np.zeros(min(m, n), dtype=np.float32)
+        u = np.zeros((m, m), dtype=np.float32)
+        vt = np.zeros((n, n), dtype=np.float32)
+        assert self.lib.vso_svd32f_full(_p(A, C.c_float), m, n, _p(w, C.c_float), _p(u, C.c_float), _p(vt, C.c_float)) == 0
+        return w, u, vt
+
+    def compute_fundamental(self, p1_set, p2_set):
+        p1_set = np.ascontiguousarray(p1_set, dtype=np.float32); p2_set = np.ascontiguousarray(p2_set, dtype=np.float32)
+        F = np.zeros(9, dtype=np.float32)
+        assert self.lib.vso_compute_fundamental(_p(p1_set, C.c_float), _p(p2_set, C.c_float), p1_set.shape[0], _p(F, C.c_float)) == 0
+        return F
+
+    def residual(self, p1, p2, pairs, F, thr):
+        p1 = np.ascontiguousarray(p1, dtype=np.float32); p2 = np.ascontiguousarray(p2, dtype=np.float32)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32); F = np.ascontiguousarray(F, dtype=np.float32)
+        m = pairs.shape[0]
+        mask = np.zeros(max(m, 1), dtype=np.uint8)
+        cnt = C.c_int32(); s = C.c_float()
+        assert self.lib.vso_fundamental_residual(_p(p1, C.c_float), _p(p2, C.c_float), _p(pairs, C.c_int32), m,
+                                                 _p(F, C.c_float), C.c_float(thr), _p(mask, C.c_uint8),
+                                                 C.byref(cnt), C.byref(s)) == 0
+        return mask[:m], cnt.value, np.float32(s.value)
+
+    def find_fundamental(self, p1, p2, pairs, sets, thr, want_all=True):
+        p1 = np.ascontiguousarray(p1, dtype=np.float32); p2 = np.ascontiguousarray(p2, dtype=np.float32)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32); sets = np.ascontiguousarray(sets, dtype=np.int32)
+        m, H = pairs.shape[0], sets.shape[0]
+        F = np.zeros(9, dtype=np.float32)
+        mask = np.zeros(max(m, 1), dtype=np.uint8)
+        bc = C.c_int32(); bs = C.c_float(); bi = C.c_int32()
+        allF = np.zeros((H, 9), dtype=np.float32); allc = np.zeros(H, dtype=np.int32); alls = np.zeros(H, dtype=np.float32)
+        assert self.lib.vso_find_fundamental(_p(p1, C.c_float), _p(p2, C.c_float), _p(pairs, C.c_int32), m,
+                                             _p(sets, C.c_int32), H, C.c_float(thr), _p(F, C.c_float),
+                                             _p(mask, C.c_uint8), C.byref(bc), C.byref(bs), C.byref(bi),
+                                             _p(allF, C.c_float) if want_all else None,
+                                             _p(allc, C.c_int32) if want_all else None,
+                                             _p(alls, C.c_float) if want_all else None) == 0
+        return dict(F=F, mask=mask[:m], count=bc.value, sum=np.float32(bs.value), winner=bi.value,
+                    hypF=allF, hyp_count=allc, hyp_sum=alls)
+
+    def match_features(self, xy1, d1, xy2, d2, seed, H, thr):
+        xy1 = np.ascontiguousarray(xy1, dtype=np.float32); xy2 = np.ascontiguousarray(xy2, dtype=np.float32)
+        d1 = np.ascontiguousarray(d1, dtype=np.uint8); d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+        n1, n2 = d1.shape[0], d2.shape[0]
+        out = np.zeros((max(n1, 1), 2), dtype=np.int32)
+        n = C.c_int32(); npre = C.c_int32()
+        F = np.zeros(9, dtype=np.float32)
+        rc = self.lib.vso_match_features(_p(xy1, C.c_float), _p(d1, C.c_uint8), n1, _p(xy2, C.c_float), _p(d2, C.c_uint8),
+                                         n2, C.c_uint32(seed & 0xFFFFFFFF), H, C.c_float(thr), _p(out, C.c_int32),
+                                         C.byref(n), _p(F, C.c_float), C.byref(npre))
+        return dict(rc=rc, matches=out[:n.value].copy(), F=F, prelim=npre.value)
+
+    # ------------------------------------------------------------ extraction
+    def bgr2gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        h, w, _ = bgr.shape
+        g = np.zeros((h, w), dtype=np.uint8)
+        assert self.lib.vso_bgr2gray(_p(bgr, C.c_uint8), w, h, 3 * w, _p(g, C.c_uint8)) == 0
+        return g
+
+    def min_eigen(self, gray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        e = np.zeros((h, w), dtype=np.float32)
+        assert self.lib.vso_min_eigen(_p(gray, C.c_uint8), w, h, _p(e, C.c_float)) == 0
+        return e
+
+    def good_features(self, gray, max_corners, quality=0.01, min_dist=3.0):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        xy = np.zeros((max_corners, 2), dtype=np.float32)
+        n = C.c_int32()
+        assert self.lib.vso_good_features(_p(gray, C.c_uint8), w, h, max_corners, C.c_double(quality),
+                                          C.c_double(min_dist), _p(xy, C.c_float), C.byref(n)) == 0
+        return xy[:n.value].copy()
+
+    def gaussian7(self, gray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        o = np.zeros((h, w), dtype=np.uint8)
+        assert self.lib.vso_gaussian7(_p(gray, C.c_uint8), w, h, _p(o, C.c_uint8)) == 0
+        return o
+
+    def orb_describe(self, blurred, xy, cos_a, sin_a, pattern):
+        blurred = np.ascontiguousarray(blurred, dtype=np.uint8)
+        xy = np.ascontiguousarray(xy, dtype=np.float32); pattern = np.ascontiguousarray(pattern, dtype=np.int8)
+        h, w = blurred.shape
+        n = xy.shape[0]
+        desc = np.zeros((max(n, 1), 32), dtype=np.uint8)
+        keep = np.zeros(max(n, 1), dtype=np.int32)
+        k = C.c_int32()
+        assert self.lib.vso_orb_describe(_p(blurred, C.c_uint8), w, h, _p(xy, C.c_float), n, C.c_float(cos_a),
+                                         C.c_float(sin_a), _p(pattern, C.c_int8), _p(desc, C.c_uint8),
+                                         _p(keep, C.c_int32), C.byref(k)) == 0
+        return desc[:k.value].copy(), keep[:k.value].copy()
+
+    def extract_features(self, bgr, max_corners, cos_a, sin_a, pattern):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8); pattern = np.ascontiguousarray(pattern, dtype=np.int8)
+        h, w, _ = bgr.shape
+        xy = np.zeros((max_corners, 2), dtype=np.float32)
+        desc = np.zeros((max_corners, 32), dtype=np.uint8)
+        kd = np.zeros(max_corners, dtype=np.int32)
+        n = C.c_int32(); nd = C.c_int32()
+        assert self.lib.vso_extract_features(_p(bgr, C.c_uint8), w, h, 3 * w, max_corners, C.c_float(cos_a),
+                                             C.c_float(sin_a), _p(pattern, C.c_int8), _p(xy, C.c_float),
+                                             _p(desc, C.c_uint8), _p(kd, C.c_int32), C.byref(n), C.byref(nd)) == 0
+        k = n.value
+        return dict(xy=xy[:k].copy(), desc=desc[:k].copy(), nodes=kd[:k].copy(), n=k, n_detected=nd.value)

@@ -1,0 +1,56 @@
+"""The C-ABI library builds, loads without a GPU, exports every symbol include/vslam_amd.h
+declares, and refuses to run without a device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vslam_amd import build, capi
+    build.build()
+    return capi.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vslam_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vslam_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from vslam_amd import capi
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vslam_amd.h but not exported"
+    assert sorted(capi.SYMBOLS) == names
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    h = ctypes.c_void_p()
+    assert lib.vslam_ctx_create(0, ctypes.byref(h)) == -3   # VSLAM_ERR_NO_DEVICE
+    from vslam_amd import Context, VslamError
+    with pytest.raises(VslamError):
+        Context(0)
+
+
+def test_product_does_not_reference_oracle():
+    """Nothing under vslam_amd/ or include/ may include, link or import the oracle."""
+    bad = []
+    for base in ("vslam_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".so", ".pyc")):
+                    continue
+                s = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r'#include\s+"[^"]*(vso|oracle)', s) or "liboracle" in s or "oracle_lib" in s:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,300 @@
+"""ctypes binding of include/vslam_amd.h for the Python harness (tests, bench.py, smoke()).
+
+Plumbing only: torch provides device memory and streams; every computation goes through the
+C ABI in libvslam_amd.so.  There is no fallback path: if the library is missing or no HIP device
+is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvslam_amd.so")
+
+OK = 0
+ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE",
+          -4: "VSLAM_ERR_CAPACITY", -5: "VSLAM_ERR_DEGENERATE"}
+
+# every symbol include/vslam_amd.h declares (tests/test_capi_symbols.py checks the header too)
+SYMBOLS = [
+    "vslam_ctx_create", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_synchronize",
+    "vslam_last_error", "vslam_version", "vslam_dev_alloc", "vslam_dev_free", "vslam_copy_h2d",
+    "vslam_copy_d2h", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
+    "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_kdtree_build",
+    "vslam_kdtree_radius", "vslam_extract_features", "vslam_bgr2gray", "vslam_min_eigen",
+    "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_match_features",
+    "vslam_frontend_pairs",
+]
+
+
+class ExtractParams(C.Structure):
+    _fields_ = [("max_corners", C.c_int32), ("quality", C.c_double), ("min_distance", C.c_double),
+                ("cos_a", C.c_float), ("sin_a", C.c_float), ("d_pattern", C.c_void_p)]
+
+
+class VslamError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise VslamError(
+            f"{path} is missing: run `python -m vslam_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.vslam_last_error.restype = C.c_char_p
+    lib.vslam_version.restype = C.c_char_p
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One vslam_ctx bound to a torch device/stream."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        rc = self.lib.vslam_ctx_create(C.c_int(device), C.byref(self.handle))
+        if rc != OK:
+            raise VslamError(f"vslam_ctx_create failed: {ERRORS.get(rc, rc)} (no HIP device? there is no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        if use_torch_stream:
+            s = torch.cuda.current_stream(self.device)
+            self._check(self.lib.vslam_ctx_set_stream(self.handle, C.c_void_p(s.cuda_stream)))
+
+    def close(self):
+        if self.handle:
+            self.lib.vslam_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            msg = self.lib.vslam_last_error(self.handle)
+            raise VslamError(f"{ERRORS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def _dev(self, t, dtype, name):
+        torch = self.torch
+        if t is None:
+            return None
+        if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+            raise VslamError(f"{name}: need a contiguous cuda tensor of {dtype}, got {t.dtype} on {t.device}")
+        return t
+
+    def synchronize(self):
+        self._check(self.lib.vslam_ctx_synchronize(self.handle))
+
+    # ---------------------------------------------------------------- profiling
+    def prof_enable(self, on=True):
+        self._check(self.lib.vslam_prof_enable(self.handle, C.c_int(1 if on else 0)))
+
+    def prof_reset(self):
+        self._check(self.lib.vslam_prof_reset(self.handle))
+
+    def prof_report(self):
+        n = self.lib.vslam_prof_count(self.handle)
+        if n < 0:
+            self._check(n)
+        out = {}
+        for i in range(n):
+            name = C.create_string_buffer(128)
+            ms = C.c_double()
+            cnt = C.c_int64()
+            self._check(self.lib.vslam_prof_get(self.handle, C.c_int(i), name, C.c_int(128), C.byref(ms), C.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+    # ---------------------------------------------------------------- stages
+    def match_knn2_ratio(self, desc1, n1, desc2, n2, want_knn=False):
+        torch = self.torch
+        B, K, _ = desc1.shape
+        self._dev(desc1, torch.uint8, "desc1"); self._dev(desc2, torch.uint8, "desc2")
+        self._dev(n1, torch.int32, "n1"); self._dev(n2, torch.int32, "n2")
+        pairs = torch.empty((B, K, 2), dtype=torch.int32, device=desc1.device)
+        m = torch.empty((B,), dtype=torch.int32, device=desc1.device)
+        knn = torch.empty((B, K, 4), dtype=torch.int32, device=desc1.device) if want_knn else None
+        self._check(self.lib.vslam_match_knn2_ratio(self.handle, _ptr(desc1), _ptr(n1), _ptr(desc2), _ptr(n2),
+                                                    C.c_int(B), C.c_int(K), _ptr(pairs), _ptr(m), _ptr(knn)))
+        return (pairs, m, knn) if want_knn else (pairs, m)
+
+    def ransac_sets(self, seeds, m, hyp):
+        torch = self.torch
+        B = seeds.shape[0]
+        self._dev(seeds, torch.int32, "seeds"); self._dev(m, torch.int32, "m")
+        sets = torch.empty((B, hyp, 8), dtype=torch.int32, device=seeds.device)
+        draws = torch.empty((B, hyp * 8), dtype=torch.int32, device=seeds.device)
+        self._check(self.lib.vslam_ransac_sets(self.handle, _ptr(seeds), _ptr(m), C.c_int(B), C.c_int(hyp),
+                                               _ptr(sets), _ptr(draws)))
+        return sets
+
+    def ransac_fundamental(self, xy1, xy2, pairs, m, sets, threshold):
+        torch = self.torch
+        B, K, _ = xy1.shape
+        H = sets.shape[1]
+        dev = xy1.device
+        for t, dt, nm in ((xy1, torch.float32, "xy1"), (xy2, torch.float32, "xy2"), (pairs, torch.int32, "pairs"),
+                          (m, torch.int32, "m"), (sets, torch.int32, "sets")):
+            self._dev(t, dt, nm)
+        out = dict(
+            F=torch.zeros((B, 9), dtype=torch.float32, device=dev),
+            mask=torch.zeros((B, K), dtype=torch.uint8, device=dev),
+            best=torch.zeros((B, 4), dtype=torch.int32, device=dev),
+            matches=torch.zeros((B, K, 2), dtype=torch.int32, device=dev),
+            hypF=torch.zeros((B, H, 9), dtype=torch.float32, device=dev),
+            hyp_count=torch.zeros((B, H), dtype=torch.int32, device=dev),
+            hyp_sum=torch.zeros((B, H), dtype=torch.float32, device=dev),
+        )
+        self._check(self.lib.vslam_ransac_fundamental(
+            self.handle, _ptr(xy1), _ptr(xy2), _ptr(pairs), _ptr(m), _ptr(sets), C.c_int(B), C.c_int(K),
+            C.c_int(H), C.c_float(threshold), _ptr(out["F"]), _ptr(out["mask"]), _ptr(out["best"]),
+            _ptr(out["matches"]), _ptr(out["hypF"]), _ptr(out["hyp_count"]), _ptr(out["hyp_sum"])))
+        return out
+
+    def kdtree_build(self, xy, n):
+        torch = self.torch
+        B, K, _ = xy.shape
+        self._dev(xy, torch.float32, "xy"); self._dev(n, torch.int32, "n")
+        nodes = torch.full((B, K), -1, dtype=torch.int32, device=xy.device)
+        self._check(self.lib.vslam_kdtree_build(self.handle, _ptr(xy), _ptr(n), C.c_int(B), C.c_int(K), _ptr(nodes)))
+        return nodes
+
+    def kdtree_radius(self, nodes, xy, n, queries, nq, radius, hit_cap=8):
+        torch = self.torch
+        B, K, _ = xy.shape
+        Q = queries.shape[1]
+        self._dev(nodes, torch.int32, "nodes"); self._dev(xy, torch.float32, "xy"); self._dev(n, torch.int32, "n")
+        self._dev(queries, torch.float32, "queries"); self._dev(nq, torch.int32, "nq")
+        hits = torch.full((B, Q, hit_cap), -1, dtype=torch.int32, device=xy.device)
+        counts = torch.zeros((B, Q), dtype=torch.int32, device=xy.device)
+        self._check(self.lib.vslam_kdtree_radius(self.handle, _ptr(nodes), _ptr(xy), _ptr(n), C.c_int(B), C.c_int(K),
+                                                 _ptr(queries), _ptr(nq), C.c_int(Q), C.c_float(radius),
+                                                 _ptr(hits), _ptr(counts), C.c_int(hit_cap)))
+        return hits, counts
+
+    def bgr2gray(self, bgr):
+        torch = self.torch
+        F, H, W, _ = bgr.shape
+        self._dev(bgr, torch.uint8, "bgr")
+        gray = torch.empty((F, H, W), dtype=torch.uint8, device=bgr.device)
+        self._check(self.lib.vslam_bgr2gray(self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H), C.c_int(3 * W), _ptr(gray)))
+        return gray
+
+    def min_eigen(self, gray):
+        torch = self.torch
+        F, H, W = gray.shape
+        self._dev(gray, torch.uint8, "gray")
+        eig = torch.empty((F, H, W), dtype=torch.float32, device=gray.device)
+        self._check(self.lib.vslam_min_eigen(self.handle, _ptr(gray), C.c_int(F), C.c_int(W), C.c_int(H), _ptr(eig)))
+        return eig
+
+    def good_features(self, gray, max_corners, quality=0.01, min_distance=3.0, kp_stride=None):
+        torch = self.torch
+        F, H, W = gray.shape
+        K = kp_stride or max_corners
+        self._dev(gray, torch.uint8, "gray")
+        xy = torch.zeros((F, K, 2), dtype=torch.float32, device=gray.device)
+        n = torch.zeros((F,), dtype=torch.int32, device=gray.device)
+        self._check(self.lib.vslam_good_features(self.handle, _ptr(gray), C.c_int(F), C.c_int(W), C.c_int(H),
+                                                 C.c_int(max_corners), C.c_double(quality), C.c_double(min_distance),
+                                                 C.c_int(K), _ptr(xy), _ptr(n)))
+        return xy, n
+
+    def gaussian7(self, gray):
+        torch = self.torch
+        F, H, W = gray.shape
+        self._dev(gray, torch.uint8, "gray")
+        out = torch.empty_like(gray)
+        self._check(self.lib.vslam_gaussian7(self.handle, _ptr(gray), C.c_int(F), C.c_int(W), C.c_int(H), _ptr(out)))
+        return out
+
+    def orb_describe(self, blurred, xy, n, cos_a, sin_a, pattern):
+        torch = self.torch
+        F, H, W = blurred.shape
+        K = xy.shape[1]
+        self._dev(blurred, torch.uint8, "blurred"); self._dev(xy, torch.float32, "xy"); self._dev(n, torch.int32, "n")
+        self._dev(pattern, torch.int8, "pattern")
+        xy_out = torch.zeros_like(xy)
+        desc = torch.zeros((F, K, 32), dtype=torch.uint8, device=xy.device)
+        n_out = torch.zeros_like(n)
+        self._check(self.lib.vslam_orb_describe(self.handle, _ptr(blurred), C.c_int(F), C.c_int(W), C.c_int(H),
+                                                _ptr(xy), _ptr(n), C.c_int(K), C.c_float(cos_a), C.c_float(sin_a),
+                                                _ptr(pattern), _ptr(xy_out), _ptr(desc), _ptr(n_out)))
+        return xy_out, desc, n_out
+
+    def _params(self, max_corners, cos_a, sin_a, pattern, quality=0.01, min_distance=3.0):
+        p = ExtractParams()
+        p.max_corners = max_corners
+        p.quality = quality
+        p.min_distance = min_distance
+        p.cos_a = cos_a
+        p.sin_a = sin_a
+        p.d_pattern = pattern.data_ptr()
+        return p
+
+    def extract_features(self, bgr, max_corners, cos_a, sin_a, pattern, kp_stride=None, out=None):
+        torch = self.torch
+        F, H, W, _ = bgr.shape
+        K = kp_stride or max_corners
+        self._dev(bgr, torch.uint8, "bgr"); self._dev(pattern, torch.int8, "pattern")
+        dev = bgr.device
+        if out is None:
+            out = dict(xy=torch.zeros((F, K, 2), dtype=torch.float32, device=dev),
+                       desc=torch.zeros((F, K, 32), dtype=torch.uint8, device=dev),
+                       nodes=torch.full((F, K), -1, dtype=torch.int32, device=dev),
+                       n=torch.zeros((F,), dtype=torch.int32, device=dev),
+                       n_detected=torch.zeros((F,), dtype=torch.int32, device=dev))
+        p = self._params(max_corners, cos_a, sin_a, pattern)
+        self._check(self.lib.vslam_extract_features(self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H),
+                                                    C.c_int(3 * W), C.byref(p), C.c_int(K), _ptr(out["xy"]),
+                                                    _ptr(out["desc"]), _ptr(out["nodes"]), _ptr(out["n"]),
+                                                    _ptr(out["n_detected"])))
+        return out
+
+    def match_features(self, xy1, desc1, n1, xy2, desc2, n2, seeds, hyp, threshold, out=None):
+        torch = self.torch
+        B, K, _ = xy1.shape
+        dev = xy1.device
+        if out is None:
+            out = dict(matches=torch.zeros((B, K, 2), dtype=torch.int32, device=dev),
+                       best=torch.zeros((B, 4), dtype=torch.int32, device=dev),
+                       F=torch.zeros((B, 9), dtype=torch.float32, device=dev),
+                       prelim_m=torch.zeros((B,), dtype=torch.int32, device=dev))
+        self._check(self.lib.vslam_match_features(
+            self.handle, _ptr(xy1), _ptr(desc1), _ptr(n1), _ptr(xy2), _ptr(desc2), _ptr(n2), C.c_int(B), C.c_int(K),
+            _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"]),
+            _ptr(out["prelim_m"])))
+        return out
+
+    def frontend_pairs(self, bgr, pairs, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, kp_stride=None, out=None):
+        torch = self.torch
+        F, H, W, _ = bgr.shape
+        assert F == 2 * pairs
+        K = kp_stride or max_corners
+        dev = bgr.device
+        if out is None:
+            out = dict(xy=torch.zeros((F, K, 2), dtype=torch.float32, device=dev),
+                       desc=torch.zeros((F, K, 32), dtype=torch.uint8, device=dev),
+                       nodes=torch.full((F, K), -1, dtype=torch.int32, device=dev),
+                       n=torch.zeros((F,), dtype=torch.int32, device=dev),
+                       matches=torch.zeros((pairs, K, 2), dtype=torch.int32, device=dev),
+                       best=torch.zeros((pairs, 4), dtype=torch.int32, device=dev),
+                       F=torch.zeros((pairs, 9), dtype=torch.float32, device=dev))
+        p = self._params(max_corners, cos_a, sin_a, pattern)
+        self._check(self.lib.vslam_frontend_pairs(
+            self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K),
+            _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out["nodes"]),
+            _ptr(out["n"]), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"])))
+        return out

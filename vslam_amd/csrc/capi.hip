@@ -1,0 +1,357 @@
+// C ABI (include/vslam_amd.h): context, memory, event timing, and the entry points that chain
+// the stage launchers.  No CPU fallback anywhere: every entry point needs a live HIP device.
+#include "ctx.h"
+
+#include <cstring>
+
+// ------------------------------------------------------------------------------------------
+// arena + profiling helpers
+// ------------------------------------------------------------------------------------------
+int vs_arena_get(vslam_ctx *ctx, const char *name, size_t bytes, void **out) {
+    vslam_ctx::Buf &buf = ctx->arena[name];
+    if (buf.bytes < bytes) {
+        if (buf.ptr) {
+            // the old block may still be in use by queued kernels
+            VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            VS_HIP(ctx, hipFree(buf.ptr));
+            buf.ptr = nullptr;
+            buf.bytes = 0;
+        }
+        VS_HIP(ctx, hipMalloc(&buf.ptr, bytes));
+        buf.bytes = bytes;
+    }
+    *out = buf.ptr;
+    return VSLAM_OK;
+}
+
+static hipEvent_t vs_event_take(vslam_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+VsProfScope::VsProfScope(vslam_ctx *c, const char *name) : ctx(c), active(c && c->prof) {
+    if (!active) return;
+    auto it = ctx->prof_index.find(name);
+    if (it == ctx->prof_index.end()) {
+        p.slot = (int)ctx->prof_slots.size();
+        ctx->prof_index[name] = p.slot;
+        vslam_prof_slot s;
+        s.name = name;
+        ctx->prof_slots.push_back(s);
+    } else {
+        p.slot = it->second;
+    }
+    p.start = vs_event_take(ctx);
+    p.stop = vs_event_take(ctx);
+    (void)hipEventRecord(p.start, ctx->stream);
+}
+
+VsProfScope::~VsProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(p.stop, ctx->stream);
+    ctx->prof_pending.push_back(p);
+}
+
+static int vs_prof_fold(vslam_ctx *ctx) {
+    if (ctx->prof_pending.empty()) return VSLAM_OK;
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0;
+        VS_HIP(ctx, hipEventElapsedTime(&ms, p.start, p.stop));
+        ctx->prof_slots[p.slot].total_ms += ms;
+        ctx->prof_slots[p.slot].launches += 1;
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->prof_pending.clear();
+    return VSLAM_OK;
+}
+
+extern "C" {
+
+const char *vslam_version(void) { return "vslam_amd 0.1 (gfx950)"; }
+
+int vslam_ctx_create(int device, vslam_ctx **out) {
+    if (!out) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return VSLAM_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return VSLAM_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return VSLAM_ERR_HIP;
+    vslam_ctx *ctx = new vslam_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return VSLAM_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_destroy(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->arena)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (auto &p : ctx->prof_pending) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VSLAM_OK;
+}
+
+int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->stream = nullptr;
+        ctx->own_stream = false;
+    }
+    if (hip_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    } else {
+        VS_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return VSLAM_OK;
+}
+
+int vslam_ctx_synchronize(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VSLAM_OK;
+}
+
+const char *vslam_last_error(vslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vslam_dev_alloc(vslam_ctx *ctx, size_t bytes, void **d_out) {
+    VS_REQUIRE(ctx, ctx && d_out, VSLAM_ERR_INVALID);
+    VS_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
+    return VSLAM_OK;
+}
+int vslam_dev_free(vslam_ctx *ctx, void *d_ptr) {
+    VS_REQUIRE(ctx, ctx, VSLAM_ERR_INVALID);
+    if (d_ptr) VS_HIP(ctx, hipFree(d_ptr));
+    return VSLAM_OK;
+}
+int vslam_copy_h2d(vslam_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    VS_REQUIRE(ctx, ctx && (bytes == 0 || (d_dst && h_src)), VSLAM_ERR_INVALID);
+    if (bytes) {
+        VS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return VSLAM_OK;
+}
+int vslam_copy_d2h(vslam_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    VS_REQUIRE(ctx, ctx && (bytes == 0 || (h_dst && d_src)), VSLAM_ERR_INVALID);
+    if (bytes) {
+        VS_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return VSLAM_OK;
+}
+
+int vslam_prof_enable(vslam_ctx *ctx, int on) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    int rc = vs_prof_fold(ctx);
+    ctx->prof = on != 0;
+    return rc;
+}
+int vslam_prof_reset(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    int rc = vs_prof_fold(ctx);
+    for (auto &s : ctx->prof_slots) {
+        s.total_ms = 0;
+        s.launches = 0;
+    }
+    return rc;
+}
+int vslam_prof_count(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    int rc = vs_prof_fold(ctx);
+    if (rc) return rc;
+    return (int)ctx->prof_slots.size();
+}
+int vslam_prof_get(vslam_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *launches) {
+    if (!ctx || i < 0 || i >= (int)ctx->prof_slots.size()) return VSLAM_ERR_INVALID;
+    const vslam_prof_slot &s = ctx->prof_slots[i];
+    if (name && name_cap > 0) {
+        std::strncpy(name, s.name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = s.total_ms;
+    if (launches) *launches = s.launches;
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage entry points
+// ------------------------------------------------------------------------------------------
+int vslam_match_knn2_ratio(vslam_ctx *ctx, const uint8_t *d_desc1, const int32_t *d_n1,
+                           const uint8_t *d_desc2, const int32_t *d_n2, int batch, int kp_stride,
+                           int32_t *d_pairs, int32_t *d_m, int32_t *d_knn) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_match(ctx, d_desc1, d_n1, d_desc2, d_n2, batch, kp_stride, d_pairs, d_m, d_knn);
+}
+
+int vslam_ransac_sets(vslam_ctx *ctx, const uint32_t *d_seeds, const int32_t *d_m, int batch, int hyp,
+                      int32_t *d_sets, uint32_t *d_draw_scratch) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_ransac_sets(ctx, d_seeds, d_m, batch, hyp, d_sets, d_draw_scratch);
+}
+
+int vslam_ransac_fundamental(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2,
+                             const int32_t *d_pairs, const int32_t *d_m, const int32_t *d_sets,
+                             int batch, int kp_stride, int hyp, float threshold, float *d_F,
+                             uint8_t *d_mask, int32_t *d_best, int32_t *d_matches, float *d_hypF,
+                             int32_t *d_hyp_count, float *d_hyp_sum) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_ransac(ctx, d_xy1, d_xy2, d_pairs, d_m, d_sets, batch, kp_stride, hyp, threshold,
+                            d_F, d_mask, d_best, d_matches, d_hypF, d_hyp_count, d_hyp_sum);
+}
+
+int vslam_kdtree_build(vslam_ctx *ctx, const float *d_xy, const int32_t *d_n, int batch, int kp_stride,
+                       int32_t *d_nodes) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_kdtree_build(ctx, d_xy, d_n, batch, kp_stride, d_nodes);
+}
+
+int vslam_kdtree_radius(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_xy, const int32_t *d_n,
+                        int batch, int kp_stride, const float *d_queries, const int32_t *d_nq,
+                        int q_stride, float radius, int32_t *d_hits, int32_t *d_counts, int hit_cap) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_kdtree_radius(ctx, d_nodes, d_xy, d_n, batch, kp_stride, d_queries, d_nq, q_stride,
+                                   radius, d_hits, d_counts, hit_cap);
+}
+
+int vslam_bgr2gray(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
+                   int row_stride, uint8_t *d_gray) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_bgr2gray(ctx, d_bgr, frames, width, height, row_stride, d_gray);
+}
+
+int vslam_min_eigen(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int width, int height,
+                    float *d_eig) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_min_eigen(ctx, d_gray, frames, width, height, d_eig, nullptr);
+}
+
+int vslam_good_features(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int width, int height,
+                        int max_corners, double quality, double min_distance, int kp_stride,
+                        float *d_xy, int32_t *d_n) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_good_features(ctx, d_gray, frames, width, height, max_corners, quality,
+                                   min_distance, kp_stride, d_xy, d_n);
+}
+
+int vslam_gaussian7(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int width, int height,
+                    uint8_t *d_out) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_gaussian7(ctx, d_gray, frames, width, height, d_out);
+}
+
+int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int width, int height,
+                       const float *d_xy_in, const int32_t *d_n_in, int kp_stride, float cos_a,
+                       float sin_a, const int8_t *d_pattern, float *d_xy_out, uint8_t *d_desc,
+                       int32_t *d_n_out) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_orb_describe(ctx, d_blurred, frames, width, height, d_xy_in, d_n_in, kp_stride,
+                                  cos_a, sin_a, d_pattern, d_xy_out, d_desc, d_n_out);
+}
+
+// extract_features(Frame&), src/Frame.cpp:53-80
+int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
+                           int row_stride, const vslam_extract_params *params, int kp_stride,
+                           float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                           int32_t *d_n_detected) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, d_bgr && params && d_xy && d_desc && d_n, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, params->d_pattern, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, params->max_corners > 0 && params->max_corners <= kp_stride, VSLAM_ERR_INVALID);
+    const size_t px = (size_t)frames * width * height;
+    uint8_t *gray = nullptr, *blur = nullptr;
+    float *xy_det = nullptr;
+    int32_t *n_det = nullptr;
+    int rc;
+    if ((rc = vs_arena_get(ctx, "extract.gray", px, (void **)&gray))) return rc;
+    if ((rc = vs_arena_get(ctx, "extract.blur", px, (void **)&blur))) return rc;
+    if ((rc = vs_arena_get(ctx, "extract.xy_det", sizeof(float) * 2 * (size_t)frames * kp_stride, (void **)&xy_det))) return rc;
+    if (d_n_detected) n_det = d_n_detected;
+    else if ((rc = vs_arena_get(ctx, "extract.n_det", sizeof(int32_t) * (size_t)frames, (void **)&n_det))) return rc;
+
+    if ((rc = vs_launch_bgr2gray(ctx, d_bgr, frames, width, height, row_stride, gray))) return rc;      // :56
+    if ((rc = vs_launch_good_features(ctx, gray, frames, width, height, params->max_corners,             // :61
+                                      params->quality, params->min_distance, kp_stride, xy_det, n_det)))
+        return rc;
+    if ((rc = vs_launch_gaussian7(ctx, gray, frames, width, height, blur))) return rc;                   // ORB::compute
+    if ((rc = vs_launch_orb_describe(ctx, blur, frames, width, height, xy_det, n_det, kp_stride,         // :68-72
+                                     params->cos_a, params->sin_a, params->d_pattern, d_xy, d_desc, d_n)))
+        return rc;
+    if (d_nodes)
+        if ((rc = vs_launch_kdtree_build(ctx, d_xy, d_n, frames, kp_stride, d_nodes))) return rc;       // :76
+    return VSLAM_OK;
+}
+
+// match_features, src/Frame.cpp:82-105
+int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_desc1,
+                         const int32_t *d_n1, const float *d_xy2, const uint8_t *d_desc2,
+                         const int32_t *d_n2, int batch, int kp_stride, const uint32_t *d_seeds,
+                         int hyp, float threshold, int32_t *d_matches, int32_t *d_best, float *d_F,
+                         int32_t *d_prelim_m) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, d_xy1 && d_desc1 && d_n1 && d_xy2 && d_desc2 && d_n2 && d_seeds, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, d_matches && d_best && d_F, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && hyp > 0, VSLAM_ERR_INVALID);
+    int32_t *pairs = nullptr, *m = nullptr, *sets = nullptr, *hyp_count = nullptr;
+    uint32_t *draws = nullptr;
+    float *hypF = nullptr, *hyp_sum = nullptr;
+    uint8_t *mask = nullptr;
+    int rc;
+    const size_t bk = (size_t)batch * kp_stride, bh = (size_t)batch * hyp;
+    if ((rc = vs_arena_get(ctx, "mf.pairs", sizeof(int32_t) * 2 * bk, (void **)&pairs))) return rc;
+    if (d_prelim_m) m = d_prelim_m;
+    else if ((rc = vs_arena_get(ctx, "mf.m", sizeof(int32_t) * (size_t)batch, (void **)&m))) return rc;
+    if ((rc = vs_arena_get(ctx, "mf.sets", sizeof(int32_t) * 8 * bh, (void **)&sets))) return rc;
+    if ((rc = vs_arena_get(ctx, "mf.draws", sizeof(uint32_t) * 8 * bh, (void **)&draws))) return rc;
+    if ((rc = vs_arena_get(ctx, "mf.hypF", sizeof(float) * 9 * bh, (void **)&hypF))) return rc;
+    if ((rc = vs_arena_get(ctx, "mf.hyp_count", sizeof(int32_t) * bh, (void **)&hyp_count))) return rc;
+    if ((rc = vs_arena_get(ctx, "mf.hyp_sum", sizeof(float) * bh, (void **)&hyp_sum))) return rc;
+    if ((rc = vs_arena_get(ctx, "mf.mask", bk, (void **)&mask))) return rc;
+
+    if ((rc = vs_launch_match(ctx, d_desc1, d_n1, d_desc2, d_n2, batch, kp_stride, pairs, m, nullptr))) return rc;
+    if ((rc = vs_launch_ransac_sets(ctx, d_seeds, m, batch, hyp, sets, draws))) return rc;
+    return vs_launch_ransac(ctx, d_xy1, d_xy2, pairs, m, sets, batch, kp_stride, hyp, threshold, d_F, mask,
+                            d_best, d_matches, hypF, hyp_count, hyp_sum);
+}
+
+// extract both frames of every pair, then match_features on (frame p, frame pairs + p)
+int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int width, int height,
+                         int row_stride, const vslam_extract_params *params, int kp_stride,
+                         const uint32_t *d_seeds, int hyp, float threshold, float *d_xy,
+                         uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches,
+                         int32_t *d_best, float *d_F) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, pairs > 0, VSLAM_ERR_INVALID);
+    int rc = vslam_extract_features(ctx, d_bgr, 2 * pairs, width, height, row_stride, params, kp_stride,
+                                    d_xy, d_desc, d_nodes, d_n, nullptr);
+    if (rc) return rc;
+    const size_t half = (size_t)pairs * kp_stride;
+    return vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * half, d_desc + VSLAM_DESC_BYTES * half,
+                                d_n + pairs, pairs, kp_stride, d_seeds, hyp, threshold, d_matches, d_best,
+                                d_F, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// Context, error plumbing, workspace arena and per-kernel event timing shared by the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vslam_amd.h"
+
+struct vslam_prof_pending {
+    int slot;
+    hipEvent_t start, stop;
+};
+
+struct vslam_prof_slot {
+    std::string name;
+    double total_ms = 0;
+    int64_t launches = 0;
+};
+
+struct vslam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // named, grow-only device buffers (never allocated inside a timed loop after warm-up)
+    struct Buf {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<std::string, Buf> arena;
+
+    bool prof = false;
+    std::vector<vslam_prof_slot> prof_slots;
+    std::map<std::string, int> prof_index;
+    std::vector<vslam_prof_pending> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+#define VS_HIP(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                \
+            return VSLAM_ERR_HIP;                                                           \
+        }                                                                                   \
+    } while (0)
+
+#define VS_REQUIRE(ctx, cond, code)                                                         \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            if (ctx) (ctx)->err = std::string("requirement failed: ") + #cond;              \
+            return (code);                                                                  \
+        }                                                                                   \
+    } while (0)
+
+// grow-only named workspace
+int vs_arena_get(vslam_ctx *ctx, const char *name, size_t bytes, void **out);
+
+// event bracket around one kernel launch when profiling is on
+struct VsProfScope {
+    vslam_ctx *ctx;
+    vslam_prof_pending p;
+    bool active;
+    VsProfScope(vslam_ctx *c, const char *name);
+    ~VsProfScope();
+};
+
+static inline int vs_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- stage launchers implemented in the .hip files (all async on ctx->stream) ----
+int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const uint8_t *d2,
+                    const int32_t *n2, int batch, int kp_stride, int32_t *pairs, int32_t *m,
+                    int32_t *knn);
+int vs_launch_ransac_sets(vslam_ctx *ctx, const uint32_t *seeds, const int32_t *m, int batch, int hyp,
+                          int32_t *sets, uint32_t *draws);
+int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
+                     const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
+                     float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,
+                     float *hypF, int32_t *hyp_count, float *hyp_sum);
+int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, int batch, int kp_stride,
+                           int32_t *nodes);
+int vs_launch_kdtree_radius(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n,
+                            int batch, int kp_stride, const float *queries, const int32_t *nq,
+                            int q_stride, float radius, int32_t *hits, int32_t *counts, int hit_cap);
+int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, int h, int stride,
+                       uint8_t *gray);
+int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, float *eig,
+                        uint32_t *frame_max_bits);
+int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h,
+                            int max_corners, double quality, double min_distance, int kp_stride,
+                            float *xy, int32_t *n);
+int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, uint8_t *out);
+int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, int w, int h,
+                           const float *xy_in, const int32_t *n_in, int kp_stride, float ca, float sa,
+                           const int8_t *pattern, float *xy_out, uint8_t *desc, int32_t *n_out);

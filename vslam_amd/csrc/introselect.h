@@ -1,0 +1,168 @@
+// Position-exact re-implementation of libstdc++'s std::nth_element (GCC 11 introselect) over an
+// abstract random-access store, usable from host and device code.
+//
+// Why: the reference builds its k-d trees with std::nth_element (src/KDTree.cpp:10,12,128).
+// Keypoint coordinates are integer-valued, so ties on the split axis are the norm, and which of
+// the tied points lands left/right of the median — and in what order, which steers every deeper
+// split — is decided by the exact sequence of swaps introselect performs.  To emit a tree that is
+// bit-identical to the reference's, the device has to replay that sequence:
+//   median-of-three to *first (first+1, mid, last-1), unguarded Hoare partition around *first,
+//   keep the side holding nth, depth limit 2*floor(lg n) then heap-select, insertion sort for
+//   ranges of <= 3 elements.
+// tests/test_introselect.py compiles this header for the host and checks the final permutation
+// against the platform's std::nth_element on tie-heavy and adversarial inputs.
+//
+// Store concept:  struct S { using value_type = ...;
+//   value_type get(int i) const; void set(int i, const value_type&); void swap(int i, int j);
+//   bool less(const value_type& a, const value_type& b) const; }
+#pragma once
+
+#ifdef __HIPCC__
+#define VS_HD __host__ __device__
+#else
+#define VS_HD
+#endif
+
+// test hook: lets the host check count how often the depth-limit fallback ran
+#ifndef VS_SEL_ON_HEAP_SELECT
+#define VS_SEL_ON_HEAP_SELECT()
+#endif
+
+namespace vs_sel {
+
+VS_HD inline int floor_lg(int n) {   // std::__lg
+    int k = 0;
+    while (n > 1) {
+        n >>= 1;
+        k++;
+    }
+    return k;
+}
+
+template <class S>
+VS_HD inline void move_median_to_first(S &s, int result, int a, int b, int c) {
+    const auto va = s.get(a), vb = s.get(b), vc = s.get(c);
+    if (s.less(va, vb)) {
+        if (s.less(vb, vc)) s.swap(result, b);
+        else if (s.less(va, vc)) s.swap(result, c);
+        else s.swap(result, a);
+    } else if (s.less(va, vc)) s.swap(result, a);
+    else if (s.less(vb, vc)) s.swap(result, c);
+    else s.swap(result, b);
+}
+
+template <class S>
+VS_HD inline int unguarded_partition(S &s, int first, int last, int pivot) {
+    const auto pv = s.get(pivot);   // *pivot is never moved by the swaps below (pivot < first)
+    while (true) {
+        while (s.less(s.get(first), pv)) ++first;
+        --last;
+        while (s.less(pv, s.get(last))) --last;
+        if (!(first < last)) return first;
+        s.swap(first, last);
+        ++first;
+    }
+}
+
+template <class S>
+VS_HD inline int unguarded_partition_pivot(S &s, int first, int last) {
+    const int mid = first + (last - first) / 2;
+    move_median_to_first(s, first, first + 1, mid, last - 1);
+    return unguarded_partition(s, first + 1, last, first);
+}
+
+template <class S>
+VS_HD inline void insertion_sort(S &s, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        const auto val = s.get(i);
+        if (s.less(val, s.get(first))) {
+            for (int k = i; k > first; --k) s.set(k, s.get(k - 1));   // move_backward
+            s.set(first, val);
+        } else {   // __unguarded_linear_insert
+            int hole = i, next = i - 1;
+            while (s.less(val, s.get(next))) {
+                s.set(hole, s.get(next));
+                hole = next;
+                --next;
+            }
+            s.set(hole, val);
+        }
+    }
+}
+
+// heap helpers operate on [first, first+len) with indices relative to first
+template <class S, class V>
+VS_HD inline void push_heap_rel(S &s, int first, int hole, int top, const V &value) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && s.less(s.get(first + parent), value)) {
+        s.set(first + hole, s.get(first + parent));
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    s.set(first + hole, value);
+}
+
+template <class S, class V>
+VS_HD inline void adjust_heap(S &s, int first, int hole, int len, const V &value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (s.less(s.get(first + child), s.get(first + child - 1))) child--;
+        s.set(first + hole, s.get(first + child));
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        s.set(first + hole, s.get(first + child - 1));
+        hole = child - 1;
+    }
+    push_heap_rel(s, first, hole, top, value);
+}
+
+template <class S>
+VS_HD inline void make_heap(S &s, int first, int last) {
+    const int len = last - first;
+    if (len < 2) return;
+    int parent = (len - 2) / 2;
+    while (true) {
+        const auto v = s.get(first + parent);
+        adjust_heap(s, first, parent, len, v);
+        if (parent == 0) return;
+        parent--;
+    }
+}
+
+template <class S>
+VS_HD inline void heap_select(S &s, int first, int middle, int last) {
+    make_heap(s, first, middle);
+    for (int i = middle; i < last; ++i)
+        if (s.less(s.get(i), s.get(first))) {   // __pop_heap(first, middle, i)
+            const auto v = s.get(i);
+            s.set(i, s.get(first));
+            adjust_heap(s, first, 0, middle - first, v);
+        }
+}
+
+// std::nth_element(first, nth, last)
+template <class S>
+VS_HD inline void nth_element(S &s, int first, int nth, int last) {
+    if (first == last || nth == last) return;
+    int depth_limit = floor_lg(last - first) * 2;
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            VS_SEL_ON_HEAP_SELECT();
+            heap_select(s, first, nth + 1, last);
+            s.swap(first, nth);
+            return;
+        }
+        --depth_limit;
+        const int cut = unguarded_partition_pivot(s, first, last);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    insertion_sort(s, first, last);
+}
+
+}  // namespace vs_sel

@@ -1,0 +1,184 @@
+// 2-D k-d tree for gfx950: batched build and batched radius query.
+//
+// Replaces construct_kdtree(frame_kdtree&, points) (/root/reference/src/KDTree.cpp:107-143) and
+// radius_search(frame_kdtree, points, query, radius) (:145-171).
+//
+// Layout: the reference appends nodes to one malloc'd array before recursing, so that array is
+// the tree in PRE-ORDER, and because the split is always at l + len/2 the shape depends on n
+// only: a subtree of len nodes at position p has its left child at p+1 (len/2 nodes) and its
+// right child at p+1+len/2 (len - len/2 - 1 nodes).  The device tree is therefore just the
+// pt_index column, int32 [n] — 4 B/node instead of 24 — and child links are arithmetic.
+//
+// Build: one workgroup per frame.  (x, y, index) triples live in LDS; the recursion is run level
+// by level (all subtrees of one depth are independent), one lane per subtree, each lane replaying
+// libstdc++'s introselect step for step (introselect.h) so tied coordinates land exactly where
+// std::nth_element puts them.  The top levels are serial by nature (depth 0 is one 2000-element
+// selection); 512 frames per batch keep the other CUs busy.
+//
+// Query: one lane per query, explicit stack in LDS, hits appended in visit order (node, left,
+// right), which is the order vslam.cpp:150-158 observes through its `break`.
+#include "ctx.h"
+#include "introselect.h"
+
+namespace {
+
+constexpr int kBuildThreads = 256;
+
+struct Triple {
+    float x, y;
+    int id;
+};
+
+struct LdsStore {
+    using value_type = Triple;
+    float *kx, *ky;
+    int *id;
+    int axis;
+    __device__ Triple get(int i) const { return Triple{kx[i], ky[i], id[i]}; }
+    __device__ void set(int i, const Triple &t) {
+        kx[i] = t.x;
+        ky[i] = t.y;
+        id[i] = t.id;
+    }
+    __device__ void swap(int i, int j) {
+        const Triple a = get(i), b = get(j);
+        set(i, b);
+        set(j, a);
+    }
+    // P(points[i1], axis) < P(points[i2], axis), src/KDTree.cpp:128
+    __device__ bool less(const Triple &a, const Triple &b) const {
+        return axis == 0 ? (a.x < b.x) : (a.y < b.y);
+    }
+};
+
+__global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float *__restrict__ xy,
+                                                                     const int32_t *__restrict__ n_arr,
+                                                                     int kp_stride,
+                                                                     int32_t *__restrict__ nodes) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = n_arr[b];
+    if (n <= 0) return;   // root = NULL, src/KDTree.cpp:109-110
+    float *kx = reinterpret_cast<float *>(smem);
+    float *ky = kx + kp_stride;
+    int *id = reinterpret_cast<int *>(ky + kp_stride);
+    const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)b * kp_stride;
+    int32_t *out = nodes + (size_t)b * kp_stride;
+    for (int i = tid; i < n; i += kBuildThreads) {
+        const float2 p = P[i];
+        kx[i] = p.x;
+        ky[i] = p.y;
+        id[i] = i;   // point_indices = 0..N-1, :113-117
+    }
+    __syncthreads();
+
+    int height = 0;
+    for (int t = n; t > 0; t >>= 1) height++;   // floor(log2 n) + 1, :119
+    for (int depth = 0; depth < height; depth++) {
+        const int tasks = 1 << depth;
+        for (int t = tid; t < tasks; t += kBuildThreads) {
+            int first = 0, last = n, pos = 0;
+            for (int bit = depth - 1; bit >= 0 && last > first; bit--) {
+                const int len = last - first, mid = first + len / 2;
+                if ((t >> bit) & 1) {
+                    pos += 1 + len / 2;
+                    first = mid + 1;
+                } else {
+                    pos += 1;
+                    last = mid;
+                }
+            }
+            if (last > first) {
+                LdsStore s{kx, ky, id, depth & 1};
+                const int mid = first + (last - first) / 2;
+                vs_sel::nth_element(s, first, mid, last);
+                out[pos] = id[mid];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int kQueryThreads = 256;
+constexpr int kStackDepth = 18;
+
+__global__ __launch_bounds__(kQueryThreads) void kdtree_radius_kernel(
+    const int32_t *__restrict__ nodes, const float *__restrict__ xy, const int32_t *__restrict__ n_arr,
+    int kp_stride, const float *__restrict__ queries, const int32_t *__restrict__ nq_arr, int q_stride,
+    float radius, int32_t *__restrict__ hits, int32_t *__restrict__ counts, int hit_cap) {
+    __shared__ uint32_t stack[kStackDepth * kQueryThreads];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int q = blockIdx.x * kQueryThreads + tid;
+    const int n = n_arr[b];
+    if (q >= nq_arr[b]) return;
+    const float2 qp = reinterpret_cast<const float2 *>(queries)[(size_t)b * q_stride + q];
+    const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)b * kp_stride;
+    const int32_t *T = nodes + (size_t)b * kp_stride;
+    int32_t *H = hits + ((size_t)b * q_stride + q) * hit_cap;
+    const float radius_sq = radius * radius;   // SQ(radius), :146
+
+    int cnt = 0, sp = 0;
+    // stack entry: pos (15 bits) | len (15 bits) << 15 | axis << 30
+    if (n > 0) stack[(sp++) * kQueryThreads + tid] = 0u | ((uint32_t)n << 15);
+    while (sp > 0) {
+        const uint32_t e = stack[(--sp) * kQueryThreads + tid];
+        const int pos = (int)(e & 0x7FFFu), len = (int)((e >> 15) & 0x7FFFu), axis = (int)(e >> 30);
+        const int idx = T[pos];
+        const float2 pt = P[idx];
+        const float split = (axis == 0 ? qp.x : qp.y) - (axis == 0 ? pt.x : pt.y);   // :156
+        const int nl = len / 2, nr = len - nl - 1;
+        const uint32_t nax = (uint32_t)(1 - axis) << 30;
+        const uint32_t le = (uint32_t)(pos + 1) | ((uint32_t)nl << 15) | nax;
+        const uint32_t re = (uint32_t)(pos + 1 + nl) | ((uint32_t)nr << 15) | nax;
+        const float abs_split = (split > 0) ? split : -split;   // ABS macro
+        if (abs_split <= radius) {                              // inclusive, :158
+            const float dx = qp.x - pt.x, dy = qp.y - pt.y;
+            const float d2 = dx * dx + dy * dy;
+            if (d2 < radius_sq) {                               // strict, :161
+                if (cnt < hit_cap) H[cnt] = idx;
+                cnt++;
+            }
+            if (nr > 0) stack[(sp++) * kQueryThreads + tid] = re;   // right is visited after left
+            if (nl > 0) stack[(sp++) * kQueryThreads + tid] = le;
+        } else if (split < 0) {
+            if (nl > 0) stack[(sp++) * kQueryThreads + tid] = le;
+        } else {
+            if (nr > 0) stack[(sp++) * kQueryThreads + tid] = re;
+        }
+    }
+    counts[(size_t)b * q_stride + q] = cnt;
+}
+
+}  // namespace
+
+int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, int batch, int kp_stride,
+                           int32_t *nodes) {
+    VS_REQUIRE(ctx, xy && n && nodes, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
+    const size_t lds = (size_t)kp_stride * 12;
+    VS_REQUIRE(ctx, lds <= 160 * 1024 - 512, VSLAM_ERR_CAPACITY);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kdtree_build_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        attr_set = true;
+    }
+    VsProfScope ps(ctx, "kdtree_build_kernel");
+    kdtree_build_kernel<<<batch, kBuildThreads, lds, ctx->stream>>>(xy, n, kp_stride, nodes);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_kdtree_radius(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n,
+                            int batch, int kp_stride, const float *queries, const int32_t *nq,
+                            int q_stride, float radius, int32_t *hits, int32_t *counts, int hit_cap) {
+    VS_REQUIRE(ctx, nodes && xy && n && queries && nq && hits && counts, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && q_stride > 0 && hit_cap > 0, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
+    VsProfScope ps(ctx, "kdtree_radius_kernel");
+    dim3 grid(vs_div_up(q_stride, kQueryThreads), batch);
+    kdtree_radius_kernel<<<grid, kQueryThreads, 0, ctx->stream>>>(nodes, xy, n, kp_stride, queries, nq,
+                                                                  q_stride, radius, hits, counts, hit_cap);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}

@@ -1,0 +1,718 @@
+// RANSAC fundamental-matrix loop for gfx950.
+//
+// Replaces RansacFilter (/root/reference/src/RansacFilter.cpp):
+//   initialize_sets              :6-34    -> ransac_sets_kernel   (mt19937 + Lemire, on device)
+//   compute_fundamental          :69-103  -> ransac_solve_kernel  (one lane per hypothesis)
+//   compute_fundamental_residual :105-140 -> ransac_score_kernel  (one lane per hypothesis,
+//                                            matches broadcast from LDS)
+//   find_fundamental             :36-67   -> ransac_select_kernel (argmax with the reference's
+//                                            sequential accept rule, winner's mask, and the
+//                                            inlier filter of src/Frame.cpp:96-102)
+//
+// Numerics: the reference's two cv::SVDecomp calls are OpenCV's one-sided Jacobi with double
+// accumulators and float rotations; the kernels execute the same operations in the same order
+// (no FMA contraction: the file is built with -ffp-contract=off; explicit fma() is used only
+// where the product of two floats is exact in double, which makes fma == mul+add bit for bit).
+// std::hypot is pinned to sqrt(p*p + beta*beta) on both sides.
+//
+// Why one lane per hypothesis: the per-hypothesis residual sum is a sequential double
+// accumulation whose value breaks inlier-count ties (RansacFilter.cpp:59,138).  A lane that
+// walks the matches in index order reproduces that sum exactly with no cross-lane reduction;
+// the match coordinates are the same for all 64 lanes, so LDS serves them as broadcasts.
+#include "ctx.h"
+
+#include <cfloat>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// initialize_sets
+// ------------------------------------------------------------------------------------------
+constexpr int kSetThreads = 256;
+constexpr int kMtN = 624, kMtM = 397;
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far) {
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7FFFFFFFu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9D2C5680u;
+    y ^= (y << 15) & 0xEFC60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// One workgroup per frame pair.  The 624-word state lives in LDS; a block of 624 outputs is
+// produced in three dependency phases (i < 227 | 227 <= i < 454 | i >= 454), then mapped to
+// draws with libstdc++'s uniform_int_distribution<int>(0, size-1) for a 32-bit URBG:
+// Lemire multiply-shift with rejection (bits/uniform_int_dist.h _S_nd).  A rejection shifts
+// every later draw by one raw output, so each block is resolved left to right: evaluate all
+// lanes under the current shift, find the first rejected raw output, finalise everything
+// before it, bump the shift, repeat (almost always zero iterations: p(reject) ~ n / 2^32).
+__global__ __launch_bounds__(kSetThreads) void ransac_sets_kernel(const uint32_t *__restrict__ seeds,
+                                                                  const int32_t *__restrict__ m_arr,
+                                                                  int hyp, int32_t *__restrict__ sets,
+                                                                  uint32_t *__restrict__ draws) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = m_arr[b];
+    int32_t *S = sets + (size_t)b * hyp * VSLAM_SET_SIZE;
+    uint32_t *D = draws + (size_t)b * hyp * VSLAM_SET_SIZE;
+    const int total = hyp * VSLAM_SET_SIZE;
+    if (n < VSLAM_SET_SIZE) {   // reference: UB (distribution over (0,-1)); defined here as zeros
+        for (int i = tid; i < total; i += kSetThreads) S[i] = 0;
+        return;
+    }
+
+    __shared__ uint32_t mt[kMtN];
+    __shared__ uint32_t out[kMtN];
+    __shared__ int s_first;
+
+    if (tid == 0) {   // std::mt19937(seed) seeding recurrence
+        uint32_t x = seeds[b];
+        mt[0] = x;
+        for (int i = 1; i < kMtN; i++) {
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+            mt[i] = x;
+        }
+    }
+    __syncthreads();
+
+    int raw_base = 0;   // raw outputs consumed before this block
+    int rej = 0;        // rejections so far (identical in every lane)
+    while (raw_base - rej < total) {
+        // ---- twist: three phases, each read -> barrier -> write -> barrier
+        {
+            uint32_t v = 0;
+            if (tid < kMtN - kMtM) v = mt_twist(mt[tid], mt[tid + 1], mt[tid + kMtM]);
+            __syncthreads();
+            if (tid < kMtN - kMtM) mt[tid] = v;
+            __syncthreads();
+            const int i1 = tid + (kMtN - kMtM);   // 227 .. 453
+            if (tid < kMtN - kMtM) v = mt_twist(mt[i1], mt[i1 + 1], mt[i1 - (kMtN - kMtM)]);
+            __syncthreads();
+            if (tid < kMtN - kMtM) mt[i1] = v;
+            __syncthreads();
+            const int i2 = tid + 2 * (kMtN - kMtM);   // 454 .. 623
+            if (i2 < kMtN) v = mt_twist(mt[i2], mt[i2 == kMtN - 1 ? 0 : i2 + 1], mt[i2 - (kMtN - kMtM)]);
+            __syncthreads();
+            if (i2 < kMtN) mt[i2] = v;
+            __syncthreads();
+        }
+        for (int i = tid; i < kMtN; i += kSetThreads) out[i] = mt_temper(mt[i]);
+        __syncthreads();
+
+        // ---- map raw outputs to draws, resolving rejections in order
+        int lo = 0;
+        while (true) {
+            if (tid == 0) s_first = 0x7FFFFFFF;
+            __syncthreads();
+            uint32_t res[3];
+            bool live[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int t = tid + r * kSetThreads;
+                live[r] = false;
+                res[r] = 0;
+                if (t < kMtN && t >= lo) {
+                    const int d = raw_base + t - rej;
+                    if (d < total) {
+                        const uint32_t range = (uint32_t)(n - (d & 7));
+                        const uint64_t prod = (uint64_t)out[t] * (uint64_t)range;
+                        const uint32_t low = (uint32_t)prod;
+                        bool rejected = false;
+                        if (low < range) {
+                            const uint32_t thr = (0u - range) % range;
+                            rejected = low < thr;
+                        }
+                        if (rejected) atomicMin(&s_first, t);
+                        live[r] = true;
+                        res[r] = (uint32_t)(prod >> 32);
+                    }
+                }
+            }
+            __syncthreads();
+            const int first = s_first;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int t = tid + r * kSetThreads;
+                if (live[r] && t < first) D[raw_base + t - rej] = res[r];
+            }
+            if (first == 0x7FFFFFFF) break;
+            rej += 1;
+            lo = first + 1;
+            __syncthreads();
+        }
+        raw_base += kMtN;
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- draws -> indices without replacement: available[r] = available.back(); pop_back()
+    // (RansacFilter.cpp:26-31) tracked as a <= 8-entry sparse overlay on the identity array.
+    for (int h = tid; h < hyp; h += kSetThreads) {
+        int pos[VSLAM_SET_SIZE], val[VSLAM_SET_SIZE];
+        int cnt = 0, size = n;
+#pragma unroll
+        for (int j = 0; j < VSLAM_SET_SIZE; j++) {
+            const int r = (int)D[(size_t)h * VSLAM_SET_SIZE + j];
+            int v = r, lv = size - 1, slot = -1;
+#pragma unroll
+            for (int k = 0; k < VSLAM_SET_SIZE; k++) {
+                if (k < cnt && pos[k] == r) {
+                    v = val[k];
+                    slot = k;
+                }
+                if (k < cnt && pos[k] == size - 1) lv = val[k];
+            }
+            S[(size_t)h * VSLAM_SET_SIZE + j] = v;
+            if (slot >= 0) {
+#pragma unroll
+                for (int k = 0; k < VSLAM_SET_SIZE; k++)
+                    if (k == slot) val[k] = lv;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VSLAM_SET_SIZE; k++)
+                    if (k == cnt) {
+                        pos[k] = r;
+                        val[k] = lv;
+                    }
+                cnt++;
+            }
+            size--;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// compute_fundamental: OpenCV JacobiSVDImpl_<float> on per-lane matrices held in LDS
+// ------------------------------------------------------------------------------------------
+constexpr int kSolveThreads = 128;
+constexpr int kSolveFloats = 81;    // 9 rows x 9 (row 8 is the FULL_UV null-space row)
+constexpr int kSolveDoubles = 8;
+
+__device__ __forceinline__ uint32_t cvrng_next(uint64_t &state) {   // cv::RNG (MWC)
+    state = (uint64_t)(uint32_t)state * 4164903690ull + (uint32_t)(state >> 32);
+    return (uint32_t)state;
+}
+
+// Element (r,k) of this lane's matrix; lanes are interleaved so every ds access is conflict-free.
+#define VS_A(r, k) sA[((r) * M + (k)) * kSolveThreads + tid]
+#define VS_V(r, k) sV[((r) * N + (k)) * kSolveThreads + tid]
+#define VS_W(i) sW[(i) * kSolveThreads + tid]
+
+// JacobiSVDImpl_(At, astep, W, Vt, vstep, m = M, n = N, n1 = N1, FLT_MIN, FLT_EPSILON*2).
+// Rows 0..N-1 of A are orthogonalised; rows up to N1-1 are normalised / generated.
+// wout receives (float)W[i].
+template <int M, int N, int N1, bool HASV>
+__device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, float *wout) {
+    const double minval = FLT_MIN;
+    const float eps = FLT_EPSILON * 2;
+    constexpr int max_iter = M > 30 ? M : 30;
+
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            const float t = VS_A(i, k);
+            sd = __builtin_fma((double)t, (double)t, sd);
+        }
+        VS_W(i) = sd;
+        if (HASV) {
+#pragma unroll
+            for (int k = 0; k < N; k++) VS_V(i, k) = (i == k) ? 1.f : 0.f;
+        }
+    }
+
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < N - 1; i++)
+            for (int j = i + 1; j < N; j++) {
+                float ai[M], aj[M];
+                double a = VS_W(i), p = 0, b = VS_W(j);
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    ai[k] = VS_A(i, k);
+                    aj[k] = VS_A(j, k);
+                    p = __builtin_fma((double)ai[k], (double)aj[k], p);
+                }
+                if (fabs(p) <= (double)eps * sqrt(a * b)) continue;
+
+                p *= 2;
+                const double beta = a - b;
+                const double gamma = sqrt(p * p + beta * beta);   // pinned hypot
+                float c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = (float)sqrt(delta / gamma);
+                    c = (float)(p / (gamma * (double)s * 2));
+                } else {
+                    c = (float)sqrt((gamma + beta) / (gamma * 2));
+                    s = (float)(p / (gamma * (double)c * 2));
+                }
+                a = b = 0;
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    const float t0 = c * ai[k] + s * aj[k];
+                    const float t1 = (-s) * ai[k] + c * aj[k];
+                    VS_A(i, k) = t0;
+                    VS_A(j, k) = t1;
+                    a = __builtin_fma((double)t0, (double)t0, a);
+                    b = __builtin_fma((double)t1, (double)t1, b);
+                }
+                VS_W(i) = a;
+                VS_W(j) = b;
+                changed = true;
+                if (HASV) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const float vi = VS_V(i, k), vj = VS_V(j, k);
+                        const float t0 = c * vi + s * vj;
+                        const float t1 = (-s) * vi + c * vj;
+                        VS_V(i, k) = t0;
+                        VS_V(j, k) = t1;
+                    }
+                }
+            }
+        if (!changed) break;
+    }
+
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            const float t = VS_A(i, k);
+            sd = __builtin_fma((double)t, (double)t, sd);
+        }
+        VS_W(i) = sqrt(sd);
+    }
+
+    for (int i = 0; i < N - 1; i++) {   // selection sort, descending, rows travel with W
+        int j = i;
+        for (int k = i + 1; k < N; k++)
+            if (VS_W(j) < VS_W(k)) j = k;
+        if (i != j) {
+            const double wi = VS_W(i), wj = VS_W(j);
+            VS_W(i) = wj;
+            VS_W(j) = wi;
+#pragma unroll
+            for (int k = 0; k < M; k++) {
+                const float x = VS_A(i, k), y = VS_A(j, k);
+                VS_A(i, k) = y;
+                VS_A(j, k) = x;
+            }
+            if (HASV) {
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const float x = VS_V(i, k), y = VS_V(j, k);
+                    VS_V(i, k) = y;
+                    VS_V(j, k) = x;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < N; i++) wout[i] = (float)VS_W(i);
+
+    uint64_t rng = 0x12345678ull;
+    for (int i = 0; i < N1; i++) {
+        double sd = i < N ? VS_W(i) : 0;
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const float val0 = (float)(1. / M);
+#pragma unroll
+            for (int k = 0; k < M; k++) VS_A(i, k) = (cvrng_next(rng) & 256) != 0 ? val0 : -val0;
+            for (int iter = 0; iter < 2; iter++) {
+                for (int j = 0; j < i; j++) {
+                    float vi[M], vj[M];
+                    sd = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        vi[k] = VS_A(i, k);
+                        vj[k] = VS_A(j, k);
+                        sd += (double)(vi[k] * vj[k]);   // float product, double running sum
+                    }
+                    float asum = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        const float t = (float)((double)vi[k] - sd * (double)vj[k]);
+                        vi[k] = t;
+                        asum += fabsf(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) VS_A(i, k) = vi[k] * asum;
+                }
+            }
+            sd = 0;
+#pragma unroll
+            for (int k = 0; k < M; k++) {
+                const float t = VS_A(i, k);
+                sd = __builtin_fma((double)t, (double)t, sd);
+            }
+            sd = sqrt(sd);
+        }
+        const float s = (float)(sd > minval ? 1 / sd : 0.);
+#pragma unroll
+        for (int k = 0; k < M; k++) VS_A(i, k) = VS_A(i, k) * s;
+    }
+}
+
+// One lane per hypothesis.  grid = (ceil(hyp / 128), batch).
+__global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, const int32_t *__restrict__ sets, int kp_stride, int hyp,
+    float *__restrict__ hypF) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int h = blockIdx.x * kSolveThreads + tid;
+    if (m_arr[b] < VSLAM_SET_SIZE) return;   // uniform per workgroup
+
+    __shared__ float sA[kSolveFloats * kSolveThreads];
+    __shared__ double sW[kSolveDoubles * kSolveThreads];
+
+    const bool live = h < hyp;
+    const int hc = live ? h : hyp - 1;   // idle lanes redo the last hypothesis; no divergence in barriers
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    const int32_t *S = sets + ((size_t)b * hyp + hc) * VSLAM_SET_SIZE;
+
+    {   // design matrix, RansacFilter.cpp:75-90
+        constexpr int M = 9;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int2 pr = PR[S[r]];
+            const float2 a = P1[pr.x], c = P2[pr.y];
+            const float u1 = a.x, v1 = a.y, u2 = c.x, v2 = c.y;
+            VS_A(r, 0) = u2 * u1;
+            VS_A(r, 1) = u2 * v1;
+            VS_A(r, 2) = u2;
+            VS_A(r, 3) = v2 * u1;
+            VS_A(r, 4) = v2 * v1;
+            VS_A(r, 5) = v2;
+            VS_A(r, 6) = u1;
+            VS_A(r, 7) = v1;
+            VS_A(r, 8) = 1.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) VS_A(8, k) = 0.f;   // temp_u = Scalar::all(0) for the extra row
+    }
+
+    float w8[8];
+    jacobi_svd_lanes<9, 8, 9, false>(sA, sW, nullptr, tid, w8);   // SVDecomp(A 8x9), :94
+
+    float f0[9];
+    {
+        constexpr int M = 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) f0[k] = VS_A(8, k);   // V_t.row(8), :95
+    }
+
+    // second SVD on the 3x3 (:98): working rows are the COLUMNS of F0 (m == n -> transpose)
+    float *sV = sA + 9 * kSolveThreads;
+    {
+        constexpr int M = 3;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) VS_A(i, k) = f0[3 * k + i];
+    }
+    float d3[3];
+    jacobi_svd_lanes<3, 3, 3, true>(sA, sW, sV, tid, d3);
+    d3[2] = 0.f;   // :99
+
+    float U[9], Vt[9];
+    {
+        constexpr int M = 3, N = 3;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                U[r * 3 + c] = VS_A(c, r);   // u = transpose(temp_u)
+                Vt[r * 3 + c] = VS_V(r, c);
+            }
+    }
+    // temp_F = U * diag(D) * V_t (:101) through OpenCV's 3x3 float fast path (a0*b0 + a1*b1 + a2*b2)
+    const float Dg[9] = {d3[0], 0.f, 0.f, 0.f, d3[1], 0.f, 0.f, 0.f, d3[2]};
+    float UD[9], F[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            UD[i * 3 + j] = U[i * 3 + 0] * Dg[0 * 3 + j] + U[i * 3 + 1] * Dg[1 * 3 + j] + U[i * 3 + 2] * Dg[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            F[i * 3 + j] = UD[i * 3 + 0] * Vt[0 * 3 + j] + UD[i * 3 + 1] * Vt[1 * 3 + j] + UD[i * 3 + 2] * Vt[2 * 3 + j];
+
+    if (live) {
+        float *o = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = F[k];
+    }
+}
+#undef VS_A
+#undef VS_V
+#undef VS_W
+
+// ------------------------------------------------------------------------------------------
+// compute_fundamental_residual
+// ------------------------------------------------------------------------------------------
+// e for one correspondence under F, exactly as RansacFilter.cpp:119-126 evaluates it through
+// OpenCV: F*x1 in float (left to right), F.t()*x2 in double with one rounding, the row reduce
+// as (r0 + r1) + r2, and n*n / a*a + b*b + c*c + d*d with C++ precedence.
+struct ResidualF {
+    float f[9];
+    double ft[6];   // F[0],F[3],F[6], F[1],F[4],F[7] as doubles
+};
+__device__ __forceinline__ void residual_prepare(ResidualF &R) {
+    R.ft[0] = (double)R.f[0];
+    R.ft[1] = (double)R.f[3];
+    R.ft[2] = (double)R.f[6];
+    R.ft[3] = (double)R.f[1];
+    R.ft[4] = (double)R.f[4];
+    R.ft[5] = (double)R.f[7];
+}
+__device__ __forceinline__ float residual_e(const ResidualF &R, const float4 c) {
+    const float x1 = c.x, y1 = c.y, x2 = c.z, y2 = c.w;
+    const float a0 = R.f[0] * x1 + R.f[1] * y1 + R.f[2];
+    const float a1 = R.f[3] * x1 + R.f[4] * y1 + R.f[5];
+    const float a2 = R.f[6] * x1 + R.f[7] * y1 + R.f[8];
+    const double dx2 = (double)x2, dy2 = (double)y2;
+    // products of two floats are exact in double: fma(a,b,c) == a*b + c rounded once
+    const float t0 = (float)(__builtin_fma(R.ft[1], dy2, R.ft[0] * dx2) + R.ft[2]);
+    const float t1 = (float)(__builtin_fma(R.ft[4], dy2, R.ft[3] * dx2) + R.ft[5]);
+    const float n = (x2 * a0 + y2 * a1) + a2;
+    const float q = (n * n) / (a0 * a0);
+    return ((q + a1 * a1) + t0 * t0) + t1 * t1;
+}
+
+constexpr int kScoreThreads = 256;
+constexpr int kScoreTile = 2048;   // correspondences per LDS tile (32 KiB)
+
+// One lane per hypothesis; correspondences gathered once per workgroup into LDS as float4
+// (x1,y1,x2,y2) and read back as wave-uniform broadcasts.  grid = (ceil(hyp/256), batch).
+__global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold,
+    const float *__restrict__ hypF, int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int h = blockIdx.x * kScoreThreads + tid;
+    const int m = m_arr[b];
+    if (m < VSLAM_SET_SIZE) return;
+
+    __shared__ float4 corr[kScoreTile];
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+
+    ResidualF R;
+    const int hc = h < hyp ? h : hyp - 1;
+    const float *src = hypF + ((size_t)b * hyp + hc) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R.f[k] = src[k];
+    residual_prepare(R);
+
+    int count = 0;
+    double total = 0;
+    for (int base = 0; base < m; base += kScoreTile) {
+        const int rows = min(kScoreTile, m - base);
+        __syncthreads();
+        for (int i = tid; i < rows; i += kScoreThreads) {
+            const int2 pr = PR[base + i];
+            const float2 a = P1[pr.x], c = P2[pr.y];
+            corr[i] = make_float4(a.x, a.y, c.x, c.y);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < rows; i++) {
+            const float e = residual_e(R, corr[i]);
+            count += (e <= threshold) ? 1 : 0;   // NaN <= thr is false, :130
+            total += (double)e;                  // cv::sum in index order, :138
+        }
+    }
+    if (h < hyp) {
+        hyp_count[(size_t)b * hyp + h] = count;
+        hyp_sum[(size_t)b * hyp + h] = (float)total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// find_fundamental's accept rule + winner mask + inlier filter
+// ------------------------------------------------------------------------------------------
+constexpr int kSelThreads = 256;
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+// monotone map float -> u32 (for non-NaN inputs), +0 and -0 collapse
+__device__ __forceinline__ uint32_t float_order(float f) {
+    if (f == 0.f) f = 0.f;
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// The reference scans hypotheses in order and accepts when count > best || (count == best &&
+// sum > best_sum), starting from (0, 0.0f) (RansacFilter.cpp:44-45,59).  Closed form used here:
+//   C* = max count, i0 = first index with count C*.
+//   C* > 0 and sum[i0] is NaN      -> winner i0 (a NaN best_sum is never beaten at equal count)
+//   otherwise                      -> first index among {count == C*, sum not NaN} with maximal sum
+//                                     (for C* == 0 only if that sum > 0.0f, else nothing accepted)
+__global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold,
+    const float *__restrict__ hypF, const int32_t *__restrict__ hyp_count,
+    const float *__restrict__ hyp_sum, float *__restrict__ F_out, uint8_t *__restrict__ mask,
+    int32_t *__restrict__ best, int32_t *__restrict__ matches) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = m_arr[b];
+    __shared__ unsigned long long s_key[kSelThreads / 64];
+    __shared__ int s_wave_cnt[kSelThreads / 64];
+    __shared__ int s_base;
+    uint8_t *MK = mask + (size_t)b * kp_stride;
+    int32_t *BO = best + (size_t)b * 4;
+
+    int winner = -1, win_count = 0;
+    float win_sum = 0.f;
+    if (m >= VSLAM_SET_SIZE) {
+        const int32_t *C = hyp_count + (size_t)b * hyp;
+        const float *Sm = hyp_sum + (size_t)b * hyp;
+        unsigned long long k = 0;
+        for (int i = tid; i < hyp; i += kSelThreads)
+            k = max(k, ((unsigned long long)(uint32_t)C[i] << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i));
+        k = wave_max_u64(k);
+        if (lane == 0) s_key[wave] = k;
+        __syncthreads();
+        k = s_key[0];
+        for (int w = 1; w < kSelThreads / 64; w++) k = max(k, s_key[w]);
+        __syncthreads();
+        const int cstar = (int)(k >> 32);
+        const int i0 = (int)(0xFFFFFFFFu - (uint32_t)k);
+        const float s0 = Sm[i0];
+        if (cstar > 0 && s0 != s0) {
+            winner = i0;
+            win_sum = s0;
+        } else {
+            unsigned long long k2 = 0;   // 0 == "no candidate" (float_order never returns 0 for finite/inf)
+            for (int i = tid; i < hyp; i += kSelThreads) {
+                const float s = Sm[i];
+                if (C[i] == cstar && s == s)
+                    k2 = max(k2, ((unsigned long long)float_order(s) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i));
+            }
+            k2 = wave_max_u64(k2);
+            if (lane == 0) s_key[wave] = k2;
+            __syncthreads();
+            k2 = s_key[0];
+            for (int w = 1; w < kSelThreads / 64; w++) k2 = max(k2, s_key[w]);
+            __syncthreads();
+            if (k2 != 0) {
+                const int iw = (int)(0xFFFFFFFFu - (uint32_t)k2);
+                const float sw = Sm[iw];
+                if (cstar > 0 || sw > 0.0f) {
+                    winner = iw;
+                    win_sum = sw;
+                }
+            }
+        }
+        win_count = winner >= 0 ? cstar : 0;
+    }
+
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+
+    ResidualF R;
+    if (winner >= 0) {
+        const float *src = hypF + ((size_t)b * hyp + winner) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.f[k] = src[k];
+        residual_prepare(R);
+        if (tid < 9) F_out[(size_t)b * 9 + tid] = R.f[tid];   // temp_F.copyTo(fundamental), :63
+    }
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    int2 *MO = reinterpret_cast<int2 *>(matches) + (size_t)b * kp_stride;
+
+    // winner's mask (inliers.swap, :64) and the ordered inlier filter of Frame.cpp:98-102
+    for (int i0 = 0; i0 < m; i0 += kSelThreads) {
+        const int i = i0 + tid;
+        bool in = false;
+        int2 pr = make_int2(0, 0);
+        if (i < m) {
+            pr = PR[i];
+            if (winner >= 0) {
+                const float2 a = P1[pr.x], c = P2[pr.y];
+                in = residual_e(R, make_float4(a.x, a.y, c.x, c.y)) <= threshold;
+            }
+            MK[i] = in ? 1 : 0;
+        }
+        const unsigned long long bal = __ballot(in);
+        const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave_cnt[w];
+        if (in) MO[off + in_wave] = pr;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < kSelThreads / 64; w++) tot += s_wave_cnt[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        BO[0] = winner;
+        BO[1] = win_count;
+        BO[2] = __float_as_int(win_sum);
+        BO[3] = s_base;
+    }
+}
+
+}  // namespace
+
+int vs_launch_ransac_sets(vslam_ctx *ctx, const uint32_t *seeds, const int32_t *m, int batch, int hyp,
+                          int32_t *sets, uint32_t *draws) {
+    VS_REQUIRE(ctx, seeds && m && sets && draws, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && hyp > 0, VSLAM_ERR_INVALID);
+    VsProfScope ps(ctx, "ransac_sets_kernel");
+    ransac_sets_kernel<<<batch, kSetThreads, 0, ctx->stream>>>(seeds, m, hyp, sets, draws);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
+                     const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
+                     float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,
+                     float *hypF, int32_t *hyp_count, float *hyp_sum) {
+    VS_REQUIRE(ctx, xy1 && xy2 && pairs && m && sets && F && mask && best && matches, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, hypF && hyp_count && hyp_sum, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && hyp > 0, VSLAM_ERR_INVALID);
+    {
+        VsProfScope ps(ctx, "ransac_solve_kernel");
+        dim3 grid(vs_div_up(hyp, kSolveThreads), batch);
+        ransac_solve_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, sets, kp_stride,
+                                                                     hyp, hypF);
+    }
+    {
+        VsProfScope ps(ctx, "ransac_score_kernel");
+        dim3 grid(vs_div_up(hyp, kScoreThreads), batch);
+        ransac_score_kernel<<<grid, kScoreThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp,
+                                                                     threshold, hypF, hyp_count, hyp_sum);
+    }
+    {
+        VsProfScope ps(ctx, "ransac_select_kernel");
+        ransac_select_kernel<<<batch, kSelThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp,
+                                                                     threshold, hypF, hyp_count, hyp_sum,
+                                                                     F, mask, best, matches);
+    }
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}

@@ -1,0 +1,123 @@
+"""Seeded synthetic inputs: descriptor sets, point correspondences, frames.
+
+Everything is generated from an integer seed with numpy's PCG64 (identical on every machine) so
+the CPU oracle and the GPU path see the same bytes.  Frames for the throughput bench can also be
+generated directly on the device with torch (same construction, device RNG).
+"""
+import math
+
+import numpy as np
+
+
+def descriptors_pair(seed, k1, k2, match_frac=0.6, flip_p=0.05):
+    """Frame-A descriptors = uniform random bytes; frame B = a permutation of A with each bit
+    flipped w.p. flip_p for match_frac of the rows and fresh random rows for the rest."""
+    rng = np.random.default_rng(seed)
+    d1 = rng.integers(0, 256, size=(k1, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, size=(k2, 32), dtype=np.uint8)
+    n_match = int(min(k1, k2) * match_frac)
+    src = rng.permutation(k1)[:n_match]
+    dst = rng.permutation(k2)[:n_match]
+    flips = rng.random((n_match, 256)) < flip_p
+    d2[dst] = d1[src] ^ np.packbits(flips, axis=1)
+    truth = np.full(k1, -1, dtype=np.int64)
+    truth[src] = dst
+    return d1, d2, truth
+
+
+def two_view_points(seed, k, width, height, inlier_frac=0.7, noise_px=0.5, integer=True):
+    """k correspondences between two pinhole views (f = 525, principal point at the centre, as
+    src/vslam.cpp:29-33) of random 3-D points under a small rigid motion; the rest are uniform
+    outliers.  Coordinates are integer-valued like Shi-Tomasi output."""
+    rng = np.random.default_rng(seed)
+    f, cx, cy = 525.0, width / 2.0, height / 2.0
+    ang = np.deg2rad(rng.uniform(-1.5, 1.5, size=3))
+    Rx = np.array([[1, 0, 0], [0, math.cos(ang[0]), -math.sin(ang[0])], [0, math.sin(ang[0]), math.cos(ang[0])]])
+    Ry = np.array([[math.cos(ang[1]), 0, math.sin(ang[1])], [0, 1, 0], [-math.sin(ang[1]), 0, math.cos(ang[1])]])
+    Rz = np.array([[math.cos(ang[2]), -math.sin(ang[2]), 0], [math.sin(ang[2]), math.cos(ang[2]), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx
+    t = rng.uniform(-0.3, 0.3, size=3)
+    p1 = np.zeros((k, 2)); p2 = np.zeros((k, 2))
+    p1[:, 0] = rng.uniform(0, width - 1, size=k); p1[:, 1] = rng.uniform(0, height - 1, size=k)
+    depth = rng.uniform(2.0, 12.0, size=k)
+    X = np.stack([(p1[:, 0] - cx) / f * depth, (p1[:, 1] - cy) / f * depth, depth], axis=1)
+    X2 = X @ R.T + t
+    p2[:, 0] = f * X2[:, 0] / X2[:, 2] + cx + rng.normal(0, noise_px, size=k)
+    p2[:, 1] = f * X2[:, 1] / X2[:, 2] + cy + rng.normal(0, noise_px, size=k)
+    outl = rng.random(k) > inlier_frac
+    p2[outl, 0] = rng.uniform(0, width - 1, size=outl.sum()); p2[outl, 1] = rng.uniform(0, height - 1, size=outl.sum())
+    p2[:, 0] = np.clip(p2[:, 0], 0, width - 1); p2[:, 1] = np.clip(p2[:, 1], 0, height - 1)
+    if integer:
+        p1 = np.rint(p1); p2 = np.rint(p2)
+    return p1.astype(np.float32), p2.astype(np.float32), ~outl
+
+
+def brief_pattern(seed=0xB21EF):
+    """256 x (x0,y0,x1,y1) int8 test pattern inside the 31x31 patch.  OpenCV's learned table
+    (bit_pattern_31_) is data compiled into OpenCV and is not available here; this seeded
+    Gaussian pattern (sigma = patch/5, clipped to +-13 so a rotated sample stays inside the
+    31-px border) stands in and is labelled synthetic everywhere it is used."""
+    rng = np.random.default_rng(seed)
+    p = np.clip(np.rint(rng.normal(0, 31 / 5.0, size=(256, 4))), -13, 13).astype(np.int8)
+    same = (p[:, 0] == p[:, 2]) & (p[:, 1] == p[:, 3])
+    p[same, 2] = np.where(p[same, 2] < 13, p[same, 2] + 1, p[same, 2] - 1)
+    return p
+
+
+def keypoint_rotation(angle_deg=-1.0):
+    """(cos, sin) of the KeyPoint angle as float32: cv::KeyPoint(p, 20) leaves angle = -1 and
+    ORB::compute does not recompute it for provided keypoints."""
+    a = np.float32(angle_deg) * np.float32(math.pi / 180.0)
+    return float(np.float32(math.cos(float(a)))), float(np.float32(math.sin(float(a))))
+
+
+def frames_numpy(seed, n_pairs, width, height):
+    """BGR uint8 frames, shape (2*n_pairs, H, W, 3): frames [0,n) are 'last', [n,2n) 'current'.
+    Blocky random texture (two cell sizes) so corner detectors find thousands of junctions,
+    low-amplitude noise, and frame B = frame A translated by a few pixels with fresh noise."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((2 * n_pairs, height, width, 3), dtype=np.uint8)
+    for p in range(n_pairs):
+        base = np.zeros((height + 32, width + 32), dtype=np.float32)
+        for cell, amp in ((16, 70.0), (24, 50.0), (10, 25.0)):
+            gh, gw = (height + 32) // cell + 2, (width + 32) // cell + 2
+            g = rng.uniform(-amp, amp, size=(gh, gw)).astype(np.float32)
+            up = np.kron(g, np.ones((cell, cell), dtype=np.float32))
+            oy, ox = rng.integers(0, cell, size=2)
+            base += up[oy:oy + height + 32, ox:ox + width + 32]
+        base = np.clip(128 + base, 8, 247)
+        dx, dy = rng.integers(-12, 13, size=2)
+        a = base[16:16 + height, 16:16 + width]
+        b = base[16 + dy:16 + dy + height, 16 + dx:16 + dx + width]
+        for f, img in ((p, a), (n_pairs + p, b)):
+            for c in range(3):
+                noise = rng.integers(-6, 7, size=(height, width))
+                tint = (c - 1) * 4
+                out[f, :, :, c] = np.clip(img + noise + tint, 0, 255).astype(np.uint8)
+    return out
+
+
+def frames_torch(seed, n_pairs, width, height, device):
+    """Same construction as frames_numpy with torch's RNG on `device` (bench inputs only)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    H2, W2 = height + 32, width + 32
+    base = torch.zeros((n_pairs, H2, W2), dtype=torch.float32, device=device)
+    for cell, amp in ((16, 70.0), (24, 50.0), (10, 25.0)):
+        gh, gw = H2 // cell + 2, W2 // cell + 2
+        grid = (torch.rand((n_pairs, gh, gw), generator=g, device=device) * 2 - 1) * amp
+        up = grid.repeat_interleave(cell, dim=1).repeat_interleave(cell, dim=2)
+        base += up[:, 3:3 + H2, 5:5 + W2]
+    base = torch.clamp(128 + base, 8, 247)
+    out = torch.empty((2 * n_pairs, height, width, 3), dtype=torch.uint8, device=device)
+    shifts = torch.randint(-12, 13, (n_pairs, 2), generator=g, device=device).cpu()
+    for p in range(n_pairs):
+        dx, dy = int(shifts[p, 0]), int(shifts[p, 1])
+        a = base[p, 16:16 + height, 16:16 + width]
+        b = base[p, 16 + dy:16 + dy + height, 16 + dx:16 + dx + width]
+        for f, img in ((p, a), (n_pairs + p, b)):
+            noise = torch.randint(-6, 7, (height, width, 3), generator=g, device=device).float()
+            tint = torch.tensor([-4.0, 0.0, 4.0], device=device)
+            out[f] = torch.clamp(img[:, :, None] + noise + tint, 0, 255).to(torch.uint8)
+    return out
