@@ -43,7 +43,8 @@ typedef struct vslam_ctx vslam_ctx;
 /* ------------------------------------------------------------------ context */
 int vslam_ctx_create(int device, vslam_ctx **out);
 int vslam_ctx_destroy(vslam_ctx *ctx);
-/* Borrow a caller-owned hipStream_t (e.g. torch's current stream).  NULL = own stream.      */
+/* Borrow a caller-owned hipStream_t (e.g. torch's current stream).  Taken literally: NULL is
+ * HIP's default stream.  A fresh context runs on a private non-blocking stream.               */
 int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream);
 int vslam_ctx_synchronize(vslam_ctx *ctx);
 const char *vslam_last_error(vslam_ctx *ctx);

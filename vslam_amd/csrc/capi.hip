@@ -114,18 +114,11 @@ int vslam_ctx_destroy(vslam_ctx *ctx) {
 int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream) {
     if (!ctx) return VSLAM_ERR_INVALID;
     VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->own_stream && ctx->stream) {
-        (void)hipStreamDestroy(ctx->stream);
-        ctx->stream = nullptr;
-        ctx->own_stream = false;
-    }
-    if (hip_stream) {
-        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
-        ctx->own_stream = false;
-    } else {
-        VS_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    // taken literally: NULL is HIP's default (null) stream, which is what torch hands out as
+    // its default current stream
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
     return VSLAM_OK;
 }
 
