@@ -1,0 +1,148 @@
+"""HIP extraction kernels vs the oracle, stage by stage and end to end (all bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from vslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(320, 240), (203, 131), (64, 96), (640, 480)]
+
+
+def frames_for(w, h, seed, n=2):
+    return synth.frames_numpy(seed, n, w, h)      # (2n, h, w, 3)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_gray_eig_blur_bit_exact(ctx, oracle, w, h):
+    bgr = frames_for(w, h, 10 + w)
+    t = torch.from_numpy(bgr).cuda()
+    gray = ctx.bgr2gray(t)
+    eig = ctx.min_eigen(gray)
+    blur = ctx.gaussian7(gray)
+    ctx.synchronize()
+    gray, eig, blur = gray.cpu().numpy(), eig.cpu().numpy(), blur.cpu().numpy()
+    for f in range(bgr.shape[0]):
+        g = oracle.bgr2gray(bgr[f])
+        assert np.array_equal(gray[f], g), f
+        e = oracle.min_eigen(g)
+        bad = np.argwhere(eig[f].view(np.uint32) != e.view(np.uint32))
+        assert bad.size == 0, (f, bad[:5], eig[f][tuple(bad[0])], e[tuple(bad[0])])
+        assert np.array_equal(blur[f], oracle.gaussian7(g)), f
+
+
+def test_gray_unaligned_rows(ctx, oracle):
+    """width not a multiple of 4 -> the byte path of bgr2gray."""
+    bgr = frames_for(131, 77, 5, n=1)
+    gray = ctx.bgr2gray(torch.from_numpy(bgr).cuda()).cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(gray[f], oracle.bgr2gray(bgr[f]))
+
+
+@pytest.mark.parametrize("w,h,maxc", [(320, 240, 300), (203, 131, 5000), (640, 480, 1000), (64, 96, 50)])
+def test_good_features_bit_exact(ctx, oracle, w, h, maxc):
+    bgr = frames_for(w, h, 20 + w)
+    gray = ctx.bgr2gray(torch.from_numpy(bgr).cuda())
+    xy, n = ctx.good_features(gray, maxc)
+    ctx.synchronize()
+    gray, xy, n = gray.cpu().numpy(), xy.cpu().numpy(), n.cpu().numpy()
+    for f in range(bgr.shape[0]):
+        ref = oracle.good_features(gray[f], maxc)
+        assert n[f] == len(ref), (f, n[f], len(ref))
+        assert np.array_equal(xy[f, :n[f]], ref), f
+
+
+def test_good_features_plateaus_and_flat(ctx, oracle):
+    """Synthetic eigenvalue plateaus: a checkerboard gives many pixels with EQUAL response, so the
+    address tie-break of the sort and the equal-value suppression chains are exercised; a flat
+    frame gives max == 0 and no corners."""
+    h, w = 120, 160
+    yy, xx = np.mgrid[0:h, 0:w]
+    board = (((yy // 8) + (xx // 8)) % 2 * 200 + 20).astype(np.uint8)
+    flat = np.full((h, w), 77, np.uint8)
+    stripes = ((xx // 5) % 2 * 180 + 30).astype(np.uint8)
+    gray = np.stack([board, flat, stripes])
+    xy, n = ctx.good_features(torch.from_numpy(gray).cuda(), 4000)
+    xy, n = xy.cpu().numpy(), n.cpu().numpy()
+    for f in range(3):
+        ref = oracle.good_features(gray[f], 4000)
+        assert n[f] == len(ref), f
+        assert np.array_equal(xy[f, :n[f]], ref), f
+    assert n[1] == 0
+
+
+def test_good_features_other_min_distance(ctx, oracle):
+    bgr = frames_for(320, 240, 31)
+    gray = ctx.bgr2gray(torch.from_numpy(bgr).cuda())
+    g = gray.cpu().numpy()
+    for md in (0.0, 1.0, 2.5, 7.0):
+        xy, n = ctx.good_features(gray, 800, min_distance=md)
+        xy, n = xy.cpu().numpy(), n.cpu().numpy()
+        for f in range(2):
+            ref = oracle.good_features(g[f], 800, min_dist=md)
+            assert n[f] == len(ref) and np.array_equal(xy[f, :n[f]], ref), (md, f)
+
+
+def test_describe_bit_exact_and_border_filter(ctx, oracle):
+    w, h = 320, 240
+    bgr = frames_for(w, h, 41)
+    gray = ctx.bgr2gray(torch.from_numpy(bgr).cuda())
+    blur = ctx.gaussian7(gray)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    rng = np.random.default_rng(1)
+    K = 500
+    pts = np.rint(np.stack([rng.uniform(0, w - 1, (4, K)), rng.uniform(0, h - 1, (4, K))], -1)).astype(np.float32)
+    pts[0, :6] = [[31, 31], [30, 31], [31, 30], [w - 32, h - 32], [w - 31, 50], [50, h - 31]]   # border cases
+    n = np.array([K, 300, 0, 1], np.int32)
+    xy_out, desc, n_out = ctx.orb_describe(blur, torch.from_numpy(pts).cuda(), torch.from_numpy(n).cuda(), ca, sa,
+                                           torch.from_numpy(pat).cuda())
+    xy_out, desc, n_out, blur = xy_out.cpu().numpy(), desc.cpu().numpy(), n_out.cpu().numpy(), blur.cpu().numpy()
+    for f in range(4):
+        rd, keep = oracle.orb_describe(blur[f], pts[f, :n[f]], ca, sa, pat)
+        assert n_out[f] == len(keep), f
+        assert np.array_equal(xy_out[f, :len(keep)], pts[f, :n[f]][keep]), f
+        assert np.array_equal(desc[f, :len(keep)], rd), f
+
+
+@pytest.mark.parametrize("w,h,maxc", [(320, 240, 400), (640, 480, 500)])
+def test_extract_features_end_to_end(ctx, oracle, w, h, maxc):
+    """extract_features(Frame&), src/Frame.cpp:53-80: points, descriptors, k-d tree, both counts."""
+    bgr = frames_for(w, h, 50 + w)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    out = ctx.extract_features(torch.from_numpy(bgr).cuda(), maxc, ca, sa, torch.from_numpy(pat).cuda())
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for f in range(bgr.shape[0]):
+        ref = oracle.extract_features(bgr[f], maxc, ca, sa, pat)
+        k = ref["n"]
+        assert out["n"][f] == k and out["n_detected"][f] == ref["n_detected"], f
+        assert k > maxc // 2, "synthetic frame should be corner-rich"
+        assert np.array_equal(out["xy"][f, :k], ref["xy"]), f
+        assert np.array_equal(out["desc"][f, :k], ref["desc"]), f
+        assert np.array_equal(out["nodes"][f, :k], ref["nodes"]), f
+
+
+def test_frontend_pairs_end_to_end(ctx, oracle):
+    """The whole path bench.py times, on C1-like inputs (640x480, 500 keypoints, 512 hypotheses):
+    extract both frames, match, RANSAC; inlier matches and F must equal the oracle's."""
+    w, h, maxc, Hy, thr, P = 640, 480, 500, 512, 10.0, 2
+    bgr = synth.frames_numpy(0x5EED0000, P, w, h)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    seeds = np.array([0x5EED0000 ^ p for p in range(P)], np.uint32)
+    out = ctx.frontend_pairs(torch.from_numpy(bgr).cuda(), P, maxc, ca, sa, torch.from_numpy(pat).cuda(),
+                             torch.from_numpy(seeds.view(np.int32)).cuda(), Hy, thr)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for p in range(P):
+        a = oracle.extract_features(bgr[p], maxc, ca, sa, pat)
+        b = oracle.extract_features(bgr[P + p], maxc, ca, sa, pat)
+        ref = oracle.match_features(a["xy"], a["desc"], b["xy"], b["desc"], int(seeds[p]), Hy, thr)
+        assert ref["rc"] == 0 and ref["prelim"] > 100, "synthetic pair should match"
+        k = len(ref["matches"])
+        assert out["best"][p, 3] == k and k > 30, p
+        assert np.array_equal(out["matches"][p, :k], ref["matches"]), p
+        assert np.array_equal(out["F"][p].view(np.uint32), ref["F"].view(np.uint32)), p

@@ -1,7 +1,649 @@
-// placeholder until the extraction kernels land (next commit)
+// Keypoint extraction + rBRIEF description for gfx950.
+//
+// Replaces extract_features(Frame&), /root/reference/src/Frame.cpp:53-80:
+//   cv::cvtColor(BGR2GRAY) :56            -> bgr2gray_kernel
+//   cv::goodFeaturesToTrack(...) :61      -> min_eigen_kernel (Sobel + products + 3x3 box + min
+//                                            eigenvalue, LDS tiled, per-frame max),
+//                                            corner_candidates_kernel (threshold + 3x3 local max),
+//                                            corner_select_kernel (greedy min-distance as a
+//                                            fixpoint, top-N by rank, sorted output)
+//   cv::ORB::compute(gray, kps, desc) :68 -> gaussian7_kernel, keypoint_border_kernel,
+//                                            rbrief_kernel
+// The arithmetic follows the oracle (oracle/vso_extract.cpp) operation for operation; float
+// steps are written so that no contraction or reassociation can occur (-ffp-contract=off).
+//
+// All of these are streaming stencils over 8-bit / 32-bit images: HBM-bound by design, so each
+// kernel reads its input tile once into LDS with coalesced loads and writes each output once.
 #include "ctx.h"
-int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *, int, int, int, int, uint8_t *) { ctx->err = "extract: not built"; return VSLAM_ERR_INVALID; }
-int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *, int, int, int, float *, uint32_t *) { ctx->err = "extract: not built"; return VSLAM_ERR_INVALID; }
-int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *, int, int, int, int, double, double, int, float *, int32_t *) { ctx->err = "extract: not built"; return VSLAM_ERR_INVALID; }
-int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *, int, int, int, uint8_t *) { ctx->err = "extract: not built"; return VSLAM_ERR_INVALID; }
-int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *, int, int, int, const float *, const int32_t *, int, float, float, const int8_t *, float *, uint8_t *, int32_t *) { ctx->err = "extract: not built"; return VSLAM_ERR_INVALID; }
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * n - 2 - p;
+    return p < 0 ? 0 : (p >= n ? n - 1 : p);   // clamp only guards halo cells that are never used
+}
+
+// monotone float <-> u32 so an unsigned max / radix order is the float order (no NaNs here)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// ------------------------------------------------------------------------------------------
+// cvtColor(BGR2GRAY), 8U: (b*3735 + g*19235 + r*9798 + 2^14) >> 15
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) {
+    return (b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15;
+}
+
+__global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t *__restrict__ bgr, int w, int h,
+                                                       int stride, uint8_t *__restrict__ gray,
+                                                       int aligned) {
+    const int f = blockIdx.y;
+    const int qpr = (w + 3) >> 2;   // 4-pixel groups per row
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * h) return;
+    const int y = q / qpr, x = (q - y * qpr) * 4;
+    const uint8_t *src = bgr + ((size_t)f * h + y) * stride + 3 * x;
+    uint8_t *dst = gray + ((size_t)f * h + y) * w + x;
+    if (aligned && x + 3 < w) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+        const uint32_t a = s4[0], b = s4[1], c = s4[2];   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint32_t g0 = gray_of(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
+        const uint32_t g1 = gray_of(a >> 24, b & 0xFF, (b >> 8) & 0xFF);
+        const uint32_t g2 = gray_of((b >> 16) & 0xFF, b >> 24, c & 0xFF);
+        const uint32_t g3 = gray_of((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24);
+        *reinterpret_cast<uint32_t *>(dst) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    } else {
+        for (int i = 0; i < 4 && x + i < w; i++) dst[i] = (uint8_t)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// cornerMinEigenVal(gray, eig, 3, 3) + per-frame max
+// ------------------------------------------------------------------------------------------
+constexpr int kET = 256;          // threads
+constexpr int kETW = 64, kETH = 16;   // output tile
+constexpr int kGW = kETW + 4, kGH = kETH + 4;   // gray tile (halo 2)
+constexpr int kHW = kETW + 2;                   // hx / R / cov width (halo 1)
+
+__global__ __launch_bounds__(kET) void min_eigen_kernel(const uint8_t *__restrict__ gray, int w, int h,
+                                                        float *__restrict__ eig,
+                                                        uint32_t *__restrict__ frame_max) {
+    __shared__ uint8_t G[kGH][kGW];
+    __shared__ float HX[kGH][kHW], RR[kGH][kHW];
+    __shared__ float CXX[kETH + 2][kHW], CXY[kETH + 2][kHW], CYY[kETH + 2][kHW];
+    __shared__ uint32_t s_max;
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kETW, y0 = blockIdx.y * kETH;
+    const uint8_t *src = gray + (size_t)f * w * h;
+    if (tid == 0) s_max = 0;
+
+    // gray tile at raw coordinates [x0-2, x0+TW+2) x [y0-2, y0+TH+2), REFLECT_101 filled
+    for (int i = tid; i < kGH * kGW; i += kET) {
+        const int r = i / kGW, c = i - r * kGW;
+        G[r][c] = src[(size_t)reflect101(y0 - 2 + r, h) * w + reflect101(x0 - 2 + c, w)];
+    }
+    __syncthreads();
+
+    // row pass of both Sobels on raw rows [y0-2, ..), raw cols [x0-1, x0+TW+1)
+    const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    const float k1 = (float)scale, k0 = 2.0f * k1;
+    for (int i = tid; i < kGH * kHW; i += kET) {
+        const int r = i / kHW, c = i - r * kHW;   // G column of this pixel is c + 1
+        const int gm = G[r][c], g0 = G[r][c + 1], gp = G[r][c + 2];
+        HX[r][c] = (float)(gp - gm);
+        const float a = (float)g0 * k0;
+        const float b = (float)(gm + gp) * k1;
+        RR[r][c] = a + b;
+    }
+    __syncthreads();
+
+    // column pass + products on raw rows [y0-1, y0+TH+1)
+    for (int i = tid; i < (kETH + 2) * kHW; i += kET) {
+        const int r = i / kHW, c = i - r * kHW;   // HX/RR row of this pixel is r + 1
+        const float a = HX[r + 1][c] * k0;
+        const float b = (HX[r][c] + HX[r + 2][c]) * k1;
+        const float dx = a + b;
+        const float dy = RR[r + 2][c] - RR[r][c];
+        CXX[r][c] = dx * dx;
+        CXY[r][c] = dx * dy;
+        CYY[r][c] = dy * dy;
+    }
+    __syncthreads();
+
+    // 3x3 box in double: r(y) = (c(x-1) + c(x)) + c(x+1), S = (r(y-1) + r(y)) + r(y+1), with the
+    // box filter's own REFLECT_101 applied to cov coordinates.  Each lane walks 4 rows of one column.
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x = x0 + tx;
+    uint32_t kmax = 0;   // f2ord() of any float is > 0, so 0 is the identity of the max
+    if (x < w) {
+        const int cm = reflect101(x - 1, w) - (x0 - 1), c0 = tx + 1, cp = reflect101(x + 1, w) - (x0 - 1);
+        double rxx[6], rxy[6], ryy[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int yy = y0 + ty * 4 - 1 + k;
+            int lr = reflect101(yy, h) - (y0 - 1);
+            lr = lr < 0 ? 0 : (lr > kETH + 1 ? kETH + 1 : lr);   // rows past the image are never output
+            rxx[k] = ((double)CXX[lr][cm] + (double)CXX[lr][c0]) + (double)CXX[lr][cp];
+            rxy[k] = ((double)CXY[lr][cm] + (double)CXY[lr][c0]) + (double)CXY[lr][cp];
+            ryy[k] = ((double)CYY[lr][cm] + (double)CYY[lr][c0]) + (double)CYY[lr][cp];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = y0 + ty * 4 + k;
+            if (y < h) {
+                const float sxx = (float)((rxx[k] + rxx[k + 1]) + rxx[k + 2]);
+                const float sxy = (float)((rxy[k] + rxy[k + 1]) + rxy[k + 2]);
+                const float syy = (float)((ryy[k] + ryy[k + 1]) + ryy[k + 2]);
+                const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
+                const float amc = a - c;
+                const float t = amc * amc + b * b;
+                const float e = (a + c) - sqrtf(t);
+                eig[((size_t)f * h + y) * w + x] = e;
+                const uint32_t ke = f2ord(e);
+                kmax = ke > kmax ? ke : kmax;
+            }
+        }
+    }
+    if (frame_max) {
+        uint32_t k = kmax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(k, off, 64);
+            k = o > k ? o : k;
+        }
+        if ((tid & 63) == 0) atomicMax(&s_max, k);
+        __syncthreads();
+        if (tid == 0) atomicMax(&frame_max[f], s_max);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// threshold + 3x3 local maximum -> candidate keys and a per-pixel state map
+// ------------------------------------------------------------------------------------------
+// state: 0 none, 1 candidate (undecided), 2 accepted, 3 rejected
+constexpr int kCT = 256, kCTW = 64, kCTH = 16;
+
+__global__ __launch_bounds__(kCT) void corner_candidates_kernel(
+    const float *__restrict__ eig, int w, int h, const uint32_t *__restrict__ frame_max, double quality,
+    uint8_t *__restrict__ state, unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
+    size_t key_cap) {
+    __shared__ float E[kCTH + 2][kCTW + 2];
+    __shared__ uint32_t s_cnt, s_base;
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kCTW, y0 = blockIdx.y * kCTH;
+    const float *src = eig + (size_t)f * w * h;
+    const float mx = ord2f(frame_max[f]);
+    const float thr = (float)((double)mx * quality);   // threshold(eig, maxVal*qualityLevel, THRESH_TOZERO)
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < (kCTH + 2) * (kCTW + 2); i += kCT) {
+        const int r = i / (kCTW + 2), c = i - r * (kCTW + 2);
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        // outside the image the dilate sees nothing: -inf never wins a max
+        E[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? src[(size_t)yy * w + xx] : -__builtin_inff();
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    unsigned long long mykeys[4];
+    int nk = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int ly = ty * 4 + k, y = y0 + ly, x = x0 + tx;
+        if (x < w && y < h) {
+            const float v = E[ly + 1][tx + 1];
+            bool cand = false;
+            if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1 && v > thr) {   // interior only, val != 0
+                float m = v;
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                    for (int dx = 0; dx < 3; dx++) {
+                        const float nb = E[ly + dy][tx + dx];
+                        m = nb > m ? nb : m;
+                    }
+                cand = (m == v);   // val == dilate(val); neighbours <= thr are 0 after TOZERO and v > thr >= 0
+            }
+            state[((size_t)f * h + y) * w + x] = cand ? 1 : 0;
+            if (cand) mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + x);
+        }
+    }
+    uint32_t my_off = 0;
+    if (nk) my_off = atomicAdd(&s_cnt, (uint32_t)nk);
+    __syncthreads();
+    if (tid == 0 && s_cnt) s_base = atomicAdd(&counts[f], s_cnt);
+    __syncthreads();
+    for (int i = 0; i < nk; i++) {
+        const size_t pos = (size_t)s_base + my_off + i;
+        if (pos < key_cap) keys[(size_t)f * key_cap + pos] = mykeys[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// greedy min-distance suppression + first-N by rank, one workgroup per frame
+// ------------------------------------------------------------------------------------------
+// goodFeaturesToTrack sorts candidates by (value desc, address desc) and accepts a candidate iff
+// no already-accepted corner lies within minDistance (featureselect.cpp; the cell grid there is
+// only an index).  Acceptance of c depends on higher-ranked candidates within that radius only,
+// so the sequential scan is the least fixpoint of
+//     c accepted  <=> every higher-ranked neighbour is rejected
+//     c rejected  <=> some higher-ranked neighbour is accepted
+// which is reached by rounds in which every undecided candidate inspects its neighbourhood;
+// each round settles at least the highest-ranked undecided candidate.  The first maxCorners
+// accepted in rank order are then the reference's output, in its order.
+constexpr int kST = 1024;
+
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *scratch /* kST/64 + 1 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (int i = 0; i < kST / 64; i++) t += scratch[i];
+    return t;
+}
+
+__global__ __launch_bounds__(kST) void corner_select_kernel(
+    const float *__restrict__ eig, int w, int h, uint8_t *__restrict__ state,
+    unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
+    int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
+    int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(smem_raw);
+    __shared__ uint32_t s_scratch[kST / 64 + 1];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_flag, s_fill;
+    __shared__ unsigned long long s_prefix;
+    __shared__ uint32_t s_need;
+
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float *E = eig + (size_t)f * w * h;
+    uint8_t *S = state + (size_t)f * w * h;
+    unsigned long long *K = keys + (size_t)f * key_cap;
+    uint32_t n = counts[f];
+    if (n > key_cap) {
+        if (tid == 0) atomicAdd(overflow, 1);
+        n = (uint32_t)key_cap;
+    }
+
+    // ---- suppression fixpoint
+    const int R = min_dist >= 1.f ? (int)ceilf(min_dist) : 0;
+    if (R > 0) {
+        while (true) {
+            __syncthreads();
+            if (tid == 0) s_flag = 0;
+            __syncthreads();
+            bool pending = false;
+            for (uint32_t i = tid; i < n; i += kST) {
+                const uint32_t off = (uint32_t)K[i];
+                if (S[off] != 1) continue;
+                const int y = off / w, x = off - y * w;
+                const float val = E[off];
+                bool rejected = false, blocked = false;
+                for (int dy = -R; dy <= R && !rejected; dy++) {
+                    const int yy = y + dy;
+                    if (yy < 0 || yy >= h) continue;
+                    for (int dx = -R; dx <= R; dx++) {
+                        const int xx = x + dx;
+                        if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+                        const float fx = (float)dx, fy = (float)dy;
+                        if (!(fx * fx + fy * fy < min_dist_sq)) continue;
+                        const uint32_t noff = (uint32_t)(yy * w + xx);
+                        const uint8_t sn = S[noff];
+                        if (sn == 0 || sn == 3) continue;
+                        const float vn = E[noff];
+                        const bool higher = (vn > val) || (vn == val && noff > off);
+                        if (!higher) continue;
+                        if (sn == 2) {
+                            rejected = true;
+                            break;
+                        }
+                        blocked = true;
+                    }
+                }
+                if (rejected) S[off] = 3;
+                else if (!blocked) S[off] = 2;
+                else pending = true;
+            }
+            if (pending) s_flag = 1;
+            __syncthreads();
+            if (!s_flag) break;
+        }
+    } else {
+        for (uint32_t i = tid; i < n; i += kST) S[(uint32_t)K[i]] = 2;
+    }
+    __syncthreads();
+
+    // ---- compact accepted keys to the front of K (unordered; entries are read before any write
+    //      of the same round can reach them)
+    uint32_t n_acc = 0;
+    for (uint32_t base = 0; base < n; base += kST) {
+        const uint32_t i = base + tid;
+        unsigned long long key = 0;
+        bool acc = false;
+        if (i < n) {
+            key = K[i];
+            acc = S[(uint32_t)key] == 2;
+        }
+        const unsigned long long bal = __ballot(acc);
+        __syncthreads();
+        if (lane == 0) s_scratch[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int wv = 0; wv < kST / 64; wv++) {
+            const uint32_t c = s_scratch[wv];
+            if (wv < wave) pre += c;
+            tot += c;
+        }
+        if (acc) K[n_acc + pre + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = key;
+        n_acc += tot;
+    }
+    __syncthreads();
+
+    // ---- threshold key of the max_corners-th best (MSB radix select, 8 bits per pass)
+    const uint32_t want = n_acc < (uint32_t)max_corners ? n_acc : (uint32_t)max_corners;
+    unsigned long long prefix = 0;
+    int known_bits = 0;
+    if (n_acc > want && want > 0) {
+        uint32_t need = want;   // how many of the keys matching `prefix` are still wanted
+        for (int pass = 0; pass < 8; pass++) {
+            const int shift = 56 - 8 * pass;
+            for (int i = tid; i < 256; i += kST) s_hist[i] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n_acc; i += kST) {
+                const unsigned long long key = K[i];
+                if (known_bits == 0 || (key >> (64 - known_bits)) == (prefix >> (64 - known_bits)))
+                    atomicAdd(&s_hist[(uint32_t)(key >> shift) & 0xFFu], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t acc = 0;
+                int d = 255;
+                for (; d > 0; d--) {
+                    if (acc + s_hist[d] >= need) break;
+                    acc += s_hist[d];
+                }
+                s_prefix = prefix | ((unsigned long long)d << shift);
+                s_need = need - acc;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            need = s_need;
+            known_bits += 8;
+            __syncthreads();
+        }
+    }
+    // keys are distinct (the offset is part of the key): exactly `want` keys are >= prefix
+
+    // ---- gather the winners into LDS, sort descending, emit
+    if (tid == 0) s_fill = 0;
+    for (int i = tid; i < sort_cap; i += kST) sortbuf[i] = 0ull;
+    __syncthreads();
+    for (uint32_t i = tid; i < n_acc; i += kST) {
+        const unsigned long long key = K[i];
+        if (key >= prefix) {
+            const uint32_t p = atomicAdd(&s_fill, 1u);
+            if (p < (uint32_t)sort_cap) sortbuf[p] = key;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= sort_cap; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sort_cap; i += kST) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = sortbuf[i], b = sortbuf[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        sortbuf[i] = b;
+                        sortbuf[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    float2 *O = reinterpret_cast<float2 *>(out_xy) + (size_t)f * kp_stride;
+    for (uint32_t i = tid; i < want; i += kST) {
+        const uint32_t off = (uint32_t)sortbuf[i];
+        const int y = off / w, x = off - y * w;
+        O[i] = make_float2((float)x, (float)y);
+    }
+    if (tid == 0) out_n[f] = (int32_t)want;
+    (void)block_sum_u32;
+}
+
+// ------------------------------------------------------------------------------------------
+// GaussianBlur 7x7 sigma 2, 8U fixed point: Q8 taps (18,34,48,56,48,34,18), Q16 accumulate
+// ------------------------------------------------------------------------------------------
+constexpr int kBT = 256, kBTW = 64, kBTH = 16;
+
+__global__ __launch_bounds__(kBT) void gaussian7_kernel(const uint8_t *__restrict__ gray, int w, int h,
+                                                        uint8_t *__restrict__ out) {
+    __shared__ uint8_t G[kBTH + 6][kBTW + 8];
+    __shared__ uint16_t RP[kBTH + 6][kBTW];
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kBTW, y0 = blockIdx.y * kBTH;
+    const uint8_t *src = gray + (size_t)f * w * h;
+    for (int i = tid; i < (kBTH + 6) * (kBTW + 6); i += kBT) {
+        const int r = i / (kBTW + 6), c = i - r * (kBTW + 6);
+        G[r][c] = src[(size_t)reflect101(y0 - 3 + r, h) * w + reflect101(x0 - 3 + c, w)];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBTH + 6) * kBTW; i += kBT) {
+        const int r = i / kBTW, c = i - r * kBTW;
+        const uint32_t s = 18u * G[r][c] + 34u * G[r][c + 1] + 48u * G[r][c + 2] + 56u * G[r][c + 3] +
+                           48u * G[r][c + 4] + 34u * G[r][c + 5] + 18u * G[r][c + 6];
+        RP[r][c] = (uint16_t)s;
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int ly = ty * 4 + k, y = y0 + ly, x = x0 + tx;
+        if (x < w && y < h) {
+            const uint32_t s = 18u * RP[ly][tx] + 34u * RP[ly + 1][tx] + 48u * RP[ly + 2][tx] + 56u * RP[ly + 3][tx] +
+                               48u * RP[ly + 4][tx] + 34u * RP[ly + 5][tx] + 18u * RP[ly + 6][tx];
+            out[((size_t)f * h + y) * w + x] = (uint8_t)((s + (1u << 15)) >> 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ORB::compute for provided keypoints: border filter (ordered) + steered BRIEF
+// ------------------------------------------------------------------------------------------
+constexpr int kKT = 256;
+
+// KeyPointsFilter::runByImageBorder(kps, size, 31): keep pt inside [31, w-31) x [31, h-31), order kept
+__global__ __launch_bounds__(kKT) void keypoint_border_kernel(const float *__restrict__ xy_in,
+                                                              const int32_t *__restrict__ n_in, int kp_stride,
+                                                              int w, int h, float *__restrict__ xy_out,
+                                                              int32_t *__restrict__ n_out) {
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_cnt[kKT / 64];
+    __shared__ int s_base;
+    const float2 *I = reinterpret_cast<const float2 *>(xy_in) + (size_t)f * kp_stride;
+    float2 *O = reinterpret_cast<float2 *>(xy_out) + (size_t)f * kp_stride;
+    const int n = n_in[f];
+    const int border = 31;
+    const bool any = !(h <= border * 2 || w <= border * 2);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kKT) {
+        const int i = i0 + tid;
+        float2 p = make_float2(0.f, 0.f);
+        bool keep = false;
+        if (i < n) {
+            p = I[i];
+            keep = any && p.x >= (float)border && p.x < (float)(w - border) && p.y >= (float)border &&
+                   p.y < (float)(h - border);
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_cnt[wave] = (int)__popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int wv = 0; wv < wave; wv++) off += s_cnt[wv];
+        if (keep) O[off + (int)__popcll(bal & ((1ull << lane) - 1ull))] = p;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int wv = 0; wv < kKT / 64; wv++) t += s_cnt[wv];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) n_out[f] = s_base;
+}
+
+// One lane per (keypoint, descriptor byte): 8 tests = 16 gathers from the blurred image.
+// The 512 rotated sample offsets are the same for every keypoint (one global angle), so each
+// workgroup rotates the pattern once into LDS:  x = px*a - py*b, y = px*b + py*a, cvRound.
+__global__ __launch_bounds__(kKT) void rbrief_kernel(const uint8_t *__restrict__ blurred, int w, int h,
+                                                     const float *__restrict__ xy, const int32_t *__restrict__ n_arr,
+                                                     int kp_stride, float ca, float sa,
+                                                     const int8_t *__restrict__ pattern,
+                                                     uint8_t *__restrict__ desc) {
+    __shared__ int s_off[512];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int n = n_arr[f];
+    const int kp0 = blockIdx.x * (kKT / 32);
+    if (kp0 >= n) return;
+    for (int i = tid; i < 512; i += kKT) {
+        const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
+        const float a1 = px * ca, a2 = py * sa, b1 = px * sa, b2 = py * ca;
+        const float rx = a1 - a2, ry = b1 + b2;
+        const int ix = (int)rintf(rx), iy = (int)rintf(ry);
+        s_off[i] = iy * w + ix;
+    }
+    __syncthreads();
+    const int kp = kp0 + (tid >> 5), byte = tid & 31;
+    if (kp >= n) return;
+    const float2 p = reinterpret_cast<const float2 *>(xy)[(size_t)f * kp_stride + kp];
+    const int cx = (int)rintf(p.x), cy = (int)rintf(p.y);
+    const uint8_t *center = blurred + (size_t)f * w * h + (size_t)cy * w + cx;
+    uint32_t val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        const int t0 = center[s_off[(byte * 8 + bit) * 2]];
+        const int t1 = center[s_off[(byte * 8 + bit) * 2 + 1]];
+        val |= (uint32_t)(t0 < t1) << bit;
+    }
+    desc[((size_t)f * kp_stride + kp) * VSLAM_DESC_BYTES + byte] = (uint8_t)val;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, int h, int stride,
+                       uint8_t *gray) {
+    VS_REQUIRE(ctx, bgr && gray, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, frames > 0 && w > 0 && h > 0 && stride >= 3 * w, VSLAM_ERR_INVALID);
+    const int aligned = (stride % 4 == 0) && (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(bgr) & 3) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && (((size_t)h * stride) % 4 == 0);
+    VsProfScope ps(ctx, "bgr2gray_kernel");
+    dim3 grid(vs_div_up(((w + 3) / 4) * h, 256), frames);
+    bgr2gray_kernel<<<grid, 256, 0, ctx->stream>>>(bgr, w, h, stride, gray, aligned);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, float *eig,
+                        uint32_t *frame_max_bits) {
+    VS_REQUIRE(ctx, gray && eig, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, frames > 0 && w >= 3 && h >= 3, VSLAM_ERR_INVALID);
+    if (frame_max_bits) VS_HIP(ctx, hipMemsetAsync(frame_max_bits, 0, sizeof(uint32_t) * (size_t)frames, ctx->stream));
+    VsProfScope ps(ctx, "min_eigen_kernel");
+    dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
+    min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h,
+                            int max_corners, double quality, double min_distance, int kp_stride,
+                            float *xy, int32_t *n) {
+    VS_REQUIRE(ctx, gray && xy && n, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, frames > 0 && w >= 3 && h >= 3, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, max_corners > 0 && max_corners <= kp_stride, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, min_distance < 64.0, VSLAM_ERR_CAPACITY);
+    const size_t px = (size_t)w * h;
+    float *eig = nullptr;
+    uint32_t *fmax = nullptr, *counts = nullptr;
+    uint8_t *state = nullptr;
+    unsigned long long *keys = nullptr;
+    int32_t *overflow = nullptr;
+    int rc;
+    if ((rc = vs_arena_get(ctx, "gf.eig", sizeof(float) * px * frames, (void **)&eig))) return rc;
+    if ((rc = vs_arena_get(ctx, "gf.fmax", sizeof(uint32_t) * (size_t)frames, (void **)&fmax))) return rc;
+    if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), (void **)&counts))) return rc;
+    if ((rc = vs_arena_get(ctx, "gf.state", px * frames, (void **)&state))) return rc;
+    // every interior pixel can be a candidate (a plateau equals its own dilation), so the key list
+    // is sized for the whole image: exactness over memory
+    const size_t key_cap = px;
+    if ((rc = vs_arena_get(ctx, "gf.keys", sizeof(unsigned long long) * key_cap * frames, (void **)&keys))) return rc;
+    overflow = reinterpret_cast<int32_t *>(counts + frames);
+
+    if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, fmax))) return rc;
+    VS_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), ctx->stream));
+    {
+        VsProfScope ps(ctx, "corner_candidates_kernel");
+        dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
+        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
+    }
+    {
+        int sort_cap = 2;
+        while (sort_cap < max_corners) sort_cap <<= 1;
+        const size_t lds = sizeof(unsigned long long) * (size_t)sort_cap;
+        VS_REQUIRE(ctx, lds <= 128 * 1024, VSLAM_ERR_CAPACITY);
+        static bool attr_set = false;
+        if (!attr_set) {
+            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corner_select_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        const float md = (float)min_distance;
+        const float md2 = (float)(min_distance * min_distance);   // `minDistance *= minDistance` in double, compared as float
+        VsProfScope ps(ctx, "corner_select_kernel");
+        corner_select_kernel<<<frames, kST, lds, ctx->stream>>>(eig, w, h, state, keys, counts, key_cap, max_corners, md,
+                                                                md2, sort_cap, xy, n, kp_stride, overflow);
+    }
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, uint8_t *out) {
+    VS_REQUIRE(ctx, gray && out, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, frames > 0 && w >= 4 && h >= 4, VSLAM_ERR_INVALID);
+    VsProfScope ps(ctx, "gaussian7_kernel");
+    dim3 grid(vs_div_up(w, kBTW), vs_div_up(h, kBTH), frames);
+    gaussian7_kernel<<<grid, kBT, 0, ctx->stream>>>(gray, w, h, out);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, int w, int h,
+                           const float *xy_in, const int32_t *n_in, int kp_stride, float ca, float sa,
+                           const int8_t *pattern, float *xy_out, uint8_t *desc, int32_t *n_out) {
+    VS_REQUIRE(ctx, blurred && xy_in && n_in && pattern && xy_out && desc && n_out, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, frames > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
+    {
+        VsProfScope ps(ctx, "keypoint_border_kernel");
+        keypoint_border_kernel<<<frames, kKT, 0, ctx->stream>>>(xy_in, n_in, kp_stride, w, h, xy_out, n_out);
+    }
+    {
+        VsProfScope ps(ctx, "rbrief_kernel");
+        dim3 grid(vs_div_up(kp_stride, kKT / 32), frames);
+        rbrief_kernel<<<grid, kKT, 0, ctx->stream>>>(blurred, w, h, xy_out, n_out, kp_stride, ca, sa, pattern, desc);
+    }
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
