@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Throughput bench for the front-end hot path (BASELINE.json metric).
+
+A step = one pass of extract(2 frames per pair) + match + RANSAC over one batch of synthetic
+frame pairs already resident in HBM.  N = 1 runs BASELINE.json configs[2] (1280x720, 2000
+keypoints, 4096 hypotheses, batch 256); with N > 1 every rank runs the same per-GPU batch on its
+own shard (weak scaling, configs[3]) and the per-pair result records are gathered over RCCL.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of the step,
+timed with HIP events on the stream the kernels run on; `cpu_baseline` is the oracle (a CPU port
+of the reference path, single thread) timed on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (width, height, keypoints, hypotheses, pairs per GPU)
+    "C2": (640, 480, 1000, 1024, 64),
+    "C3": (1280, 720, 2000, 4096, 256),
+    "C5": (1920, 1080, 4000, 8192, 512),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # lanes x clock: 78.6 T lane-ops/s (1 op per lane per cycle)
+
+
+def algorithmic_bytes(kernel, w, h, K, H, M):
+    """Compulsory HBM bytes PER FRAME PAIR for each kernel (DESIGN.md 'Roofline accounting'):
+    every input read once, every output written once, temporaries not counted."""
+    px = w * h
+    table = {
+        "bgr2gray_kernel": 2 * (3 * px + px),
+        "min_eigen_kernel": 2 * (px + 4 * px),
+        "corner_candidates_kernel": 2 * (4 * px + px),
+        "corner_select_kernel": 2 * (K * 8),
+        "gaussian7_kernel": 2 * (px + px),
+        "keypoint_border_kernel": 2 * (K * 8 * 2),
+        "rbrief_kernel": 2 * (K * 8 + K * 32),
+        "kdtree_build_kernel": 2 * (K * 8 + K * 4),
+        "match_knn2_kernel": 2 * K * 32 + K * 4,
+        "match_compact_kernel": K * 4 + K * 8,
+        "ransac_sets_kernel": H * 32,
+        "ransac_solve_kernel": H * 32 + M * 24 + H * 36,
+        "ransac_score_kernel": H * 36 + M * 24 + H * 8,
+        "ransac_select_kernel": H * 8 + M * 24 + M + M * 8 + 36,
+    }
+    return table.get(kernel, 0)
+
+
+def cpu_baseline(wl, sample_pairs, seed):
+    """The oracle (oracle/, a CPU port of the reference path; the reference itself cannot be built
+    here) on `sample_pairs` pairs of the same workload, one thread."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    from vslam_amd import synth
+    w, h, K, H, _ = WORKLOADS[wl]
+    o = Oracle()
+    bgr = synth.frames_numpy(seed, sample_pairs, w, h)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    t0 = time.perf_counter()
+    for p in range(sample_pairs):
+        a = o.extract_features(bgr[p], K, ca, sa, pat)
+        b = o.extract_features(bgr[sample_pairs + p], K, ca, sa, pat)
+        o.match_features(a["xy"], a["desc"], b["xy"], b["desc"], seed ^ p, H, 10.0)
+    dt = time.perf_counter() - t0
+    return {"value": sample_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_pairs} pairs of {wl} ({w}x{h}, {K} kp, {H} hyp), oracle single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch)")
+    ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs the CPU baseline times (0 = skip)")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vslam_amd import Context, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    w, h, K, H, P = WORKLOADS[args.workload]
+    if args.pairs:
+        P = args.pairs
+    thr = 10.0                                    # RansacFilter rf(8, 100, 10), src/vslam.cpp:19
+    seed = 0x5EED0000 + sorted(WORKLOADS).index(args.workload)
+    ctx = Context(local_rank)
+    bgr = synth.frames_torch(seed + 1000 * rank, P, w, h, dev)
+    pat = torch.from_numpy(synth.brief_pattern()).to(dev)
+    ca, sa = synth.keypoint_rotation()
+    seeds = torch.from_numpy((np.arange(P, dtype=np.uint32) ^ np.uint32(seed + rank)).view(np.int32)).to(dev)
+    out = None
+    rec_len = 9 + 4                                # F + best per pair, as float32/int32 words
+    gathered = torch.empty((world, P, rec_len + 2 * K), dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        nonlocal out
+        out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
+        if world > 1:
+            # the only exchange on the path: fixed-size per-pair result records to every rank
+            rec = torch.cat([out["F"].view(torch.int32), out["best"], out["matches"].view(P, 2 * K)], dim=1)
+            dist.all_gather_into_tensor(gathered.view(world * P, -1), rec)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity on the timed output: every pair produced keypoints, matches and an accepted model
+    best = out["best"].cpu().numpy()
+    n_kp = out["n"].cpu().numpy()
+    assert (best[:, 0] >= 0).all() and (best[:, 3] >= 8).all() and (n_kp > K // 2).all(), "bench output degenerate"
+
+    result = None
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        result = {
+            "metric": "frame-pairs/sec (extract+match+RANSAC)",
+            "value": world * P * args.steps / dt,
+            "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/f32/f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w}x{h}, {K} keypoints, {H} hypotheses, batch {P} pairs per GPU",
+                       "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}" + (", RCCL all_gather of result records" if world > 1 else "")},
+            "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
+        }
+
+    # ---- separate pass: per-kernel durations with HIP events on the kernels' own stream
+    if rank == 0 and not args.no_profile_pass:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        psteps = max(1, min(3, args.steps))
+        for _ in range(psteps):
+            ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
+        rep = ctx.prof_report()
+        ctx.prof_enable(False)
+        M = float(best[:, 3].mean())
+        m_prelim = M   # inlier matches; preliminary matches are >= this
+        kernels = []
+        for name, (ms, cnt) in rep.items():
+            per_launch_ms = ms / max(cnt, 1)
+            alg = algorithmic_bytes(name, w, h, K, H, m_prelim) * P
+            kernels.append({"kernel": name, "ms_per_launch": per_launch_ms, "launches_per_step": cnt / psteps,
+                            "alg_bytes_per_launch": alg,
+                            "alg_GBps": alg / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
+        kernels.sort(key=lambda k: -k["ms_per_launch"] * k["launches_per_step"])
+        top = kernels[0]
+        result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                              "avg_launch_ms": top["ms_per_launch"],
+                              "note": "VALU-issue-bound kernel (DESIGN.md): algorithmic bytes are tiny next to its arithmetic"}
+        result["kernels"] = kernels
+        result["profile_pass_ms_per_step"] = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels)
+
+    if rank == 0 and world == 1 and args.cpu_pairs > 0:
+        result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_pairs, seed)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
