@@ -88,7 +88,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from vslam_amd import Context, synth
+    from vslam_amd import Context, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,18 +111,17 @@ def main():
     bgr = synth.frames_torch(seed + 1000 * rank, P, w, h, dev)
     pat = torch.from_numpy(synth.brief_pattern()).to(dev)
     ca, sa = synth.keypoint_rotation()
-    seeds = torch.from_numpy((np.arange(P, dtype=np.uint32) ^ np.uint32(seed + rank)).view(np.int32)).to(dev)
+    lo, hi = shard.shard_range(world * P, rank, world)          # this rank's slice of the global batch
+    seeds = torch.from_numpy(shard.pair_seeds(seed, lo, hi).view(np.int32)).to(dev)
     out = None
-    rec_len = 9 + 4                                # F + best per pair, as float32/int32 words
-    gathered = torch.empty((world, P, rec_len + 2 * K), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * P, shard.REC_HEAD + 2 * K), dtype=torch.int32, device=dev) if world > 1 else None
 
     def step():
         nonlocal out
         out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
         if world > 1:
             # the only exchange on the path: fixed-size per-pair result records to every rank
-            rec = torch.cat([out["F"].view(torch.int32), out["best"], out["matches"].view(P, 2 * K)], dim=1)
-            dist.all_gather_into_tensor(gathered.view(world * P, -1), rec)
+            shard.gather_records(shard.pack_records(out["F"], out["best"], out["matches"]), world, out=gathered)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,50 @@
+"""Multi-GPU plumbing: the front-end shards by frame pair (independent units).
+
+One process per GPU.  Rank r owns a contiguous slice of the batch; nothing is exchanged on the
+data path.  The only collective is the final gather of fixed-size per-pair result records
+(F, winner/count/score/n, inlier matches) — all_gather_into_tensor over RCCL on GPUs (each peer
+sends its slice once over its own xGMI link), gloo on CPU in the tests.
+"""
+import numpy as np
+
+REC_HEAD = 9 + 4     # F (9 f32 words) + best (4 i32 words)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced slice [lo, hi) of n_items for `rank` (first n % world ranks get one more)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pack_records(F, best, matches):
+    """(P,9) f32, (P,4) i32, (P,K,2) i32 -> (P, 13 + 2K) i32 words (bit-preserving)."""
+    import torch
+    P = F.shape[0]
+    return torch.cat([F.contiguous().view(torch.int32), best, matches.reshape(P, -1)], dim=1).contiguous()
+
+
+def unpack_records(rec, K):
+    import torch
+    F = rec[:, :9].contiguous().view(torch.float32)
+    best = rec[:, 9:13]
+    matches = rec[:, 13:13 + 2 * K].reshape(rec.shape[0], K, 2)
+    return F, best, matches
+
+
+def gather_records(rec, world, out=None):
+    """all_gather of equally-sized per-rank record blocks -> (world * P, words)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return rec
+    if out is None:
+        out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec)
+    return out
+
+
+def pair_seeds(base_seed, lo, hi):
+    """Per-pair RANSAC seeds: base ^ global pair index, so a pair's result does not
+    depend on which rank or batch position processed it."""
+    return (np.arange(lo, hi, dtype=np.uint32) ^ np.uint32(base_seed & 0xFFFFFFFF)).astype(np.uint32)
