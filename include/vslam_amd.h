@@ -96,6 +96,20 @@ int vslam_ransac_fundamental(vslam_ctx *ctx, const float *d_xy1, const float *d_
                              uint8_t *d_mask, int32_t *d_best, int32_t *d_matches, float *d_hypF,
                              int32_t *d_hyp_count, float *d_hyp_sum);
 
+/* The two halves of vslam_ransac_fundamental, exposed because RansacFilter's public surface has
+ * them as separate methods:
+ *   vslam_ransac_solve     = compute_fundamental for every set (src/RansacFilter.cpp:69-103)
+ *   vslam_ransac_evaluate  = compute_fundamental_residual for every given hypothesis (:105-140) +
+ *                            the accept rule of find_fundamental (:59) + the winner's mask/matches.
+ * With hyp = 1 they are the single-call forms of those methods.                               */
+int vslam_ransac_solve(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, const int32_t *d_pairs,
+                       const int32_t *d_m, const int32_t *d_sets, int batch, int kp_stride, int hyp,
+                       float *d_hypF);
+int vslam_ransac_evaluate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2,
+                          const int32_t *d_pairs, const int32_t *d_m, const float *d_hypF, int batch,
+                          int kp_stride, int hyp, float threshold, float *d_F, uint8_t *d_mask,
+                          int32_t *d_best, int32_t *d_matches, int32_t *d_hyp_count, float *d_hyp_sum);
+
 /* ------------------------------------------------------------------ k-d tree */
 /* Replaces construct_kdtree(frame_kdtree&, points), src/KDTree.cpp:107-143.  The tree is the
  * reference's pre-order node array reduced to its pt_index column: d_nodes [batch][kp_stride].
@@ -110,6 +124,14 @@ int vslam_kdtree_radius(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_x
                         const int32_t *d_n, int batch, int kp_stride, const float *d_queries,
                         const int32_t *d_nq, int q_stride, float radius, int32_t *d_hits,
                         int32_t *d_counts, int hit_cap);
+
+/* Replaces nearest(KDTree, query, max_distance_sq), src/KDTree.cpp:37-71, on the same pre-order
+ * array: d_best_idx [batch][q_stride] = index of the nearest point, or -1 when none is closer than
+ * max_distance_sq (the reference then returns a default-constructed {0,0} point).             */
+int vslam_kdtree_nearest(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_xy,
+                         const int32_t *d_n, int batch, int kp_stride, const float *d_queries,
+                         const int32_t *d_nq, int q_stride, float max_distance_sq,
+                         int32_t *d_best_idx);
 
 /* ---------------------------------------------------------------- extraction */
 typedef struct vslam_extract_params {

@@ -1,0 +1,89 @@
+"""The C++ drop-in layer (include/vslam/*.h + libvslam_host.so) used like the reference's consumers
+use Frame / KDTree / RansacFilter, checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from vslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_surfaces_match_oracle(oracle, tmp_path):
+    from vslam_amd import build
+    build.build_host()
+    exe = str(tmp_path / "adapter_demo")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "native", "adapter_demo.cpp"),
+                    "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vslam_amd"), "-lvslam_host", "-lvslam_amd",
+                    "-Wl,-rpath," + os.path.join(ROOT, "vslam_amd")], check=True)
+    w, h, maxc, H, seed = 320, 240, 400, 96, 4242
+    bgr = synth.frames_numpy(61, 1, w, h)
+    pat = synth.brief_pattern()
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("5i", w, h, maxc, H, seed))
+        f.write(bgr.tobytes())
+        f.write(pat.tobytes())
+    subprocess.run([exe, fin, fout], check=True, timeout=120)
+    buf = open(fout, "rb").read()
+    off = 0
+
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(buf, dtype=dtype, count=n, offset=off)
+        off += a.nbytes
+        return a
+
+    ca, sa = synth.keypoint_rotation()        # the adapter derives the same (cos, sin) from angle = -1 deg
+    ex = []
+    for i in range(2):
+        n, nd = take(np.int32, 2)
+        ref = oracle.extract_features(bgr[i], maxc, ca, sa, pat)
+        assert (n, nd) == (ref["n"], ref["n_detected"])
+        assert np.array_equal(take(np.float32, 2 * n).reshape(n, 2), ref["xy"])
+        assert np.array_equal(take(np.uint8, 32 * n).reshape(n, 32), ref["desc"])
+        assert np.array_equal(take(np.int32, n), ref["nodes"])
+        assert int(take(np.int32, 1)[0]) == int(np.floor(np.log2(n)) + 1)
+        ex.append(ref)
+    mf = oracle.match_features(ex[0]["xy"], ex[0]["desc"], ex[1]["xy"], ex[1]["desc"], seed, H, 10.0)
+    k = int(take(np.int32, 1)[0])
+    assert k == len(mf["matches"]) and k >= 8
+    matches = take(np.int32, 2 * k).reshape(k, 2)
+    assert np.array_equal(matches, mf["matches"])
+    assert int(take(np.int32, 1)[0]) == 1
+    assert np.array_equal(take(np.float32, 9).view(np.uint32), mf["F"].view(np.uint32))
+
+    nq = int(take(np.int32, 1)[0])
+    pts = ex[1]["xy"]
+    for q in range(nq):
+        qp = (pts[q] + np.array([0.75, -1.25], np.float32)).astype(np.float32)
+        ref, cnt = oracle.kdtree_radius_frame(ex[1]["nodes"], pts, qp, 2.0)
+        c = int(take(np.int32, 1)[0])
+        assert c == cnt and np.array_equal(take(np.int32, c), ref)
+    assert int(take(np.int32, 1)[0]) == 1          # batch form == single-query form
+
+    import ctypes as C
+    tree = np.zeros((len(pts), 2), np.float32)
+    assert oracle.lib.vso_kdtree_build_points(pts.ctypes.data_as(C.POINTER(C.c_float)), len(pts), tree.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    nn = np.zeros(2, np.float32)
+    oracle.lib.vso_kdtree_nearest_points(tree.ctypes.data_as(C.POINTER(C.c_float)), len(pts), C.c_float(100.5), C.c_float(80.25),
+                                         C.c_float(np.inf), nn.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(take(np.float32, 2), nn)
+    near = np.zeros((len(pts), 2), np.float32)
+    cnt = oracle.lib.vso_kdtree_radius_points(tree.ctypes.data_as(C.POINTER(C.c_float)), len(pts), C.c_float(100.5), C.c_float(80.25),
+                                              C.c_float(12.0), near.ctypes.data_as(C.POINTER(C.c_float)), len(pts))
+    assert int(take(np.int32, 1)[0]) == cnt
+    assert np.array_equal(take(np.float32, 2 * cnt).reshape(cnt, 2), near[:cnt])
+
+    s1 = ex[0]["xy"][matches[:8, 0]]; s2 = ex[1]["xy"][matches[:8, 1]]
+    F8 = oracle.compute_fundamental(s1, s2)
+    assert np.array_equal(take(np.float32, 9).view(np.uint32), F8.view(np.uint32))
+    mask, c, s = oracle.residual(ex[0]["xy"], ex[1]["xy"], matches, F8, 10.0)
+    assert int(take(np.int32, 1)[0]) == c
+    assert take(np.float32, 1).view(np.uint32)[0] == np.float32(s).view(np.uint32)
+    assert np.array_equal(take(np.int32, k), mask.astype(np.int32))
+    assert off == len(buf)

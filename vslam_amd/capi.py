@@ -19,8 +19,9 @@ SYMBOLS = [
     "vslam_ctx_create", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_synchronize",
     "vslam_last_error", "vslam_version", "vslam_dev_alloc", "vslam_dev_free", "vslam_copy_h2d",
     "vslam_copy_d2h", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
-    "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_kdtree_build",
-    "vslam_kdtree_radius", "vslam_extract_features", "vslam_bgr2gray", "vslam_min_eigen",
+    "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
+    "vslam_ransac_evaluate", "vslam_kdtree_build",
+    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_bgr2gray", "vslam_min_eigen",
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_match_features",
     "vslam_frontend_pairs",
 ]
@@ -183,6 +184,16 @@ class Context:
                                                  _ptr(queries), _ptr(nq), C.c_int(Q), C.c_float(radius),
                                                  _ptr(hits), _ptr(counts), C.c_int(hit_cap)))
         return hits, counts
+
+    def kdtree_nearest(self, nodes, xy, n, queries, nq, max_distance_sq=float("inf")):
+        torch = self.torch
+        B, K, _ = xy.shape
+        Q = queries.shape[1]
+        best = torch.full((B, Q), -2, dtype=torch.int32, device=xy.device)
+        self._check(self.lib.vslam_kdtree_nearest(self.handle, _ptr(nodes), _ptr(xy), _ptr(n), C.c_int(B), C.c_int(K),
+                                                  _ptr(queries), _ptr(nq), C.c_int(Q), C.c_float(max_distance_sq),
+                                                  _ptr(best)))
+        return best
 
     def bgr2gray(self, bgr):
         torch = self.torch

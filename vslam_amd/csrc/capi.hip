@@ -216,6 +216,22 @@ int vslam_ransac_fundamental(vslam_ctx *ctx, const float *d_xy1, const float *d_
                             d_F, d_mask, d_best, d_matches, d_hypF, d_hyp_count, d_hyp_sum);
 }
 
+int vslam_ransac_solve(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, const int32_t *d_pairs,
+                       const int32_t *d_m, const int32_t *d_sets, int batch, int kp_stride, int hyp,
+                       float *d_hypF) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_ransac_solve(ctx, d_xy1, d_xy2, d_pairs, d_m, d_sets, batch, kp_stride, hyp, d_hypF);
+}
+
+int vslam_ransac_evaluate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2,
+                          const int32_t *d_pairs, const int32_t *d_m, const float *d_hypF, int batch,
+                          int kp_stride, int hyp, float threshold, float *d_F, uint8_t *d_mask,
+                          int32_t *d_best, int32_t *d_matches, int32_t *d_hyp_count, float *d_hyp_sum) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_ransac_evaluate(ctx, d_xy1, d_xy2, d_pairs, d_m, d_hypF, batch, kp_stride, hyp, threshold,
+                                     d_F, d_mask, d_best, d_matches, d_hyp_count, d_hyp_sum);
+}
+
 int vslam_kdtree_build(vslam_ctx *ctx, const float *d_xy, const int32_t *d_n, int batch, int kp_stride,
                        int32_t *d_nodes) {
     if (!ctx) return VSLAM_ERR_INVALID;
@@ -228,6 +244,14 @@ int vslam_kdtree_radius(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_x
     if (!ctx) return VSLAM_ERR_INVALID;
     return vs_launch_kdtree_radius(ctx, d_nodes, d_xy, d_n, batch, kp_stride, d_queries, d_nq, q_stride,
                                    radius, d_hits, d_counts, hit_cap);
+}
+
+int vslam_kdtree_nearest(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_xy, const int32_t *d_n,
+                         int batch, int kp_stride, const float *d_queries, const int32_t *d_nq,
+                         int q_stride, float max_distance_sq, int32_t *d_best_idx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_kdtree_nearest(ctx, d_nodes, d_xy, d_n, batch, kp_stride, d_queries, d_nq, q_stride,
+                                    max_distance_sq, d_best_idx);
 }
 
 int vslam_bgr2gray(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,

@@ -83,11 +83,21 @@ int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const i
                      const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
                      float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,
                      float *hypF, int32_t *hyp_count, float *hyp_sum);
+int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
+                           const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
+                           float *hypF);
+int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
+                              const int32_t *m, const float *hypF, int batch, int kp_stride, int hyp,
+                              float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,
+                              int32_t *hyp_count, float *hyp_sum);
 int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, int batch, int kp_stride,
                            int32_t *nodes);
 int vs_launch_kdtree_radius(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n,
                             int batch, int kp_stride, const float *queries, const int32_t *nq,
                             int q_stride, float radius, int32_t *hits, int32_t *counts, int hit_cap);
+int vs_launch_kdtree_nearest(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n,
+                             int batch, int kp_stride, const float *queries, const int32_t *nq,
+                             int q_stride, float max_distance_sq, int32_t *best_idx);
 int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, int h, int stride,
                        uint8_t *gray);
 int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, float *eig,

@@ -149,7 +149,69 @@ __global__ __launch_bounds__(kQueryThreads) void kdtree_radius_kernel(
     counts[(size_t)b * q_stride + q] = cnt;
 }
 
+// nearest(KDTree, query, max_distance_sq), src/KDTree.cpp:37-71: descend the near side, test the
+// node on the way back (strict <), visit the far side iff split^2 < best.  Entry = pos | len << 15 |
+// axis << 30 | stage << 31 (stage 1 = "near side done").  Result: point index or -1 when nothing
+// beats max_distance_sq (the reference then returns a default-constructed {0,0}, :38-42).
+__global__ __launch_bounds__(kQueryThreads) void kdtree_nearest_kernel(
+    const int32_t *__restrict__ nodes, const float *__restrict__ xy, const int32_t *__restrict__ n_arr,
+    int kp_stride, const float *__restrict__ queries, const int32_t *__restrict__ nq_arr, int q_stride,
+    float max_distance_sq, int32_t *__restrict__ best_idx) {
+    __shared__ uint32_t stack[kStackDepth * kQueryThreads];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int q = blockIdx.x * kQueryThreads + tid;
+    const int n = n_arr[b];
+    if (q >= nq_arr[b]) return;
+    const float2 qp = reinterpret_cast<const float2 *>(queries)[(size_t)b * q_stride + q];
+    const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)b * kp_stride;
+    const int32_t *T = nodes + (size_t)b * kp_stride;
+    float best = max_distance_sq;
+    int best_i = -1, sp = 0;
+    if (n > 0) stack[(sp++) * kQueryThreads + tid] = 0u | ((uint32_t)n << 15);
+    while (sp > 0) {
+        const uint32_t e = stack[(--sp) * kQueryThreads + tid];
+        const int pos = (int)(e & 0x7FFFu), len = (int)((e >> 15) & 0x7FFFu), axis = (int)((e >> 30) & 1u);
+        const bool back = (e >> 31) != 0;
+        const int idx = T[pos];
+        const float2 pt = P[idx];
+        const float split = (axis == 0 ? qp.x : qp.y) - (axis == 0 ? pt.x : pt.y);
+        const int nl = len / 2, nr = len - nl - 1;
+        const uint32_t nax = (uint32_t)(1 - axis) << 30;
+        const uint32_t le = (uint32_t)(pos + 1) | ((uint32_t)nl << 15) | nax;
+        const uint32_t re = (uint32_t)(pos + 1 + nl) | ((uint32_t)nr << 15) | nax;
+        const bool near_left = split < 0;
+        if (!back) {
+            stack[(sp++) * kQueryThreads + tid] = e | 0x80000000u;
+            if (near_left ? nl > 0 : nr > 0) stack[(sp++) * kQueryThreads + tid] = near_left ? le : re;
+        } else {
+            const float dx = pt.x - qp.x, dy = pt.y - qp.y;
+            const float cur = dx * dx + dy * dy;
+            if (cur < best) {
+                best = cur;
+                best_i = idx;
+            }
+            if (split * split < best && (near_left ? nr > 0 : nl > 0))
+                stack[(sp++) * kQueryThreads + tid] = near_left ? re : le;
+        }
+    }
+    best_idx[(size_t)b * q_stride + q] = best_i;
+}
+
 }  // namespace
+
+int vs_launch_kdtree_nearest(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n,
+                             int batch, int kp_stride, const float *queries, const int32_t *nq,
+                             int q_stride, float max_distance_sq, int32_t *best_idx) {
+    VS_REQUIRE(ctx, nodes && xy && n && queries && nq && best_idx, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && q_stride > 0, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
+    VsProfScope ps(ctx, "kdtree_nearest_kernel");
+    dim3 grid(vs_div_up(q_stride, kQueryThreads), batch);
+    kdtree_nearest_kernel<<<grid, kQueryThreads, 0, ctx->stream>>>(nodes, xy, n, kp_stride, queries, nq, q_stride,
+                                                                   max_distance_sq, best_idx);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
 
 int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, int batch, int kp_stride,
                            int32_t *nodes) {

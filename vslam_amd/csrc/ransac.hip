@@ -688,19 +688,25 @@ int vs_launch_ransac_sets(vslam_ctx *ctx, const uint32_t *seeds, const int32_t *
     return VSLAM_OK;
 }
 
-int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
-                     const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
-                     float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,
-                     float *hypF, int32_t *hyp_count, float *hyp_sum) {
-    VS_REQUIRE(ctx, xy1 && xy2 && pairs && m && sets && F && mask && best && matches, VSLAM_ERR_INVALID);
-    VS_REQUIRE(ctx, hypF && hyp_count && hyp_sum, VSLAM_ERR_INVALID);
+int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
+                           const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
+                           float *hypF) {
+    VS_REQUIRE(ctx, xy1 && xy2 && pairs && m && sets && hypF, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && hyp > 0, VSLAM_ERR_INVALID);
-    {
-        VsProfScope ps(ctx, "ransac_solve_kernel");
-        dim3 grid(vs_div_up(hyp, kSolveThreads), batch);
-        ransac_solve_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, sets, kp_stride,
-                                                                     hyp, hypF);
-    }
+    VsProfScope ps(ctx, "ransac_solve_kernel");
+    dim3 grid(vs_div_up(hyp, kSolveThreads), batch);
+    ransac_solve_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, sets, kp_stride, hyp, hypF);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
+                              const int32_t *m, const float *hypF, int batch, int kp_stride, int hyp,
+                              float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,
+                              int32_t *hyp_count, float *hyp_sum) {
+    VS_REQUIRE(ctx, xy1 && xy2 && pairs && m && hypF && F && mask && best && matches, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, hyp_count && hyp_sum, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && hyp > 0, VSLAM_ERR_INVALID);
     {
         VsProfScope ps(ctx, "ransac_score_kernel");
         dim3 grid(vs_div_up(hyp, kScoreThreads), batch);
@@ -715,4 +721,14 @@ int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const i
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
+}
+
+int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
+                     const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
+                     float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,
+                     float *hypF, int32_t *hyp_count, float *hyp_sum) {
+    int rc = vs_launch_ransac_solve(ctx, xy1, xy2, pairs, m, sets, batch, kp_stride, hyp, hypF);
+    if (rc) return rc;
+    return vs_launch_ransac_evaluate(ctx, xy1, xy2, pairs, m, hypF, batch, kp_stride, hyp, threshold, F, mask,
+                                     best, matches, hyp_count, hyp_sum);
 }
