@@ -91,6 +91,12 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
         return VSLAM_ERR_HIP;
     }
     ctx->own_stream = true;
+    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return VSLAM_ERR_HIP;
+    }
     *out = ctx;
     return VSLAM_OK;
 }
@@ -106,6 +112,12 @@ int vslam_ctx_destroy(vslam_ctx *ctx) {
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VSLAM_OK;
@@ -362,13 +374,29 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
                          int32_t *d_best, float *d_F) {
     if (!ctx) return VSLAM_ERR_INVALID;
     VS_REQUIRE(ctx, pairs > 0, VSLAM_ERR_INVALID);
+    // The k-d trees are an output of the path but not an input of match/RANSAC: build them on the
+    // auxiliary stream beside the matching stages (fork after extraction, join at the end).  With
+    // per-kernel timing on, everything stays on one stream so the event brackets are clean.
+    const bool overlap = d_nodes && !ctx->prof;
     int rc = vslam_extract_features(ctx, d_bgr, 2 * pairs, width, height, row_stride, params, kp_stride,
-                                    d_xy, d_desc, d_nodes, d_n, nullptr);
+                                    d_xy, d_desc, overlap ? nullptr : d_nodes, d_n, nullptr);
     if (rc) return rc;
+    if (overlap) {
+        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->aux_stream;
+        rc = vs_launch_kdtree_build(ctx, d_xy, d_n, 2 * pairs, kp_stride, d_nodes);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        VS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    }
     const size_t half = (size_t)pairs * kp_stride;
-    return vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * half, d_desc + VSLAM_DESC_BYTES * half,
-                                d_n + pairs, pairs, kp_stride, d_seeds, hyp, threshold, d_matches, d_best,
-                                d_F, nullptr);
+    rc = vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * half, d_desc + VSLAM_DESC_BYTES * half,
+                              d_n + pairs, pairs, kp_stride, d_seeds, hyp, threshold, d_matches, d_best,
+                              d_F, nullptr);
+    if (overlap) VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return rc;
 }
 
 }  // extern "C"

@@ -26,6 +26,10 @@ struct vslam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream + fork/join events: independent stages (the k-d tree build is not an input of
+    // match/RANSAC) run beside the main stream inside vslam_frontend_pairs
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     // named, grow-only device buffers (never allocated inside a timed loop after warm-up)

@@ -185,7 +185,12 @@ __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
         const int r = i / (kCTW + 2), c = i - r * (kCTW + 2);
         const int yy = y0 - 1 + r, xx = x0 - 1 + c;
         // outside the image the dilate sees nothing: -inf never wins a max
-        E[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? src[(size_t)yy * w + xx] : -__builtin_inff();
+        float v = -__builtin_inff();
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            v = src[(size_t)yy * w + xx];
+            v = v > thr ? v : 0.f;   // THRESH_TOZERO
+        }
+        E[r][c] = v;
     }
     __syncthreads();
     const int tx = tid & 63, ty = tid >> 6;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
         if (x < w && y < h) {
             const float v = E[ly + 1][tx + 1];
             bool cand = false;
-            if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1 && v > thr) {   // interior only, val != 0
+            if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1 && v != 0.f) {   // interior only, val != 0
                 float m = v;
 #pragma unroll
                 for (int dy = 0; dy < 3; dy++)
@@ -206,10 +211,93 @@ __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
                         const float nb = E[ly + dy][tx + dx];
                         m = nb > m ? nb : m;
                     }
-                cand = (m == v);   // val == dilate(val); neighbours <= thr are 0 after TOZERO and v > thr >= 0
+                cand = (m == v);   // val == dilate(val) on the thresholded image
             }
             state[((size_t)f * h + y) * w + x] = cand ? 1 : 0;
             if (cand) mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + x);
+        }
+    }
+    uint32_t my_off = 0;
+    if (nk) my_off = atomicAdd(&s_cnt, (uint32_t)nk);
+    __syncthreads();
+    if (tid == 0 && s_cnt) s_base = atomicAdd(&counts[f], s_cnt);
+    __syncthreads();
+    for (int i = 0; i < nk; i++) {
+        const size_t pos = (size_t)s_base + my_off + i;
+        if (pos < key_cap) keys[(size_t)f * key_cap + pos] = mykeys[i];
+    }
+}
+
+// Vectorised form (width % 4 == 0): 256x16 tile, one lane = 4 adjacent pixels x 4 rows, response
+// rows staged in LDS with float4 loads, state written as one dword per lane and row.
+constexpr int kC4W = 256, kC4H = 16, kC4C = kC4W + 8;
+
+__global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
+    const float *__restrict__ eig, int w, int h, const uint32_t *__restrict__ frame_max, double quality,
+    uint8_t *__restrict__ state, unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
+    size_t key_cap) {
+    __shared__ __align__(16) float E[kC4H + 2][kC4C];   // columns x0-4 .. x0+259
+    __shared__ uint32_t s_cnt, s_base;
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kC4W, y0 = blockIdx.y * kC4H;
+    const float *src = eig + (size_t)f * w * h;
+    const float thr = (float)((double)ord2f(frame_max[f]) * quality);
+    const float ninf = -__builtin_inff();
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < (kC4H + 2) * (kC4C / 4); i += 256) {
+        const int r = i / (kC4C / 4), c = i - r * (kC4C / 4);
+        const int yy = y0 - 1 + r, xs = x0 - 4 + 4 * c;
+        float4 v = make_float4(ninf, ninf, ninf, ninf);
+        if (yy >= 0 && yy < h && xs >= 0 && xs + 3 < w) {
+            v = *reinterpret_cast<const float4 *>(src + (size_t)yy * w + xs);
+            v.x = v.x > thr ? v.x : 0.f;   // THRESH_TOZERO; outside the image stays -inf (dilate ignores it)
+            v.y = v.y > thr ? v.y : 0.f;
+            v.z = v.z > thr ? v.z : 0.f;
+            v.w = v.w > thr ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(&E[r][4 * c]) = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, grp = tid >> 6;
+    const int x = x0 + 4 * lane;
+    unsigned long long mykeys[16];
+    int nk = 0;
+    if (x < w) {
+        float win[3][6];   // rolling rows: columns x-1 .. x+4
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int r = grp * 4 + k;   // E row; image row y0 - 1 + r
+            float *dst = win[k % 3];
+            const float4 c4 = *reinterpret_cast<const float4 *>(&E[r][4 * lane + 4]);
+            dst[0] = E[r][4 * lane + 3];
+            dst[1] = c4.x; dst[2] = c4.y; dst[3] = c4.z; dst[4] = c4.w;
+            dst[5] = E[r][4 * lane + 8];
+            if (k >= 2) {
+                const int y = y0 + grp * 4 + (k - 2);
+                if (y < h) {
+                    const float *up = win[(k - 2) % 3], *mid = win[(k - 1) % 3], *dn = win[k % 3];
+                    uint32_t st = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float v = mid[i + 1];
+                        float m = up[i];
+                        m = up[i + 1] > m ? up[i + 1] : m;
+                        m = up[i + 2] > m ? up[i + 2] : m;
+                        m = mid[i] > m ? mid[i] : m;
+                        m = mid[i + 2] > m ? mid[i + 2] : m;
+                        m = dn[i] > m ? dn[i] : m;
+                        m = dn[i + 1] > m ? dn[i + 1] : m;
+                        m = dn[i + 2] > m ? dn[i + 2] : m;
+                        const int xx = x + i;
+                        const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v != 0.f && !(m > v);
+                        if (cand) {
+                            st |= 1u << (8 * i);
+                            mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + xx);
+                        }
+                    }
+                    *reinterpret_cast<uint32_t *>(state + ((size_t)f * h + y) * w + x) = st;
+                }
+            }
         }
     }
     uint32_t my_off = 0;
@@ -455,6 +543,67 @@ __global__ __launch_bounds__(kBT) void gaussian7_kernel(const uint8_t *__restric
     }
 }
 
+// Vectorised form for widths that are a multiple of 4 (every config in BASELINE.json): 256x32
+// tile, one lane = 4 adjacent pixels x 8 rows.  The gray tile sits in LDS as dwords; the row pass
+// is two v_dot4_u32_u8 per pixel on byte windows cut with v_alignbyte, its results stay in a
+// rolling 7-row register window, and the column pass runs straight from those registers, so the
+// kernel reads each gray byte once from HBM and writes each output byte once as a dword store.
+constexpr int kG4W = 256, kG4H = 32, kG4C = kG4W / 4 + 2;
+
+__global__ __launch_bounds__(256) void gaussian7_v4_kernel(const uint8_t *__restrict__ gray, int w, int h,
+                                                           uint8_t *__restrict__ out) {
+    __shared__ uint32_t G[kG4H + 6][kG4C];   // bytes x0-4 .. x0+259 of rows y0-3 .. y0+34
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kG4W, y0 = blockIdx.y * kG4H;
+    const uint8_t *src = gray + (size_t)f * w * h;
+    for (int i = tid; i < (kG4H + 6) * kG4C; i += 256) {
+        const int r = i / kG4C, c = i - r * kG4C;
+        const int xs = x0 - 4 + 4 * c;
+        const uint8_t *row = src + (size_t)reflect101(y0 - 3 + r, h) * w;
+        uint32_t v;
+        if (xs >= 0 && xs + 3 < w) {
+            v = *reinterpret_cast<const uint32_t *>(row + xs);
+        } else {
+            v = (uint32_t)row[reflect101(xs, w)] | ((uint32_t)row[reflect101(xs + 1, w)] << 8) |
+                ((uint32_t)row[reflect101(xs + 2, w)] << 16) | ((uint32_t)row[reflect101(xs + 3, w)] << 24);
+        }
+        G[r][c] = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, grp = tid >> 6;
+    const int x = x0 + 4 * lane;
+    if (x >= w) return;
+    constexpr uint32_t W0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // taps 0..3
+    constexpr uint32_t W1 = 48u | (34u << 8) | (18u << 16);                 // taps 4..6
+    uint32_t rp[7][4];
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const int r = grp * 8 + k;
+        const uint32_t d0 = G[r][lane], d1 = G[r][lane + 1], d2 = G[r][lane + 2];
+        uint32_t *dst = rp[k % 7];
+        dst[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), W0,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), W1, 0u, false), false);
+        dst[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), W0,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), W1, 0u, false), false);
+        dst[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), W0,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), W1, 0u, false), false);
+        dst[3] = __builtin_amdgcn_udot4(d1, W0, __builtin_amdgcn_udot4(d2, W1, 0u, false), false);
+        if (k >= 6) {
+            const int y = y0 + grp * 8 + (k - 6);
+            if (y < h) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t sum = 18u * (rp[(k - 6) % 7][i] + rp[k % 7][i]) + 34u * (rp[(k - 5) % 7][i] + rp[(k - 1) % 7][i]) +
+                                         48u * (rp[(k - 4) % 7][i] + rp[(k - 2) % 7][i]) + 56u * rp[(k - 3) % 7][i];
+                    packed |= ((sum + (1u << 15)) >> 16) << (8 * i);
+                }
+                *reinterpret_cast<uint32_t *>(out + ((size_t)f * h + y) * w + x) = packed;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ORB::compute for provided keypoints: border filter (ordered) + steered BRIEF
 // ------------------------------------------------------------------------------------------
@@ -596,8 +745,13 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     VS_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), ctx->stream));
     {
         VsProfScope ps(ctx, "corner_candidates_kernel");
-        dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
-        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
+        if (w % 4 == 0) {
+            dim3 grid(vs_div_up(w, kC4W), vs_div_up(h, kC4H), frames);
+            corner_candidates_v4_kernel<<<grid, 256, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
+        } else {
+            dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
+            corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
+        }
     }
     {
         int sort_cap = 2;
@@ -624,8 +778,13 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VS_REQUIRE(ctx, gray && out, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, frames > 0 && w >= 4 && h >= 4, VSLAM_ERR_INVALID);
     VsProfScope ps(ctx, "gaussian7_kernel");
-    dim3 grid(vs_div_up(w, kBTW), vs_div_up(h, kBTH), frames);
-    gaussian7_kernel<<<grid, kBT, 0, ctx->stream>>>(gray, w, h, out);
+    if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
+        dim3 grid(vs_div_up(w, kG4W), vs_div_up(h, kG4H), frames);
+        gaussian7_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, out);
+    } else {
+        dim3 grid(vs_div_up(w, kBTW), vs_div_up(h, kBTH), frames);
+        gaussian7_kernel<<<grid, kBT, 0, ctx->stream>>>(gray, w, h, out);
+    }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }
