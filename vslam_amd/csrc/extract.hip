@@ -163,6 +163,129 @@ __global__ __launch_bounds__(kET) void min_eigen_kernel(const uint8_t *__restric
     }
 }
 
+// Vectorised form (width % 4 == 0): 256x32 tile, one lane = 4 adjacent pixels x 8 rows walked top
+// to bottom with every intermediate (row-pass Sobel terms, products, double row sums) in a rolling
+// register window; only the gray tile lives in LDS.
+//
+// Border rule used here: cornerEigenValsVecs box-filters the product images with REFLECT_101, i.e.
+// the product at row -1 is the product at row 1.  Evaluating the derivative stencils at raw row -1
+// on the reflect-filled gray tile gives Dx(-1) = Dx(1) and Dy(-1) = -Dy(1) exactly (a - b ==
+// -(b - a) in IEEE), so dx*dx and dy*dy are already right and dx*dy only needs its sign flipped; the
+// same holds per mirrored column with the roles of Dx and Dy swapped.  Negation commutes with every
+// rounding, so flipping the sign of the xy product of mirrored rows/columns is bit-exact.
+constexpr int kE4W = 256, kE4H = 32, kE4C = kE4W / 4 + 2;
+
+__global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__restrict__ gray, int w, int h,
+                                                           float *__restrict__ eig,
+                                                           uint32_t *__restrict__ frame_max) {
+    __shared__ uint32_t G[kE4H + 4][kE4C];   // bytes x0-4 .. x0+259 of raw rows y0-2 .. y0+33
+    __shared__ uint32_t s_max;
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kE4W, y0 = blockIdx.y * kE4H;
+    const uint8_t *src = gray + (size_t)f * w * h;
+    if (tid == 0) s_max = 0;
+    for (int i = tid; i < (kE4H + 4) * kE4C; i += 256) {
+        const int r = i / kE4C, c = i - r * kE4C;
+        const int xs = x0 - 4 + 4 * c;
+        const uint8_t *row = src + (size_t)reflect101(y0 - 2 + r, h) * w;
+        uint32_t v;
+        if (xs >= 0 && xs + 3 < w) {
+            v = *reinterpret_cast<const uint32_t *>(row + xs);
+        } else {
+            v = (uint32_t)row[reflect101(xs, w)] | ((uint32_t)row[reflect101(xs + 1, w)] << 8) |
+                ((uint32_t)row[reflect101(xs + 2, w)] << 16) | ((uint32_t)row[reflect101(xs + 3, w)] << 24);
+        }
+        G[r][c] = v;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, grp = tid >> 6;
+    const int x = x0 + 4 * lane;
+    const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    const float k1 = (float)scale, k0 = 2.0f * k1;
+    uint32_t kmax = 0;
+    if (x < w) {
+        // column c of the 6-wide window is image column x - 1 + c; mirrored columns flip the xy sign
+        bool colflip[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) colflip[c] = (x - 1 + c < 0) || (x - 1 + c >= w);
+        float hx[3][6], rr[3][6];
+        double rs[3][12];   // rolling row sums: [slot][channel * 4 + i]
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int t = grp * 8 + k;   // tile row; raw image row y0 - 2 + t
+            const uint32_t d0 = G[t][lane], d1 = G[t][lane + 1], d2 = G[t][lane + 2];
+            int g[8];   // gray at columns x-2 .. x+5 = bytes 2..9 of the 12-byte window
+            g[0] = (d0 >> 16) & 0xFF; g[1] = d0 >> 24;
+            g[2] = d1 & 0xFF; g[3] = (d1 >> 8) & 0xFF; g[4] = (d1 >> 16) & 0xFF; g[5] = d1 >> 24;
+            g[6] = d2 & 0xFF; g[7] = (d2 >> 8) & 0xFF;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                hx[k % 3][c] = (float)(g[c + 2] - g[c]);
+                const float a = (float)g[c + 1] * k0;
+                const float b = (float)(g[c] + g[c + 2]) * k1;
+                rr[k % 3][c] = a + b;
+            }
+            if (k >= 2) {
+                // products on raw row (y0 - 2 + t) - 1
+                const int crow = y0 - 3 + t;
+                const bool rowflip = crow < 0 || crow >= h;
+                float cxx[6], cxy[6], cyy[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const float a = hx[(k - 1) % 3][c] * k0;
+                    const float b = (hx[(k - 2) % 3][c] + hx[k % 3][c]) * k1;
+                    const float dx = a + b;
+                    const float dy = rr[k % 3][c] - rr[(k - 2) % 3][c];
+                    cxx[c] = dx * dx;
+                    const float xy = dx * dy;
+                    cxy[c] = (rowflip != colflip[c]) ? -xy : xy;
+                    cyy[c] = dy * dy;
+                }
+                double *cur = rs[k % 3];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    cur[i] = ((double)cxx[i] + (double)cxx[i + 1]) + (double)cxx[i + 2];
+                    cur[4 + i] = ((double)cxy[i] + (double)cxy[i + 1]) + (double)cxy[i + 2];
+                    cur[8 + i] = ((double)cyy[i] + (double)cyy[i + 1]) + (double)cyy[i + 2];
+                }
+            }
+            if (k >= 4) {
+                const int y = y0 + grp * 8 + (k - 4);
+                if (y < h) {
+                    const double *up = rs[(k - 2) % 3], *mid = rs[(k - 1) % 3], *dn = rs[k % 3];
+                    float e4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float sxx = (float)((up[i] + mid[i]) + dn[i]);
+                        const float sxy = (float)((up[4 + i] + mid[4 + i]) + dn[4 + i]);
+                        const float syy = (float)((up[8 + i] + mid[8 + i]) + dn[8 + i]);
+                        const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
+                        const float amc = a - c;
+                        const float tt = amc * amc + b * b;
+                        const float e = (a + c) - sqrtf(tt);
+                        e4[i] = e;
+                        const uint32_t ke = f2ord(e);
+                        kmax = ke > kmax ? ke : kmax;
+                    }
+                    *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                }
+            }
+        }
+    }
+    if (frame_max) {
+        uint32_t k = kmax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(k, off, 64);
+            k = o > k ? o : k;
+        }
+        if ((tid & 63) == 0) atomicMax(&s_max, k);
+        __syncthreads();
+        if (tid == 0) atomicMax(&frame_max[f], s_max);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // threshold + 3x3 local maximum -> candidate keys and a per-pixel state map
 // ------------------------------------------------------------------------------------------
@@ -711,8 +834,13 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VS_REQUIRE(ctx, frames > 0 && w >= 3 && h >= 3, VSLAM_ERR_INVALID);
     if (frame_max_bits) VS_HIP(ctx, hipMemsetAsync(frame_max_bits, 0, sizeof(uint32_t) * (size_t)frames, ctx->stream));
     VsProfScope ps(ctx, "min_eigen_kernel");
-    dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
-    min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
+    if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && ((reinterpret_cast<uintptr_t>(eig) & 15) == 0)) {
+        dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), frames);
+        min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
+    } else {
+        dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
+        min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
+    }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }
