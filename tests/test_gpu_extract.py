@@ -146,3 +146,25 @@ def test_frontend_pairs_end_to_end(ctx, oracle):
         assert out["best"][p, 3] == k and k > 30, p
         assert np.array_equal(out["matches"][p, :k], ref["matches"]), p
         assert np.array_equal(out["F"][p].view(np.uint32), ref["F"].view(np.uint32)), p
+
+
+def test_good_features_tiny_max_corners_forces_slow_path(ctx, oracle):
+    """With a handful of corners wanted the LDS rank window (2x maxCorners) is too small when the
+    best-ranked candidates sit on response plateaus and mostly suppress each other: the kernel must
+    fall back to suppression over every candidate and still equal the sequential greedy."""
+    h, w = 120, 160
+    yy, xx = np.mgrid[0:h, 0:w]
+    board = (((yy // 8) + (xx // 8)) % 2 * 200 + 20).astype(np.uint8)
+    blobs = np.full((h, w), 30, np.uint8)
+    for cy, cx in [(30, 40), (30, 44), (34, 40), (80, 100), (80, 103), (60, 20)]:
+        blobs[cy:cy + 3, cx:cx + 3] = 220
+    noisy = synth.frames_numpy(77, 1, w, h)[0, :, :, 1]
+    gray = np.stack([board, blobs, noisy])
+    g = torch.from_numpy(gray).cuda()
+    for maxc in (1, 2, 3, 4, 7, 16):
+        xy, n = ctx.good_features(g, maxc)
+        xy, n = xy.cpu().numpy(), n.cpu().numpy()
+        for f in range(3):
+            ref = oracle.good_features(gray[f], maxc)
+            assert n[f] == len(ref), (maxc, f, n[f], len(ref))
+            assert np.array_equal(xy[f, :n[f]], ref), (maxc, f)

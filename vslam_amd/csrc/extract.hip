@@ -448,18 +448,127 @@ __global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
 // accepted in rank order are then the reference's output, in its order.
 constexpr int kST = 1024;
 
-__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *scratch /* kST/64 + 1 */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    uint32_t t = 0;
-    for (int i = 0; i < kST / 64; i++) t += scratch[i];
-    return t;
+struct SelectShared {
+    uint32_t wave_cnt[kST / 64];
+    uint32_t hist[256];
+    uint32_t flag, fill, need;
+    unsigned long long prefix;
+};
+
+// One fixpoint visit of candidate `off`: 2 = accepted, 3 = rejected, 1 = still blocked by an
+// undecided higher-ranked neighbour.  Rank = (response desc, address desc).
+__device__ __forceinline__ int nms_visit(const float *__restrict__ E, const uint8_t *S, int w, int h, uint32_t off,
+                                         int R, float min_dist_sq) {
+    const int y = off / w, x = off - y * w;
+    const float val = E[off];
+    bool blocked = false;
+    for (int dy = -R; dy <= R; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -R; dx <= R; dx++) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+            const float fx = (float)dx, fy = (float)dy;
+            if (!(fx * fx + fy * fy < min_dist_sq)) continue;
+            const uint32_t noff = (uint32_t)(yy * w + xx);
+            const uint8_t sn = S[noff];
+            if (sn == 0 || sn == 3) continue;
+            const float vn = E[noff];
+            const bool higher = (vn > val) || (vn == val && noff > off);
+            if (!higher) continue;
+            if (sn == 2) return 3;
+            blocked = true;
+        }
+    }
+    return blocked ? 1 : 2;
 }
 
+// Key T such that exactly `want` of the n distinct keys are >= T (0 when want >= n): MSB radix
+// select, 8 bits per pass, stopping as soon as a whole bucket is wanted.
+__device__ unsigned long long radix_select_nth(const unsigned long long *K, uint32_t n, uint32_t want,
+                                               SelectShared &sh) {
+    if (want >= n) return 0ull;
+    const int tid = threadIdx.x;
+    unsigned long long prefix = 0;
+    uint32_t need = want;
+    int known_bits = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 56 - 8 * pass;
+        __syncthreads();
+        for (int i = tid; i < 256; i += kST) sh.hist[i] = 0;
+        if (tid == 0) sh.flag = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kST) {
+            const unsigned long long key = K[i];
+            if (known_bits == 0 || (key >> (64 - known_bits)) == (prefix >> (64 - known_bits)))
+                atomicAdd(&sh.hist[(uint32_t)(key >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {   // bucket d is the one where the running count (from the top) crosses `need`
+            uint32_t above = 0;
+            for (int d = tid + 1; d < 256; d++) above += sh.hist[d];
+            const uint32_t mine = sh.hist[tid];
+            if (above < need && need <= above + mine) {
+                sh.prefix = prefix | ((unsigned long long)tid << shift);
+                sh.need = need - above;
+                sh.flag = (need - above == mine) ? 1u : 0u;   // whole bucket wanted: done
+            }
+        }
+        __syncthreads();
+        prefix = sh.prefix;
+        need = sh.need;
+        known_bits += 8;
+        if (sh.flag) break;
+    }
+    __syncthreads();
+    return prefix;
+}
+
+__device__ void bitonic_sort_desc(unsigned long long *buf, int cap) {
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= cap; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < cap; i += kST) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = buf[i], b = buf[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        buf[i] = b;
+                        buf[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// Gather the keys >= T into LDS (unordered) and sort them descending; returns how many.
+__device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsigned long long T,
+                                  unsigned long long *sortbuf, int sort_cap, SelectShared &sh) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) sh.fill = 0;
+    for (int i = tid; i < sort_cap; i += kST) sortbuf[i] = 0ull;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kST) {
+        const unsigned long long key = K[i];
+        if (key >= T) {
+            const uint32_t p = atomicAdd(&sh.fill, 1u);
+            if (p < (uint32_t)sort_cap) sortbuf[p] = key;
+        }
+    }
+    __syncthreads();
+    bitonic_sort_desc(sortbuf, sort_cap);
+    return sh.fill < (uint32_t)sort_cap ? sh.fill : (uint32_t)sort_cap;
+}
+
+// One workgroup per frame.
+//  fast path: only the first maxCorners ACCEPTED corners in rank order are wanted, and a
+//    candidate's fate depends on higher-ranked candidates only, so suppression is run on the N
+//    best-ranked candidates (N a little above maxCorners), sorted in LDS; if they yield fewer than
+//    maxCorners survivors N is doubled (decisions already made stay valid).
+//  slow path (N would exceed the LDS sort buffer): suppression over every candidate, then select.
 __global__ __launch_bounds__(kST) void corner_select_kernel(
     const float *__restrict__ eig, int w, int h, uint8_t *__restrict__ state,
     unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
@@ -467,73 +576,112 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
     int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(smem_raw);
-    __shared__ uint32_t s_scratch[kST / 64 + 1];
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_flag, s_fill;
-    __shared__ unsigned long long s_prefix;
-    __shared__ uint32_t s_need;
+    __shared__ SelectShared sh;
 
     const int f = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const float *E = eig + (size_t)f * w * h;
     uint8_t *S = state + (size_t)f * w * h;
     unsigned long long *K = keys + (size_t)f * key_cap;
+    float2 *O = reinterpret_cast<float2 *>(out_xy) + (size_t)f * kp_stride;
     uint32_t n = counts[f];
     if (n > key_cap) {
         if (tid == 0) atomicAdd(overflow, 1);
         n = (uint32_t)key_cap;
     }
-
-    // ---- suppression fixpoint
     const int R = min_dist >= 1.f ? (int)ceilf(min_dist) : 0;
+    const uint32_t want_max = (uint32_t)max_corners;
+
+    // ---------------------------------------------------------------- fast path
+    bool done = false;
+    {
+        uint32_t N = want_max + want_max / 4 + 64;
+        if (R == 0) N = want_max;
+        while (true) {
+            if (N > n) N = n;
+            if (N > (uint32_t)sort_cap) N = (uint32_t)sort_cap;
+            const unsigned long long T = radix_select_nth(K, n, N, sh);
+            const uint32_t got = gather_sorted(K, n, T, sortbuf, sort_cap, sh);   // == N
+            if (R > 0) {
+                while (true) {   // suppression fixpoint over the N best-ranked candidates
+                    __syncthreads();
+                    if (tid == 0) sh.flag = 0;
+                    __syncthreads();
+                    bool pending = false;
+                    for (uint32_t i = tid; i < got; i += kST) {
+                        const uint32_t off = (uint32_t)sortbuf[i];
+                        if (S[off] != 1) continue;
+                        const int d = nms_visit(E, S, w, h, off, R, min_dist_sq);
+                        if (d == 1) pending = true;
+                        else S[off] = (uint8_t)d;
+                    }
+                    if (pending) sh.flag = 1;
+                    __syncthreads();
+                    if (!sh.flag) break;
+                }
+            }
+            // survivors in rank order: ordered scan over the sorted buffer
+            __syncthreads();
+            uint32_t base = 0;
+            for (uint32_t i0 = 0; i0 < got; i0 += kST) {
+                const uint32_t i = i0 + tid;
+                uint32_t off = 0;
+                bool acc = false;
+                if (i < got) {
+                    off = (uint32_t)sortbuf[i];
+                    acc = (R == 0) || S[off] == 2;
+                }
+                const unsigned long long bal = __ballot(acc);
+                __syncthreads();
+                if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t pre = 0, tot = 0;
+                for (int wv = 0; wv < kST / 64; wv++) {
+                    const uint32_t c = sh.wave_cnt[wv];
+                    if (wv < wave) pre += c;
+                    tot += c;
+                }
+                const uint32_t pos = base + pre + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                // written speculatively: if this attempt falls short the next one rewrites the
+                // same prefix with the same values (rank order does not change)
+                if (acc && pos < want_max) {
+                    const int y = off / w, x = off - y * w;
+                    O[pos] = make_float2((float)x, (float)y);
+                }
+                base += tot;
+            }
+            if (base >= want_max || got == n) {
+                if (tid == 0) out_n[f] = (int32_t)(base < want_max ? base : want_max);
+                done = true;
+                break;
+            }
+            if (N == (uint32_t)sort_cap) break;   // cannot widen in LDS: slow path
+            N *= 2;
+        }
+    }
+    if (done) return;
+
+    // ---------------------------------------------------------------- slow path (rare)
     if (R > 0) {
         while (true) {
             __syncthreads();
-            if (tid == 0) s_flag = 0;
+            if (tid == 0) sh.flag = 0;
             __syncthreads();
             bool pending = false;
             for (uint32_t i = tid; i < n; i += kST) {
                 const uint32_t off = (uint32_t)K[i];
                 if (S[off] != 1) continue;
-                const int y = off / w, x = off - y * w;
-                const float val = E[off];
-                bool rejected = false, blocked = false;
-                for (int dy = -R; dy <= R && !rejected; dy++) {
-                    const int yy = y + dy;
-                    if (yy < 0 || yy >= h) continue;
-                    for (int dx = -R; dx <= R; dx++) {
-                        const int xx = x + dx;
-                        if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
-                        const float fx = (float)dx, fy = (float)dy;
-                        if (!(fx * fx + fy * fy < min_dist_sq)) continue;
-                        const uint32_t noff = (uint32_t)(yy * w + xx);
-                        const uint8_t sn = S[noff];
-                        if (sn == 0 || sn == 3) continue;
-                        const float vn = E[noff];
-                        const bool higher = (vn > val) || (vn == val && noff > off);
-                        if (!higher) continue;
-                        if (sn == 2) {
-                            rejected = true;
-                            break;
-                        }
-                        blocked = true;
-                    }
-                }
-                if (rejected) S[off] = 3;
-                else if (!blocked) S[off] = 2;
-                else pending = true;
+                const int d = nms_visit(E, S, w, h, off, R, min_dist_sq);
+                if (d == 1) pending = true;
+                else S[off] = (uint8_t)d;
             }
-            if (pending) s_flag = 1;
+            if (pending) sh.flag = 1;
             __syncthreads();
-            if (!s_flag) break;
+            if (!sh.flag) break;
         }
-    } else {
-        for (uint32_t i = tid; i < n; i += kST) S[(uint32_t)K[i]] = 2;
     }
     __syncthreads();
-
-    // ---- compact accepted keys to the front of K (unordered; entries are read before any write
-    //      of the same round can reach them)
+    // compact accepted keys to the front of K (entries are read before any write of the same round)
     uint32_t n_acc = 0;
     for (uint32_t base = 0; base < n; base += kST) {
         const uint32_t i = base + tid;
@@ -541,15 +689,15 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
         bool acc = false;
         if (i < n) {
             key = K[i];
-            acc = S[(uint32_t)key] == 2;
+            acc = (R == 0) || S[(uint32_t)key] == 2;
         }
         const unsigned long long bal = __ballot(acc);
         __syncthreads();
-        if (lane == 0) s_scratch[wave] = (uint32_t)__popcll(bal);
+        if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t pre = 0, tot = 0;
         for (int wv = 0; wv < kST / 64; wv++) {
-            const uint32_t c = s_scratch[wv];
+            const uint32_t c = sh.wave_cnt[wv];
             if (wv < wave) pre += c;
             tot += c;
         }
@@ -557,77 +705,16 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
         n_acc += tot;
     }
     __syncthreads();
-
-    // ---- threshold key of the max_corners-th best (MSB radix select, 8 bits per pass)
-    const uint32_t want = n_acc < (uint32_t)max_corners ? n_acc : (uint32_t)max_corners;
-    unsigned long long prefix = 0;
-    int known_bits = 0;
-    if (n_acc > want && want > 0) {
-        uint32_t need = want;   // how many of the keys matching `prefix` are still wanted
-        for (int pass = 0; pass < 8; pass++) {
-            const int shift = 56 - 8 * pass;
-            for (int i = tid; i < 256; i += kST) s_hist[i] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < n_acc; i += kST) {
-                const unsigned long long key = K[i];
-                if (known_bits == 0 || (key >> (64 - known_bits)) == (prefix >> (64 - known_bits)))
-                    atomicAdd(&s_hist[(uint32_t)(key >> shift) & 0xFFu], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t acc = 0;
-                int d = 255;
-                for (; d > 0; d--) {
-                    if (acc + s_hist[d] >= need) break;
-                    acc += s_hist[d];
-                }
-                s_prefix = prefix | ((unsigned long long)d << shift);
-                s_need = need - acc;
-            }
-            __syncthreads();
-            prefix = s_prefix;
-            need = s_need;
-            known_bits += 8;
-            __syncthreads();
-        }
-    }
-    // keys are distinct (the offset is part of the key): exactly `want` keys are >= prefix
-
-    // ---- gather the winners into LDS, sort descending, emit
-    if (tid == 0) s_fill = 0;
-    for (int i = tid; i < sort_cap; i += kST) sortbuf[i] = 0ull;
-    __syncthreads();
-    for (uint32_t i = tid; i < n_acc; i += kST) {
-        const unsigned long long key = K[i];
-        if (key >= prefix) {
-            const uint32_t p = atomicAdd(&s_fill, 1u);
-            if (p < (uint32_t)sort_cap) sortbuf[p] = key;
-        }
-    }
-    __syncthreads();
-    for (int k = 2; k <= sort_cap; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < sort_cap; i += kST) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = sortbuf[i], b = sortbuf[ixj];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < b) : (a > b)) {
-                        sortbuf[i] = b;
-                        sortbuf[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    float2 *O = reinterpret_cast<float2 *>(out_xy) + (size_t)f * kp_stride;
+    uint32_t want = n_acc < want_max ? n_acc : want_max;
+    if (want > (uint32_t)sort_cap) want = (uint32_t)sort_cap;
+    const unsigned long long T = radix_select_nth(K, n_acc, want, sh);
+    gather_sorted(K, n_acc, T, sortbuf, sort_cap, sh);
     for (uint32_t i = tid; i < want; i += kST) {
         const uint32_t off = (uint32_t)sortbuf[i];
         const int y = off / w, x = off - y * w;
         O[i] = make_float2((float)x, (float)y);
     }
     if (tid == 0) out_n[f] = (int32_t)want;
-    (void)block_sum_u32;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -883,7 +970,8 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     }
     {
         int sort_cap = 2;
-        while (sort_cap < max_corners) sort_cap <<= 1;
+        while (sort_cap < 2 * max_corners && sort_cap < 16384) sort_cap <<= 1;
+        while (sort_cap < max_corners) sort_cap <<= 1;   // at least max_corners slots
         const size_t lds = sizeof(unsigned long long) * (size_t)sort_cap;
         VS_REQUIRE(ctx, lds <= 128 * 1024, VSLAM_ERR_CAPACITY);
         static bool attr_set = false;
