@@ -52,6 +52,28 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
     return table.get(kernel, 0)
 
 
+# VALU issue slots per unit of work, counted in the gfx950 ISA of the inner loops;
+# f64-rate instructions count as two slots.
+VALU_SLOTS = {
+    "ransac_score_kernel": ("(hypothesis, match) evaluations", 62.0),
+    "match_knn2_kernel": ("(query, train) descriptor pairs", 21.0),
+}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/, C3 batch of 256 pairs);
+    bench.py cannot collect PMC counters on itself."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc_hbm_traffic.csv")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["kernel"].replace("_v4", "") == kernel:
+                return (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
+    return None
+
+
 def cpu_baseline(wl, sample_pairs, seed):
     """The oracle (oracle/, a CPU port of the reference path; the reference itself cannot be built
     here) on `sample_pairs` pairs of the same workload, one thread."""
@@ -83,6 +105,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch)")
     ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs the CPU baseline times (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--pmc-calibrate", action="store_true",
+                    help="also run two 1 GiB streaming copies (4 B and 16 B per lane) so FETCH_SIZE/WRITE_SIZE can be calibrated")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,8 +121,15 @@ def main():
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # VSLAM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks
+        # (ranks then share devices and the record gather goes through host memory)
+        backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -121,7 +152,19 @@ def main():
         out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
         if world > 1:
             # the only exchange on the path: fixed-size per-pair result records to every rank
-            shard.gather_records(shard.pack_records(out["F"], out["best"], out["matches"]), world, out=gathered)
+            rec = shard.pack_records(out["F"], out["best"], out["matches"])
+            if dist.get_backend() == "nccl":
+                shard.gather_records(rec, world, out=gathered)
+            else:
+                gathered.copy_(shard.gather_records(rec.cpu(), world))
+
+    if args.pmc_calibrate and rank == 0:
+        a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
+        b = torch.empty_like(a)
+        ctx.debug_stream_copy(a, b, 4)
+        ctx.debug_stream_copy(a, b, 16)
+        ctx.synchronize()
+        del a, b
 
     for _ in range(args.warmup):
         step()
@@ -138,7 +181,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -182,10 +225,19 @@ def main():
                             "alg_GBps": alg / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
         kernels.sort(key=lambda k: -k["ms_per_launch"] * k["launches_per_step"])
         top = kernels[0]
+        traffic = pmc_traffic(top["kernel"]) if (args.workload == "C3" and P == WORKLOADS["C3"][4]) else None
         result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": None,
-                              "avg_launch_ms": top["ms_per_launch"],
-                              "note": "VALU-issue-bound kernel (DESIGN.md): algorithmic bytes are tiny next to its arithmetic"}
+                              "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                              "avg_launch_ms": top["ms_per_launch"]}
+        if top["kernel"] in VALU_SLOTS:
+            what, slots = VALU_SLOTS[top["kernel"]]
+            work = (H * m_prelim if top["kernel"] == "ransac_score_kernel" else float(n_kp.mean()) ** 2) * P
+            tops = work * slots / (top["ms_per_launch"] * 1e-3) / 1e12
+            result["roofline"]["valu"] = {"achieved": tops, "peak": VALU_PEAK_GOPS / 1e3, "unit": "T lane-slots/s",
+                                          "frac": tops / (VALU_PEAK_GOPS / 1e3), "work": what, "slots_per_unit": slots}
+            result["roofline"]["note"] = ("this kernel is VALU-issue bound by construction (SURVEY.md 8d): its compulsory "
+                                          "bytes are a rounding error next to its arithmetic, so the HBM fraction is "
+                                          "small by design; `valu` is the ceiling that binds")
         result["kernels"] = kernels
         result["profile_pass_ms_per_step"] = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels)
 

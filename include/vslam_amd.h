@@ -62,6 +62,10 @@ int vslam_prof_reset(vslam_ctx *ctx);
 int vslam_prof_count(vslam_ctx *ctx);   /* synchronises, folds pending events, returns #kernels */
 int vslam_prof_get(vslam_ctx *ctx, int i, char *name, int name_cap, double *total_ms, int64_t *launches);
 
+/* profiling aid: a plain streaming copy of `bytes` (multiple of 16) with 4 or 16 bytes per lane, so
+ * rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count per access width */
+int vslam_debug_stream_copy(vslam_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int bytes_per_lane);
+
 /* ----------------------------------------------------------------- matching */
 /* Replaces match_features' front half, src/Frame.cpp:83-94:
  *   BFMatcher(NORM_HAMMING)->knnMatch(desc1, desc2, k=2) + `m[0].distance < m[1].distance*0.7`.

@@ -73,7 +73,31 @@ static int vs_prof_fold(vslam_ctx *ctx) {
     return VSLAM_OK;
 }
 
+// Known-byte-count streaming copies used only to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE
+// counters for this repo's two access widths (4 B and 16 B per lane), as MI355X_MICROARCH.md asks.
+__global__ __launch_bounds__(256) void pmc_calib_copy4_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                              size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void pmc_calib_copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                               size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 extern "C" {
+
+int vslam_debug_stream_copy(vslam_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int bytes_per_lane) {
+    if (!ctx || !d_src || !d_dst || (bytes_per_lane != 4 && bytes_per_lane != 16) || bytes % 16) return VSLAM_ERR_INVALID;
+    if (bytes_per_lane == 4) {
+        VsProfScope ps(ctx, "pmc_calib_copy4_kernel");
+        pmc_calib_copy4_kernel<<<2048, 256, 0, ctx->stream>>>((const uint32_t *)d_src, (uint32_t *)d_dst, bytes / 4);
+    } else {
+        VsProfScope ps(ctx, "pmc_calib_copy16_kernel");
+        pmc_calib_copy16_kernel<<<2048, 256, 0, ctx->stream>>>((const uint4 *)d_src, (uint4 *)d_dst, bytes / 16);
+    }
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
 
 const char *vslam_version(void) { return "vslam_amd 0.1 (gfx950)"; }
 

@@ -77,6 +77,18 @@ struct VsProfScope {
 
 static inline int vs_div_up(int a, int b) { return (a + b - 1) / b; }
 
+#ifdef __HIPCC__
+// Workgroups are dealt round-robin over the 8 XCDs (linear id L lands on XCD L % 8 — observed, used
+// for speed only, never for correctness).  Remap a 1-D grid of ceil(items/8)*8*per_item blocks so that
+// all `per_item` blocks of one item (frame / pair) share an XCD and therefore its 4 MiB L2.
+__device__ __forceinline__ void vs_xcd_item_block(int linear, int per_item, int &item, int &blk) {
+    const int xcd = linear & 7, slot = linear >> 3;
+    item = ((slot / per_item) << 3) + xcd;
+    blk = slot - (slot / per_item) * per_item;
+}
+#endif
+static inline int vs_xcd_grid(int items, int per_item) { return vs_div_up(items, 8) * 8 * per_item; }
+
 // ---- stage launchers implemented in the .hip files (all async on ctx->stream) ----
 int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const uint8_t *d2,
                     const int32_t *n2, int batch, int kp_stride, int32_t *pairs, int32_t *m,

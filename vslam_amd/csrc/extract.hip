@@ -868,11 +868,14 @@ __global__ __launch_bounds__(kKT) void rbrief_kernel(const uint8_t *__restrict__
                                                      const float *__restrict__ xy, const int32_t *__restrict__ n_arr,
                                                      int kp_stride, float ca, float sa,
                                                      const int8_t *__restrict__ pattern,
-                                                     uint8_t *__restrict__ desc) {
+                                                     uint8_t *__restrict__ desc, int frames, int per_frame) {
     __shared__ int s_off[512];
-    const int f = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int f, bx;
+    vs_xcd_item_block(blockIdx.x, per_frame, f, bx);   // a frame's patches are gathered through one XCD's L2
+    if (f >= frames) return;
     const int n = n_arr[f];
-    const int kp0 = blockIdx.x * (kKT / 32);
+    const int kp0 = bx * (kKT / 32);
     if (kp0 >= n) return;
     for (int i = tid; i < 512; i += kKT) {
         const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
@@ -1016,8 +1019,9 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
     }
     {
         VsProfScope ps(ctx, "rbrief_kernel");
-        dim3 grid(vs_div_up(kp_stride, kKT / 32), frames);
-        rbrief_kernel<<<grid, kKT, 0, ctx->stream>>>(blurred, w, h, xy_out, n_out, kp_stride, ca, sa, pattern, desc);
+        const int per_frame = vs_div_up(kp_stride, kKT / 32);
+        rbrief_kernel<<<vs_xcd_grid(frames, per_frame), kKT, 0, ctx->stream>>>(blurred, w, h, xy_out, n_out, kp_stride, ca,
+                                                                                sa, pattern, desc, frames, per_frame);
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
