@@ -15,11 +15,14 @@ static int g_heap_calls = 0;
 struct Item { float key; int id; };
 struct Store {
     using value_type = Item;
+    using key_type = float;
     std::vector<Item> *v;
+    float key(int i) const { return (*v)[i].key; }
+    float key_of(const Item &x) const { return x.key; }
     Item get(int i) const { return (*v)[i]; }
     void set(int i, const Item &x) { (*v)[i] = x; }
     void swap(int i, int j) { std::swap((*v)[i], (*v)[j]); }
-    bool less(const Item &a, const Item &b) const { return a.key < b.key; }
+    bool less(float a, float b) const { return a < b; }
 };
 
 static bool run_case(std::vector<Item> base, int first, int nth, int last) {

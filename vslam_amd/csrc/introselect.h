@@ -12,9 +12,12 @@
 // tests/test_introselect.py compiles this header for the host and checks the final permutation
 // against the platform's std::nth_element on tie-heavy and adversarial inputs.
 //
-// Store concept:  struct S { using value_type = ...;
+// Store concept:  struct S { using value_type = ...; using key_type = ...;
 //   value_type get(int i) const; void set(int i, const value_type&); void swap(int i, int j);
-//   bool less(const value_type& a, const value_type& b) const; }
+//   key_type key(int i) const;  key_type key_of(const value_type&) const;
+//   bool less(key_type a, key_type b) const; }
+// Comparisons only ever look at keys, so the scanning loops touch one word per element; whole
+// elements move only in swaps and shifts.
 #pragma once
 
 #ifdef __HIPCC__
@@ -41,7 +44,7 @@ VS_HD inline int floor_lg(int n) {   // std::__lg
 
 template <class S>
 VS_HD inline void move_median_to_first(S &s, int result, int a, int b, int c) {
-    const auto va = s.get(a), vb = s.get(b), vc = s.get(c);
+    const auto va = s.key(a), vb = s.key(b), vc = s.key(c);
     if (s.less(va, vb)) {
         if (s.less(vb, vc)) s.swap(result, b);
         else if (s.less(va, vc)) s.swap(result, c);
@@ -53,11 +56,11 @@ VS_HD inline void move_median_to_first(S &s, int result, int a, int b, int c) {
 
 template <class S>
 VS_HD inline int unguarded_partition(S &s, int first, int last, int pivot) {
-    const auto pv = s.get(pivot);   // *pivot is never moved by the swaps below (pivot < first)
+    const auto pv = s.key(pivot);   // *pivot is never moved by the swaps below (pivot < first)
     while (true) {
-        while (s.less(s.get(first), pv)) ++first;
+        while (s.less(s.key(first), pv)) ++first;
         --last;
-        while (s.less(pv, s.get(last))) --last;
+        while (s.less(pv, s.key(last))) --last;
         if (!(first < last)) return first;
         s.swap(first, last);
         ++first;
@@ -76,12 +79,13 @@ VS_HD inline void insertion_sort(S &s, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
         const auto val = s.get(i);
-        if (s.less(val, s.get(first))) {
+        const auto vk = s.key_of(val);
+        if (s.less(vk, s.key(first))) {
             for (int k = i; k > first; --k) s.set(k, s.get(k - 1));   // move_backward
             s.set(first, val);
         } else {   // __unguarded_linear_insert
             int hole = i, next = i - 1;
-            while (s.less(val, s.get(next))) {
+            while (s.less(vk, s.key(next))) {
                 s.set(hole, s.get(next));
                 hole = next;
                 --next;
@@ -95,7 +99,8 @@ VS_HD inline void insertion_sort(S &s, int first, int last) {
 template <class S, class V>
 VS_HD inline void push_heap_rel(S &s, int first, int hole, int top, const V &value) {
     int parent = (hole - 1) / 2;
-    while (hole > top && s.less(s.get(first + parent), value)) {
+    const auto vk = s.key_of(value);
+    while (hole > top && s.less(s.key(first + parent), vk)) {
         s.set(first + hole, s.get(first + parent));
         hole = parent;
         parent = (hole - 1) / 2;
@@ -109,7 +114,7 @@ VS_HD inline void adjust_heap(S &s, int first, int hole, int len, const V &value
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (s.less(s.get(first + child), s.get(first + child - 1))) child--;
+        if (s.less(s.key(first + child), s.key(first + child - 1))) child--;
         s.set(first + hole, s.get(first + child));
         hole = child;
     }
@@ -138,7 +143,7 @@ template <class S>
 VS_HD inline void heap_select(S &s, int first, int middle, int last) {
     make_heap(s, first, middle);
     for (int i = middle; i < last; ++i)
-        if (s.less(s.get(i), s.get(first))) {   // __pop_heap(first, middle, i)
+        if (s.less(s.key(i), s.key(first))) {   // __pop_heap(first, middle, i)
             const auto v = s.get(i);
             s.set(i, s.get(first));
             adjust_heap(s, first, 0, middle - first, v);

@@ -31,9 +31,12 @@ struct Triple {
 
 struct LdsStore {
     using value_type = Triple;
+    using key_type = float;
     float *kx, *ky;
     int *id;
-    int axis;
+    const float *kaxis;   // kx or ky: the coordinate this level splits on
+    bool use_y;
+    __device__ LdsStore(float *x, float *y, int *i, int axis) : kx(x), ky(y), id(i), kaxis(axis ? y : x), use_y(axis != 0) {}
     __device__ Triple get(int i) const { return Triple{kx[i], ky[i], id[i]}; }
     __device__ void set(int i, const Triple &t) {
         kx[i] = t.x;
@@ -45,10 +48,10 @@ struct LdsStore {
         set(i, b);
         set(j, a);
     }
+    __device__ float key(int i) const { return kaxis[i]; }
+    __device__ float key_of(const Triple &t) const { return use_y ? t.y : t.x; }
     // P(points[i1], axis) < P(points[i2], axis), src/KDTree.cpp:128
-    __device__ bool less(const Triple &a, const Triple &b) const {
-        return axis == 0 ? (a.x < b.x) : (a.y < b.y);
-    }
+    __device__ bool less(float a, float b) const { return a < b; }
 };
 
 __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float *__restrict__ xy,
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float
                 }
             }
             if (last > first) {
-                LdsStore s{kx, ky, id, depth & 1};
+                LdsStore s(kx, ky, id, depth & 1);
                 const int mid = first + (last - first) / 2;
                 vs_sel::nth_element(s, first, mid, last);
                 out[pos] = id[mid];
