@@ -175,15 +175,34 @@ __global__ __launch_bounds__(kET) void min_eigen_kernel(const uint8_t *__restric
 // rounding, so flipping the sign of the xy product of mirrored rows/columns is bit-exact.
 constexpr int kE4W = 256, kE4H = 32, kE4C = kE4W / 4 + 2;
 
+// FUSED = false: plain cornerMinEigenVal (tile owns all 256x32 pixels it computes).
+// FUSED = true : the same strip computation, but tiles overlap by one lane / one row on every side
+//   (owned region 248x30), the responses also go to an LDS tile, and after one barrier every owned
+//   pixel is tested for being a 3x3 maximum, which replaces a second pass over the response image.
+//   The corner threshold needs the frame's maximum, which is not known yet, so candidates are
+//   prefiltered with the running maximum (always <= the final one, hence a superset) and
+//   corner_select_kernel applies the exact threshold.  Valid when the final maximum is >= 0 (then
+//   "3x3 maximum of the thresholded image" == "3x3 maximum of the raw image and above threshold");
+//   frames with a negative maximum are redone by corner_candidates_v4_kernel.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__restrict__ gray, int w, int h,
                                                            float *__restrict__ eig,
-                                                           uint32_t *__restrict__ frame_max) {
+                                                           uint32_t *__restrict__ frame_max, double quality,
+                                                           uint8_t *__restrict__ state,
+                                                           unsigned long long *__restrict__ keys,
+                                                           uint32_t *__restrict__ counts, size_t key_cap) {
     __shared__ uint32_t G[kE4H + 4][kE4C];   // bytes x0-4 .. x0+259 of raw rows y0-2 .. y0+33
-    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_max, s_cnt, s_base;
+    __shared__ __align__(16) float ET[FUSED ? kE4H : 1][FUSED ? kE4W + 8 : 4];   // responses, columns x0-4 .. x0+259
     const int f = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * kE4W, y0 = blockIdx.y * kE4H;
+    const int x0 = FUSED ? blockIdx.x * (kE4W - 8) - 4 : blockIdx.x * kE4W;
+    const int y0 = FUSED ? blockIdx.y * (kE4H - 2) - 1 : blockIdx.y * kE4H;
     const uint8_t *src = gray + (size_t)f * w * h;
-    if (tid == 0) s_max = 0;
+    const uint32_t seen_max = (FUSED && frame_max) ? frame_max[f] : 0u;   // loaded early, used after the strip loop
+    if (tid == 0) {
+        s_max = 0;
+        s_cnt = 0;
+    }
     for (int i = tid; i < (kE4H + 4) * kE4C; i += 256) {
         const int r = i / kE4C, c = i - r * kE4C;
         const int xs = x0 - 4 + 4 * c;
@@ -203,8 +222,10 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
     const int x = x0 + 4 * lane;
     const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0);
     const float k1 = (float)scale, k0 = 2.0f * k1;
+    const float ninf = -__builtin_inff();
+    const bool own_lane = !FUSED || (lane >= 1 && lane <= 62);
     uint32_t kmax = 0;
-    if (x < w) {
+    if (x >= 0 && x < w) {
         // column c of the 6-wide window is image column x - 1 + c; mirrored columns flip the xy sign
         bool colflip[6];
 #pragma unroll
@@ -251,10 +272,11 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
                 }
             }
             if (k >= 4) {
-                const int y = y0 + grp * 8 + (k - 4);
-                if (y < h) {
+                const int lr = grp * 8 + (k - 4);   // row inside the tile
+                const int y = y0 + lr;
+                float e4[4] = {ninf, ninf, ninf, ninf};
+                if (y >= 0 && y < h) {
                     const double *up = rs[(k - 2) % 3], *mid = rs[(k - 1) % 3], *dn = rs[k % 3];
-                    float e4[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const float sxx = (float)((up[i] + mid[i]) + dn[i]);
@@ -263,15 +285,24 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
                         const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
                         const float amc = a - c;
                         const float tt = amc * amc + b * b;
-                        const float e = (a + c) - sqrtf(tt);
-                        e4[i] = e;
-                        const uint32_t ke = f2ord(e);
-                        kmax = ke > kmax ? ke : kmax;
+                        e4[i] = (a + c) - sqrtf(tt);
                     }
-                    *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                    const bool own = own_lane && (!FUSED || (lr >= 1 && lr <= kE4H - 2));
+                    if (own) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t ke = f2ord(e4[i]);
+                            kmax = ke > kmax ? ke : kmax;
+                        }
+                        *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                    }
                 }
+                if (FUSED) *reinterpret_cast<float4 *>(&ET[lr][4 * lane + 4]) = make_float4(e4[0], e4[1], e4[2], e4[3]);
             }
         }
+    } else if (FUSED) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) *reinterpret_cast<float4 *>(&ET[grp * 8 + k][4 * lane + 4]) = make_float4(ninf, ninf, ninf, ninf);
     }
     if (frame_max) {
         uint32_t k = kmax;
@@ -282,8 +313,79 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
         }
         if ((tid & 63) == 0) atomicMax(&s_max, k);
         __syncthreads();
-        if (tid == 0) atomicMax(&frame_max[f], s_max);
+        if (tid == 0) atomicMax(&frame_max[f], s_max);   // fire and forget
     }
+    if (!FUSED) return;
+    __syncthreads();
+
+    // ---- 3x3 maxima of the owned pixels (lanes 1..62, tile rows 1..30), prefiltered by the running maximum
+    // running maximum = what other tiles had published when this one started, or this tile's own
+    const uint32_t run_max = seen_max > s_max ? seen_max : s_max;
+    const float thr_p = (float)((double)ord2f(run_max) * quality);
+    uint32_t cmask = 0;   // bit (8 rows x 4 pixels) set where this lane found a candidate
+    if (own_lane && x >= 0 && x < w) {
+        float win[3][6];   // rolling rows, columns x-1 .. x+4: one b128 + two b32 LDS reads per row
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int lr = grp * 8 + k - 1;   // tile row being loaded (0 .. 31 where it exists)
+            float *dst = win[k % 3];
+            if (lr >= 0 && lr < kE4H) {
+                const float4 c4 = *reinterpret_cast<const float4 *>(&ET[lr][4 * lane + 4]);
+                dst[0] = ET[lr][4 * lane + 3];
+                dst[1] = c4.x; dst[2] = c4.y; dst[3] = c4.z; dst[4] = c4.w;
+                dst[5] = ET[lr][4 * lane + 8];
+            }
+            if (k >= 2) {
+                const int tr = lr - 1;   // row under test
+                const int y = y0 + tr;
+                if (tr >= 1 && tr <= kE4H - 2 && y >= 0 && y < h) {
+                    const float *up = win[(k - 2) % 3], *mid = win[(k - 1) % 3], *dn = win[k % 3];
+                    uint32_t st = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float v = mid[i + 1];
+                        float m = up[i];
+                        m = up[i + 1] > m ? up[i + 1] : m;
+                        m = up[i + 2] > m ? up[i + 2] : m;
+                        m = mid[i] > m ? mid[i] : m;
+                        m = mid[i + 2] > m ? mid[i + 2] : m;
+                        m = dn[i] > m ? dn[i] : m;
+                        m = dn[i + 1] > m ? dn[i + 1] : m;
+                        m = dn[i + 2] > m ? dn[i + 2] : m;
+                        const int xx = x + i;
+                        const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v > thr_p && !(m > v);
+                        if (cand) {
+                            st |= 1u << (8 * i);
+                            cmask |= 1u << (4 * (k - 2) + i);
+                        }
+                    }
+                    *reinterpret_cast<uint32_t *>(state + ((size_t)f * h + y) * w + x) = st;
+                }
+            }
+        }
+    }
+    const int nk = __popc(cmask);
+    uint32_t my_off = 0;
+    if (nk) my_off = atomicAdd(&s_cnt, (uint32_t)nk);
+    __syncthreads();
+    if (tid == 0 && s_cnt) s_base = atomicAdd(&counts[f], s_cnt);
+    __syncthreads();
+    size_t pos = (size_t)s_base + my_off;
+    while (cmask) {
+        const int b = __ffs(cmask) - 1;
+        cmask &= cmask - 1;
+        const int lr = grp * 8 + (b >> 2), i = b & 3;
+        const float v = ET[lr][4 * lane + 4 + i];
+        if (pos < key_cap)
+            keys[(size_t)f * key_cap + pos] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)((y0 + lr) * w + x + i);
+        pos++;
+    }
+}
+
+// frames whose maximum response is negative cannot use the fused candidates: forget them
+__global__ void negative_max_reset_kernel(const uint32_t *__restrict__ frame_max, uint32_t *__restrict__ counts, int frames) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < frames && ord2f(frame_max[f]) < 0.f) counts[f] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -358,10 +460,11 @@ constexpr int kC4W = 256, kC4H = 16, kC4C = kC4W + 8;
 __global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
     const float *__restrict__ eig, int w, int h, const uint32_t *__restrict__ frame_max, double quality,
     uint8_t *__restrict__ state, unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
-    size_t key_cap) {
+    size_t key_cap, int only_negative_max) {
     __shared__ __align__(16) float E[kC4H + 2][kC4C];   // columns x0-4 .. x0+259
     __shared__ uint32_t s_cnt, s_base;
     const int f = blockIdx.z, tid = threadIdx.x;
+    if (only_negative_max && !(ord2f(frame_max[f]) < 0.f)) return;
     const int x0 = blockIdx.x * kC4W, y0 = blockIdx.y * kC4H;
     const float *src = eig + (size_t)f * w * h;
     const float thr = (float)((double)ord2f(frame_max[f]) * quality);
@@ -573,7 +676,8 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
     const float *__restrict__ eig, int w, int h, uint8_t *__restrict__ state,
     unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
     int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
-    int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow) {
+    int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow,
+    const uint32_t *__restrict__ frame_max, double quality) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(smem_raw);
     __shared__ SelectShared sh;
@@ -591,6 +695,38 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
     }
     const int R = min_dist >= 1.f ? (int)ceilf(min_dist) : 0;
     const uint32_t want_max = (uint32_t)max_corners;
+
+    // ---- exact threshold: the fused detector prefilters with a running maximum, so drop keys
+    //      whose response is not > (float)(max * quality)  (a no-op for exactly-thresholded lists)
+    {
+        float thr = (float)((double)ord2f(frame_max[f]) * quality);
+        if (thr == 0.f) thr = 0.f;   // -0 -> +0 so the ordered-key compare equals the float compare
+        const unsigned long long tkey = ((unsigned long long)f2ord(thr) << 32) | 0xFFFFFFFFull;
+        uint32_t kept = 0;
+        for (uint32_t base = 0; base < n; base += kST) {
+            const uint32_t i = base + tid;
+            unsigned long long key = 0;
+            bool keep = false;
+            if (i < n) {
+                key = K[i];
+                keep = key > tkey;
+            }
+            const unsigned long long bal = __ballot(keep);
+            __syncthreads();
+            if (lane == 0) sh.wave_cnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+            for (int wv = 0; wv < kST / 64; wv++) {
+                const uint32_t c = sh.wave_cnt[wv];
+                if (wv < wave) pre += c;
+                tot += c;
+            }
+            if (keep) K[kept + pre + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = key;
+            kept += tot;
+        }
+        n = kept;
+        __syncthreads();
+    }
 
     // ---------------------------------------------------------------- fast path
     bool done = false;
@@ -926,7 +1062,7 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VsProfScope ps(ctx, "min_eigen_kernel");
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && ((reinterpret_cast<uintptr_t>(eig) & 15) == 0)) {
         dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), frames);
-        min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
+        min_eigen_v4_kernel<false><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits, 0.0, nullptr, nullptr, nullptr, 0);
     } else {
         dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
         min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
@@ -959,17 +1095,26 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     if ((rc = vs_arena_get(ctx, "gf.keys", sizeof(unsigned long long) * key_cap * frames, (void **)&keys))) return rc;
     overflow = reinterpret_cast<int32_t *>(counts + frames);
 
-    if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, fmax))) return rc;
+    const bool fused = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
     VS_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), ctx->stream));
-    {
-        VsProfScope ps(ctx, "corner_candidates_kernel");
-        if (w % 4 == 0) {
-            dim3 grid(vs_div_up(w, kC4W), vs_div_up(h, kC4H), frames);
-            corner_candidates_v4_kernel<<<grid, 256, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
-        } else {
-            dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
-            corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
+    if (fused) {
+        VS_HIP(ctx, hipMemsetAsync(fmax, 0, sizeof(uint32_t) * (size_t)frames, ctx->stream));
+        {
+            VsProfScope ps(ctx, "min_eigen_kernel");
+            dim3 grid(vs_div_up(w, kE4W - 8), vs_div_up(h, kE4H - 2), frames);
+            min_eigen_v4_kernel<true><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, state, keys, counts, key_cap);
         }
+        {   // frames with a negative maximum (not seen in practice) are redone the two-pass way
+            VsProfScope ps(ctx, "corner_candidates_kernel");
+            negative_max_reset_kernel<<<vs_div_up(frames, 256), 256, 0, ctx->stream>>>(fmax, counts, frames);
+            dim3 grid(vs_div_up(w, kC4W), vs_div_up(h, kC4H), frames);
+            corner_candidates_v4_kernel<<<grid, 256, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap, 1);
+        }
+    } else {
+        if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, fmax))) return rc;
+        VsProfScope ps(ctx, "corner_candidates_kernel");
+        dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
+        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
     }
     {
         int sort_cap = 2;
@@ -987,7 +1132,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         const float md2 = (float)(min_distance * min_distance);   // `minDistance *= minDistance` in double, compared as float
         VsProfScope ps(ctx, "corner_select_kernel");
         corner_select_kernel<<<frames, kST, lds, ctx->stream>>>(eig, w, h, state, keys, counts, key_cap, max_corners, md,
-                                                                md2, sort_cap, xy, n, kp_stride, overflow);
+                                                                md2, sort_cap, xy, n, kp_stride, overflow, fmax, quality);
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
