@@ -158,6 +158,19 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
                            float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
                            int32_t *d_n_detected);
 
+/* Replaces extract_features(Frame&, nrows, ncols), src/Frame.cpp:16-51 (the grid ORB/FAST extractor;
+ * dead in the reference: its call at src/vslam.cpp:63 is commented out).  Per grid cell: black outline
+ * drawn INTO d_bgr (:32), ORB(500, 1.2, 8, 31, 0, 2, HARRIS, 31, fastThreshold 20)->detect, replaced by
+ * the fastThreshold-5 detector's result when fewer than 500 keypoints were found (:33-36); then
+ * ORB::compute on the whole outlined image (:43).  Like the reference it builds no k-d tree and does
+ * not touch map_point_ids.  Outputs per frame: d_xy [frames][kp_stride][2] (ORB::compute's order:
+ * grouped by pyramid level), d_desc [frames][kp_stride][32], optional d_angle_octave
+ * [frames][kp_stride][2] (degrees, level), d_n [frames].                                          */
+int vslam_extract_features_grid(vslam_ctx *ctx, uint8_t *d_bgr, int frames, int width, int height,
+                                int row_stride, int nrows, int ncols, const int8_t *d_pattern,
+                                int kp_stride, float *d_xy, uint8_t *d_desc, float *d_angle_octave,
+                                int32_t *d_n);
+
 /* stage-level entry points (parity tests; each is one step of vslam_extract_features) */
 int vslam_bgr2gray(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
                    int row_stride, uint8_t *d_gray);

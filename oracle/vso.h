@@ -112,6 +112,22 @@ int vso_extract_features(const uint8_t *bgr, int w, int h, int bgr_stride, int m
                          float *out_xy, uint8_t *out_desc, int32_t *out_kd,
                          int32_t *out_n, int32_t *out_n_detected);
 
+/* ------------------------------------------------- grid ORB/FAST extractor (a4) */
+/* pinned sin/cos of a keypoint angle in degrees (OpenCV calls libm on a float here) */
+int vso_sincos_deg(float angle_deg, float *s, float *c);
+/* cv::FAST(gray, kps, threshold, nonmax=true), FAST-9/16: (x, y, score) triples in raster order */
+int vso_fast9_16(const uint8_t *gray, int w, int h, int threshold, float *out_xys, int cap, int32_t *out_n);
+/* cv::resize(..., INTER_LINEAR_EXACT) for 8U single channel */
+int vso_resize_linear_exact(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
+/* ORB::create(nfeatures, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, fast_threshold)->detect(gray):
+ * 6 floats per keypoint (x, y, size, angle, response, octave) */
+int vso_orb_detect(const uint8_t *gray, int w, int h, int nfeatures, int fast_threshold, float *out_kp,
+                   int cap, int32_t *out_n);
+/* extract_features(Frame&, nrows, ncols): src/Frame.cpp:16-51.  bgr is modified (:32). */
+int vso_extract_features_grid(uint8_t *bgr, int w, int h, int stride, int nrows, int ncols,
+                              const int8_t *pattern, float *out_xy, uint8_t *out_desc,
+                              float *out_angle_octave, int cap, int32_t *out_n);
+
 /* ------------------------------------------------------------------ pipeline */
 /* match_features: src/Frame.cpp:82-105 with injected seed.  out_matches 2*n1 ints.   */
 int vso_match_features(const float *xy1, const uint8_t *d1, int n1,

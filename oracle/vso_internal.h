@@ -7,5 +7,6 @@ namespace vso {
 double pinned_hypot(double a, double b);
 void jacobi_svd32f(float *At, size_t astep, float *W, float *Vt, size_t vstep, int m, int n, int n1);
 void svd32f_full(const float *A, int m, int n, float *w, float *u, float *vt);
+void sincos_deg_pinned(float angle_deg, float *s_out, float *c_out);
 }  // namespace vso
 #endif

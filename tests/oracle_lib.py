@@ -183,3 +183,45 @@ class Oracle:
                                              _p(desc, C.c_uint8), _p(kd, C.c_int32), C.byref(n), C.byref(nd)) == 0
         k = n.value
         return dict(xy=xy[:k].copy(), desc=desc[:k].copy(), nodes=kd[:k].copy(), n=k, n_detected=nd.value)
+
+    # ------------------------------------------------------------ grid ORB/FAST extractor (a4)
+    def fast9_16(self, gray, threshold, cap=200000):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        out = np.zeros((cap, 3), dtype=np.float32)
+        n = C.c_int32()
+        assert self.lib.vso_fast9_16(_p(gray, C.c_uint8), w, h, threshold, _p(out, C.c_float), cap, C.byref(n)) == 0
+        return out[:n.value].copy()
+
+    def resize_linear_exact(self, src, dw, dh):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        sh, sw = src.shape
+        dst = np.zeros((dh, dw), dtype=np.uint8)
+        assert self.lib.vso_resize_linear_exact(_p(src, C.c_uint8), sw, sh, _p(dst, C.c_uint8), dw, dh) == 0
+        return dst
+
+    def orb_detect(self, gray, nfeatures, fast_threshold, cap=20000):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        out = np.zeros((cap, 6), dtype=np.float32)
+        n = C.c_int32()
+        assert self.lib.vso_orb_detect(_p(gray, C.c_uint8), w, h, nfeatures, fast_threshold, _p(out, C.c_float), cap, C.byref(n)) == 0
+        return out[:n.value].copy()
+
+    def extract_features_grid(self, bgr, nrows, ncols, pattern, cap=100000):
+        """Returns (outlined bgr copy, xy, desc, angle_octave)."""
+        b = np.ascontiguousarray(bgr, dtype=np.uint8).copy()
+        pattern = np.ascontiguousarray(pattern, dtype=np.int8)
+        h, w, _ = b.shape
+        xy = np.zeros((cap, 2), dtype=np.float32); desc = np.zeros((cap, 32), dtype=np.uint8)
+        ao = np.zeros((cap, 2), dtype=np.float32)
+        n = C.c_int32()
+        assert self.lib.vso_extract_features_grid(_p(b, C.c_uint8), w, h, 3 * w, nrows, ncols, _p(pattern, C.c_int8),
+                                                  _p(xy, C.c_float), _p(desc, C.c_uint8), _p(ao, C.c_float), cap, C.byref(n)) == 0
+        k = n.value
+        return b, xy[:k].copy(), desc[:k].copy(), ao[:k].copy()
+
+    def sincos_deg(self, a):
+        s = C.c_float(); c = C.c_float()
+        self.lib.vso_sincos_deg(C.c_float(a), C.byref(s), C.byref(c))
+        return np.float32(s.value), np.float32(c.value)

@@ -21,7 +21,7 @@ SYMBOLS = [
     "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
-    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_bgr2gray", "vslam_min_eigen",
+    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_extract_features_grid", "vslam_bgr2gray", "vslam_min_eigen",
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_match_features",
     "vslam_frontend_pairs",
 ]
@@ -276,6 +276,22 @@ class Context:
                                                     C.c_int(3 * W), C.byref(p), C.c_int(K), _ptr(out["xy"]),
                                                     _ptr(out["desc"]), _ptr(out["nodes"]), _ptr(out["n"]),
                                                     _ptr(out["n_detected"])))
+        return out
+
+    def extract_features_grid(self, bgr, nrows, ncols, pattern, kp_stride):
+        """extract_features(frame, nrows, ncols): bgr is modified in place (cell outlines)."""
+        torch = self.torch
+        F, H, W, _ = bgr.shape
+        self._dev(bgr, torch.uint8, "bgr"); self._dev(pattern, torch.int8, "pattern")
+        dev = bgr.device
+        out = dict(xy=torch.zeros((F, kp_stride, 2), dtype=torch.float32, device=dev),
+                   desc=torch.zeros((F, kp_stride, 32), dtype=torch.uint8, device=dev),
+                   angle_octave=torch.zeros((F, kp_stride, 2), dtype=torch.float32, device=dev),
+                   n=torch.zeros((F,), dtype=torch.int32, device=dev))
+        self._check(self.lib.vslam_extract_features_grid(self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H),
+                                                         C.c_int(3 * W), C.c_int(nrows), C.c_int(ncols), _ptr(pattern),
+                                                         C.c_int(kp_stride), _ptr(out["xy"]), _ptr(out["desc"]),
+                                                         _ptr(out["angle_octave"]), _ptr(out["n"])))
         return out
 
     def match_features(self, xy1, desc1, n1, xy2, desc2, n2, seeds, hyp, threshold, out=None):

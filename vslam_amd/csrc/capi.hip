@@ -358,6 +358,15 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     return VSLAM_OK;
 }
 
+// extract_features(Frame&, nrows, ncols), src/Frame.cpp:16-51
+int vslam_extract_features_grid(vslam_ctx *ctx, uint8_t *d_bgr, int frames, int width, int height, int row_stride,
+                                int nrows, int ncols, const int8_t *d_pattern, int kp_stride, float *d_xy,
+                                uint8_t *d_desc, float *d_angle_octave, int32_t *d_n) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_extract_grid(ctx, d_bgr, frames, width, height, row_stride, nrows, ncols, d_pattern, kp_stride,
+                                  d_xy, d_desc, d_angle_octave, d_n);
+}
+
 // match_features, src/Frame.cpp:82-105
 int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_desc1,
                          const int32_t *d_n1, const float *d_xy2, const uint8_t *d_desc2,

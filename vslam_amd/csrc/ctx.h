@@ -125,3 +125,6 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
 int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, int w, int h,
                            const float *xy_in, const int32_t *n_in, int kp_stride, float ca, float sa,
                            const int8_t *pattern, float *xy_out, uint8_t *desc, int32_t *n_out);
+int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int h, int stride, int nrows, int ncols,
+                           const int8_t *pattern, int kp_cap, float *xy, uint8_t *desc, float *angle_octave,
+                           int32_t *n_out);
