@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch)")
-    ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs the CPU baseline times (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=150, help="pairs the CPU baseline times (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also run two 1 GiB streaming copies (4 B and 16 B per lane) so FETCH_SIZE/WRITE_SIZE can be calibrated")

@@ -23,8 +23,9 @@ struct Frame {   // reference: include/Frame.h:11-27
 void initialize_frame(Frame &frame, const cv::Mat &image, long frame_id);
 // reference: include/Frame.h:33, src/Frame.cpp:53-80 (Shi-Tomasi + rBRIEF + k-d tree)
 void extract_features(Frame &frame);
-// reference: include/Frame.h:32, src/Frame.cpp:16-51 — the grid ORB/FAST extractor whose only call is
-// commented out (src/vslam.cpp:63).  Declared for source compatibility; not built yet: throws.
+// reference: include/Frame.h:32, src/Frame.cpp:16-51 — the grid ORB/FAST extractor (its only call is
+// commented out at src/vslam.cpp:63).  Draws the cell outlines into frame.image like the reference,
+// fills points + descriptors, builds no k-d tree and leaves map_point_ids alone.
 void extract_features(Frame &frame, int nrows, int ncols);
 // reference: include/Frame.h:34, src/Frame.cpp:82-105
 void match_features(const Frame &frame1, const Frame &frame2, RansacFilter &rf,

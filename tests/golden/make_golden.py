@@ -68,6 +68,14 @@ def main():
     g["p_matches"], g["p_F"], g["p_prelim"] = mf["matches"], mf["F"], np.array([mf["prelim"]], np.int32)
     out = os.path.join(HERE, "frontend_v1.npz")
     np.savez_compressed(out, **g)
+    # ---- grid ORB/FAST extractor (src/Frame.cpp:16-51) on one small frame
+    bgr = synth.frames_numpy(6, 1, 256, 192)[0]
+    img, xy, desc, ao = o.extract_features_grid(bgr, 2, 2, pat)
+    g2 = dict(g_bgr=bgr, g_pattern=pat, g_outlined=img, g_xy=xy, g_desc=desc, g_angle_octave=ao,
+              g_fast20=o.fast9_16(o.bgr2gray(bgr), 20), g_resized=o.resize_linear_exact(o.bgr2gray(bgr), 213, 160))
+    out2 = os.path.join(HERE, "frontend_v2_grid.npz")
+    np.savez_compressed(out2, **g2)
+    print(out2, os.path.getsize(out2), "bytes;", len(xy), "grid keypoints")
     print(out, os.path.getsize(out), "bytes;", {k: v.shape for k, v in g.items() if v.ndim} and len(g), "arrays")
 
 

@@ -97,6 +97,19 @@ int main(int argc, char **argv) {
     wr_i(fo, r.first);
     wr(fo, &r.second, 4);
     for (size_t k = 0; k < inl.size(); k++) wr_i(fo, inl[k] ? 1 : 0);
+    // the grid ORB/FAST extractor (src/Frame.cpp:16-51; call site commented out at src/vslam.cpp:63)
+    {
+        std::vector<unsigned char> copy = img[0];
+        Frame g;
+        g.kdtree.root = nullptr;
+        cv::Mat image(h, w, CV_8UC3, copy.data());
+        initialize_frame(g, image, 7);
+        extract_features(g, 3, 4);
+        wr_i(fo, (int)g.points.size());
+        wr(fo, g.points.data(), g.points.size() * 8);
+        wr(fo, g.descriptors.data, (size_t)g.descriptors.rows * 32);
+        wr(fo, copy.data(), copy.size());            // frame.image aliases the buffer: outlines must be in it
+    }
     fclose(fo);
     for (auto &fr : frames) free(fr.kdtree.root);    // src/vslam.cpp:295-297
     free(kd.root);

@@ -51,3 +51,14 @@ def test_extract_and_pipeline(oracle):
     mf = oracle.match_features(ex[0]["xy"], ex[0]["desc"], ex[1]["xy"], ex[1]["desc"], 0x5EED0000, 64, 10.0)
     assert mf["prelim"] == int(G["p_prelim"][0]) and np.array_equal(mf["matches"], G["p_matches"])
     assert np.array_equal(bits(mf["F"]), bits(G["p_F"]))
+
+
+def test_grid_orb_golden(oracle):
+    G2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_v2_grid.npz"))
+    img, xy, desc, ao = oracle.extract_features_grid(G2["g_bgr"], 2, 2, G2["g_pattern"])
+    assert np.array_equal(img, G2["g_outlined"])
+    assert np.array_equal(bits(xy), bits(G2["g_xy"])) and np.array_equal(desc, G2["g_desc"])
+    assert np.array_equal(bits(ao), bits(G2["g_angle_octave"]))
+    gray = oracle.bgr2gray(G2["g_bgr"])
+    assert np.array_equal(oracle.fast9_16(gray, 20), G2["g_fast20"])
+    assert np.array_equal(oracle.resize_linear_exact(gray, 213, 160), G2["g_resized"])

@@ -86,4 +86,11 @@ def test_cpp_surfaces_match_oracle(oracle, tmp_path):
     assert int(take(np.int32, 1)[0]) == c
     assert take(np.float32, 1).view(np.uint32)[0] == np.float32(s).view(np.uint32)
     assert np.array_equal(take(np.int32, k), mask.astype(np.int32))
+    # extract_features(frame, 3, 4): the grid ORB/FAST extractor through the C++ surface
+    ref_img, gxy, gdesc, _ = oracle.extract_features_grid(bgr[0], 3, 4, pat)
+    gn = int(take(np.int32, 1)[0])
+    assert gn == len(gxy) and gn > 50
+    assert np.array_equal(take(np.float32, 2 * gn).reshape(gn, 2).view(np.uint32), gxy.view(np.uint32))
+    assert np.array_equal(take(np.uint8, 32 * gn).reshape(gn, 32), gdesc)
+    assert np.array_equal(take(np.uint8, w * h * 3).reshape(h, w, 3), ref_img)
     assert off == len(buf)

@@ -63,3 +63,15 @@ def test_extract_and_pipeline_golden(ctx):
     k = len(G["p_matches"])
     assert out["best"][0, 3] == k and np.array_equal(out["matches"][0, :k], G["p_matches"])
     assert np.array_equal(bits(out["F"][0]), bits(G["p_F"]))
+
+
+def test_grid_orb_golden(ctx):
+    G2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_v2_grid.npz"))
+    dev = t(G2["g_bgr"][None].copy())
+    out = ctx.extract_features_grid(dev, 2, 2, t(G2["g_pattern"]), 8192)
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    n = len(G2["g_xy"])
+    assert out["n"][0] == n
+    assert np.array_equal(dev[0].cpu().numpy(), G2["g_outlined"])
+    assert np.array_equal(bits(out["xy"][0, :n]), bits(G2["g_xy"])) and np.array_equal(out["desc"][0, :n], G2["g_desc"])
+    assert np.array_equal(bits(out["angle_octave"][0, :n]), bits(G2["g_angle_octave"]))

@@ -442,10 +442,29 @@ void initialize_frame(Frame &frame, const cv::Mat &image, long frame_id) {
     frame.id = (u64)frame_id;
 }
 
-void extract_features(Frame &frame, int, int) {
-    (void)frame;
-    throw std::logic_error("extract_features(frame, nrows, ncols): the grid ORB/FAST extractor is dead code in the "
-                           "reference (src/vslam.cpp:63) and is not built yet");
+void extract_features(Frame &frame, int nrows, int ncols) {
+    cv::Mat &img = frame.image;
+    if (img.empty() || img.type() != CV_8UC3) throw std::invalid_argument("extract_features: expects a CV_8UC3 BGR image");
+    const int w = img.cols, h = img.rows;
+    const int K = 500 * nrows * ncols + 4096;   // 500 per cell plus room for response ties
+    const std::vector<s8> &pat = pattern();
+    DBuf<uint8_t> dimg((size_t)h * img.step), ddesc((size_t)K * 32);
+    DBuf<int8_t> dpat(1024);
+    DBuf<float> dxy(2 * (size_t)K);
+    DBuf<int32_t> dn(1);
+    dimg.upload(img.data, (size_t)h * img.step);
+    dpat.upload(reinterpret_cast<const int8_t *>(pat.data()), 1024);
+    check(vslam_extract_features_grid(ctx(), dimg.p, 1, w, h, (int)img.step, nrows, ncols, dpat.p, K, dxy.p, ddesc.p, nullptr,
+                                      dn.p),
+          "extract_features_grid");
+    dimg.download(img.data, (size_t)h * img.step);   // cv::rectangle drew into frame.image (src/Frame.cpp:32)
+    int32_t n = 0;
+    dn.download(&n, 1);
+    frame.descriptors.create(n, 32, CV_8UC1);
+    if (n) ddesc.download(frame.descriptors.data, (size_t)n * 32);
+    const size_t old = frame.points.size();
+    frame.points.resize(old + n);   // push_back loop, :47-49; no k-d tree, no map_point_ids (as the reference)
+    if (n) dxy.download(reinterpret_cast<float *>(frame.points.data() + old), 2 * (size_t)n);
 }
 
 void extract_features(Frame &frame) {
