@@ -186,6 +186,20 @@ int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int
                        float sin_a, const int8_t *d_pattern, float *d_xy_out, uint8_t *d_desc,
                        int32_t *d_n_out);
 
+/* ------------------------------------------------------- pose (SURVEY.md 8f "next" rows) */
+/* Replaces extract_Rt(fundamental, K, rotation, translation), src/helpers.cpp:3-35, for a batch of
+ * fundamental matrices, plus the camera matrix c2 = K * [R | t] of src/vslam.cpp:83-85,125.
+ * d_F [batch][9]; d_best [batch][4] as written by vslam_ransac_* (items with winner < 0 are skipped;
+ * may be NULL); h_K: HOST 3x3 intrinsics (row-major).  d_R [batch][9], d_t [batch][3], d_c2 [batch][12]. */
+int vslam_extract_Rt(vslam_ctx *ctx, const float *d_F, const int32_t *d_best, int batch, const float *h_K,
+                     float *d_R, float *d_t, float *d_c2);
+/* Replaces triangulate(p1, p2, c1, c2, points_4d), src/helpers.cpp:37-80, with c1 = [K | 0]
+ * (src/vslam.cpp:123-124): one 4x4 SVD per inlier match (d_matches / d_best[.][3] from RANSAC).
+ * d_points4d [batch][kp_stride][4] (x, y, z, 1).                                                    */
+int vslam_triangulate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, const int32_t *d_matches,
+                      const int32_t *d_best, int batch, int kp_stride, const float *h_K,
+                      const float *d_c2, float *d_points4d);
+
 /* ------------------------------------------------------------------ pipeline */
 /* match_features(frame1, frame2, rf, matches, F), src/Frame.cpp:82-105, for a batch of pairs
  * whose features are already on the device: match -> sets -> RANSAC -> inlier matches.

@@ -128,6 +128,14 @@ int vso_extract_features_grid(uint8_t *bgr, int w, int h, int stride, int nrows,
                               const int8_t *pattern, float *out_xy, uint8_t *out_desc,
                               float *out_angle_octave, int cap, int32_t *out_n);
 
+/* ------------------------------------------------- pose helpers */
+/* extract_Rt(fundamental, K, rotation, translation): src/helpers.cpp:3-35 (3x3 row-major, t[3]) */
+int vso_extract_Rt(const float *F, const float *K, float *R_out, float *t_out);
+/* c2 = K * [R | t] (src/vslam.cpp:83-85,125), 3x4 row-major */
+int vso_camera_matrix(const float *K, const float *R, const float *t, float *c2);
+/* triangulate(p1, p2, c1, c2, points_4d): src/helpers.cpp:37-80 */
+int vso_triangulate(const float *p1, const float *p2, int n, const float *c1, const float *c2, float *points_4d);
+
 /* ------------------------------------------------------------------ pipeline */
 /* match_features: src/Frame.cpp:82-105 with injected seed.  out_matches 2*n1 ints.   */
 int vso_match_features(const float *xy1, const uint8_t *d1, int n1,

@@ -1,0 +1,119 @@
+// ORACLE (test infrastructure only) — pose helpers downstream of the hot path.
+//
+// Follows /root/reference/src/helpers.cpp:
+//   extract_Rt   :3-35   E = K^T F K, SVD, t = U.col(2) / |.|, R from U W V^T / U W^T V^T, sign fixes
+//   triangulate  :37-80  per match: 4x4 DLT system, SVD, X = V_t.row(3) / V_t(3,3)
+// cv::Mat algebra restated from OpenCV 4.x's built-in paths [OpenCV, from memory] — PARITY UNPINNED:
+//   * A*B with flags == 0 and inner length 3 or 4 where it equals a result dimension: the float
+//     "small matrix" code, a0*b0 + a1*b1 + ... left to right;
+//   * products carrying a transpose flag (K.t()*F, U*W.t()) go through GEMMSingleMul<float,double>:
+//     double products and running sum, one rounding to float;
+//   * s*row - row (MatOp_AddEx) is addWeighted in float: fl(fl(a*s) - b);
+//   * cv::norm(NORM_L2) accumulates squares in double; `m /= s` is convertTo(alpha = 1./s) with the
+//     factor cast to float; cv::determinant of a 3x3 CV_32F evaluates in double.
+//   * cv::SVD::compute on CV_32F = the Jacobi of vso_svd.cpp.
+#include "vso.h"
+#include "vso_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+// float small-matrix product C(r x c) = A(r x n) * B(n x c), left-to-right float accumulation
+void mul_small(const float *A, const float *B, float *C, int r, int n, int c) {
+    for (int i = 0; i < r; i++)
+        for (int j = 0; j < c; j++) {
+            float t = A[i * n + 0] * B[0 * c + j];
+            for (int k = 1; k < n; k++) t = t + A[i * n + k] * B[k * c + j];
+            C[i * c + j] = t;
+        }
+}
+// C = At * B (GEMM_1_T) with double accumulation
+void mul_At_B_d(const float *A, const float *B, float *C, int n) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += (double)A[k * n + i] * (double)B[k * n + j];
+            C[i * n + j] = (float)s;
+        }
+}
+// C = A * Bt (GEMM_2_T) with double accumulation
+void mul_A_Bt_d(const float *A, const float *B, float *C, int n) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += (double)A[i * n + k] * (double)B[j * n + k];
+            C[i * n + j] = (float)s;
+        }
+}
+double det3(const float *m) {
+    return m[0] * ((double)m[4] * m[8] - (double)m[5] * m[7]) - m[1] * ((double)m[3] * m[8] - (double)m[5] * m[6]) +
+           m[2] * ((double)m[3] * m[7] - (double)m[4] * m[6]);
+}
+
+}  // namespace
+
+extern "C" {
+
+// extract_Rt(fundamental, K, rotation, translation): src/helpers.cpp:3-35
+int vso_extract_Rt(const float *F, const float *K, float *R_out, float *t_out) {
+    float KtF[9], E[9];
+    mul_At_B_d(K, F, KtF, 3);                // K.t() * fundamental
+    mul_small(KtF, K, E, 3, 3, 3);           // ... * K
+    float D[3], U[9], Vt[9];
+    vso::svd32f_full(E, 3, 3, D, U, Vt);     // cv::SVD::compute(E, D, U, V_t), :7
+    float t[3] = {U[2], U[5], U[8]};         // U.col(2), :9
+    const double nrm = std::sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]);
+    const float inv = (float)(1. / nrm);     // translation /= cv::norm(translation), :11
+    for (float &v : t) v = v * inv;
+    const float W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};   // :13-16
+    float UW[9], R1[9], UWt[9], R2[9];
+    mul_small(U, W, UW, 3, 3, 3);
+    mul_small(UW, Vt, R1, 3, 3, 3);          // R_1 = U * W * V_t, :18
+    if (det3(R1) < 0)
+        for (float &v : R1) v = -v;
+    mul_A_Bt_d(U, W, UWt, 3);                // U * W.t()
+    mul_small(UWt, Vt, R2, 3, 3, 3);         // R_2, :23
+    if (det3(R2) < 0)
+        for (float &v : R2) v = -v;
+    const float tr = R1[0] + R1[4] + R1[8];  // :29
+    std::memcpy(R_out, tr < 0 ? R2 : R1, sizeof(R1));
+    if (t[2] < 0)                            // :31-33
+        for (float &v : t) v = v * -1.f;
+    std::memcpy(t_out, t, sizeof(t));
+    return 0;
+}
+
+// c2 = K * R_t.rowRange(0,3) with R_t = [R | t] (src/vslam.cpp:83-85,125): 3x4, float small-matrix path
+int vso_camera_matrix(const float *K, const float *R, const float *t, float *c2) {
+    float Rt[12];
+    for (int r = 0; r < 3; r++) {
+        Rt[r * 4 + 0] = R[r * 3 + 0]; Rt[r * 4 + 1] = R[r * 3 + 1]; Rt[r * 4 + 2] = R[r * 3 + 2]; Rt[r * 4 + 3] = t[r];
+    }
+    mul_small(K, Rt, c2, 3, 3, 4);
+    return 0;
+}
+
+// triangulate(p1, p2, c1, c2, points_4d): src/helpers.cpp:37-80.  p1/p2: n x 2, c1/c2: 3 x 4, out: n x 4
+int vso_triangulate(const float *p1, const float *p2, int n, const float *c1, const float *c2, float *points_4d) {
+    for (int i = 0; i < n; i++) {
+        float A[16];
+        for (int c = 0; c < 4; c++) {
+            A[0 * 4 + c] = p1[2 * i] * c1[2 * 4 + c] - c1[0 * 4 + c];       // :49-52
+            A[1 * 4 + c] = p1[2 * i + 1] * c1[2 * 4 + c] - c1[1 * 4 + c];
+            A[2 * 4 + c] = p2[2 * i] * c2[2 * 4 + c] - c2[0 * 4 + c];
+            A[3 * 4 + c] = p2[2 * i + 1] * c2[2 * 4 + c] - c2[1 * 4 + c];
+        }
+        float D[4], U[16], Vt[16];
+        vso::svd32f_full(A, 4, 4, D, U, Vt);                                // :59
+        const float *v = &Vt[3 * 4];
+        points_4d[4 * i + 0] = v[0] / v[3];                                 // :72-75
+        points_4d[4 * i + 1] = v[1] / v[3];
+        points_4d[4 * i + 2] = v[2] / v[3];
+        points_4d[4 * i + 3] = 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -225,3 +225,25 @@ class Oracle:
         s = C.c_float(); c = C.c_float()
         self.lib.vso_sincos_deg(C.c_float(a), C.byref(s), C.byref(c))
         return np.float32(s.value), np.float32(c.value)
+
+    # ------------------------------------------------------------ pose helpers (8f)
+    def extract_Rt(self, F, K):
+        F = np.ascontiguousarray(F, dtype=np.float32).reshape(9); K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        R = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+        assert self.lib.vso_extract_Rt(_p(F, C.c_float), _p(K, C.c_float), _p(R, C.c_float), _p(t, C.c_float)) == 0
+        return R.reshape(3, 3), t
+
+    def camera_matrix(self, K, R, t):
+        K = np.ascontiguousarray(K, dtype=np.float32).reshape(9); R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+        t = np.ascontiguousarray(t, dtype=np.float32)
+        c2 = np.zeros(12, np.float32)
+        assert self.lib.vso_camera_matrix(_p(K, C.c_float), _p(R, C.c_float), _p(t, C.c_float), _p(c2, C.c_float)) == 0
+        return c2.reshape(3, 4)
+
+    def triangulate(self, p1, p2, c1, c2):
+        p1 = np.ascontiguousarray(p1, dtype=np.float32); p2 = np.ascontiguousarray(p2, dtype=np.float32)
+        c1 = np.ascontiguousarray(c1, dtype=np.float32).reshape(12); c2 = np.ascontiguousarray(c2, dtype=np.float32).reshape(12)
+        n = p1.shape[0]
+        out = np.zeros((max(n, 1), 4), np.float32)
+        assert self.lib.vso_triangulate(_p(p1, C.c_float), _p(p2, C.c_float), n, _p(c1, C.c_float), _p(c2, C.c_float), _p(out, C.c_float)) == 0
+        return out[:n]

@@ -19,7 +19,7 @@ def lib():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "vslam_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vslam_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(vslam_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(lib):

@@ -22,7 +22,8 @@ SYMBOLS = [
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
     "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_extract_features_grid", "vslam_bgr2gray", "vslam_min_eigen",
-    "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_match_features",
+    "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate",
+    "vslam_match_features",
     "vslam_frontend_pairs",
 ]
 
@@ -293,6 +294,28 @@ class Context:
                                                          C.c_int(kp_stride), _ptr(out["xy"]), _ptr(out["desc"]),
                                                          _ptr(out["angle_octave"]), _ptr(out["n"])))
         return out
+
+    def extract_Rt(self, F, best, K):
+        import numpy as np
+        torch = self.torch
+        B = F.shape[0]
+        Kh = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        R = torch.zeros((B, 9), dtype=torch.float32, device=F.device)
+        t = torch.zeros((B, 3), dtype=torch.float32, device=F.device)
+        c2 = torch.zeros((B, 12), dtype=torch.float32, device=F.device)
+        self._check(self.lib.vslam_extract_Rt(self.handle, _ptr(F), _ptr(best), C.c_int(B), Kh.ctypes.data_as(C.c_void_p),
+                                              _ptr(R), _ptr(t), _ptr(c2)))
+        return R, t, c2
+
+    def triangulate(self, xy1, xy2, matches, best, K, c2):
+        import numpy as np
+        torch = self.torch
+        B, Kp, _ = xy1.shape
+        Kh = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        pts = torch.zeros((B, Kp, 4), dtype=torch.float32, device=xy1.device)
+        self._check(self.lib.vslam_triangulate(self.handle, _ptr(xy1), _ptr(xy2), _ptr(matches), _ptr(best), C.c_int(B),
+                                               C.c_int(Kp), Kh.ctypes.data_as(C.c_void_p), _ptr(c2), _ptr(pts)))
+        return pts
 
     def match_features(self, xy1, desc1, n1, xy2, desc2, n2, seeds, hyp, threshold, out=None):
         torch = self.torch

@@ -367,6 +367,21 @@ int vslam_extract_features_grid(vslam_ctx *ctx, uint8_t *d_bgr, int frames, int 
                                   d_xy, d_desc, d_angle_octave, d_n);
 }
 
+// extract_Rt + camera matrix, src/helpers.cpp:3-35, src/vslam.cpp:83-85,125
+int vslam_extract_Rt(vslam_ctx *ctx, const float *d_F, const int32_t *d_best, int batch, const float *h_K, float *d_R,
+                     float *d_t, float *d_c2) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_extract_Rt(ctx, d_F, d_best, batch, h_K, d_R, d_t, d_c2);
+}
+
+// triangulate, src/helpers.cpp:37-80
+int vslam_triangulate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, const int32_t *d_matches,
+                      const int32_t *d_best, int batch, int kp_stride, const float *h_K, const float *d_c2,
+                      float *d_points4d) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_triangulate(ctx, d_xy1, d_xy2, d_matches, d_best, batch, kp_stride, h_K, d_c2, d_points4d);
+}
+
 // match_features, src/Frame.cpp:82-105
 int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_desc1,
                          const int32_t *d_n1, const float *d_xy2, const uint8_t *d_desc2,

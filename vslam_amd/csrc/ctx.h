@@ -128,3 +128,8 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
 int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int h, int stride, int nrows, int ncols,
                            const int8_t *pattern, int kp_cap, float *xy, uint8_t *desc, float *angle_octave,
                            int32_t *n_out);
+int vs_launch_extract_Rt(vslam_ctx *ctx, const float *F, const int32_t *best, int batch, const float *h_K, float *R,
+                         float *t, float *c2);
+int vs_launch_triangulate(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *matches,
+                          const int32_t *best, int batch, int kp_stride, const float *h_K, const float *c2,
+                          float *points4d);
