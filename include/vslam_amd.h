@@ -200,6 +200,23 @@ int vslam_triangulate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, co
                       const int32_t *d_best, int batch, int kp_stride, const float *h_K,
                       const float *d_c2, float *d_points4d);
 
+/* Replaces the map-association loop of src/vslam.cpp:129-161 and orb_distance (src/PointMap.cpp:36-46):
+ * project each map point with c2, radius_search (r = 2 in the reference) in the frame's k-d tree, and
+ * give it the first hit that is unassigned and within `dist_threshold` (64) Hamming of the map point's
+ * observations.  Sequential semantics preserved: lower map indices claim first.
+ * d_map_points [batch][map_stride][4] (x,y,z,1), d_n_map [batch]; d_c2 [batch][12];
+ * d_nodes/d_xy/d_desc/d_n: the frame's features as written by vslam_extract_features;
+ * observations in CSR form: d_obs_offsets [batch][map_stride+1], d_obs_desc [batch][obs_stride][32];
+ * d_map_point_ids [batch][kp_stride] in/out (-1 = free); d_claim [batch][map_stride] = keypoint or -1.
+ * At most 16 acceptable hits per map point are kept; more sets a sticky flag that
+ * vslam_ctx_synchronize reports as VSLAM_ERR_CAPACITY.                                            */
+int vslam_associate_map_points(vslam_ctx *ctx, const float *d_map_points, const int32_t *d_n_map, int batch,
+                               int map_stride, const float *d_c2, int img_w, int img_h,
+                               const int32_t *d_nodes, const float *d_xy, const uint8_t *d_desc,
+                               const int32_t *d_n, int kp_stride, const int32_t *d_obs_offsets,
+                               const uint8_t *d_obs_desc, int obs_stride, float radius,
+                               uint32_t dist_threshold, int32_t *d_map_point_ids, int32_t *d_claim);
+
 /* ------------------------------------------------------------------ pipeline */
 /* match_features(frame1, frame2, rf, matches, F), src/Frame.cpp:82-105, for a batch of pairs
  * whose features are already on the device: match -> sets -> RANSAC -> inlier matches.

@@ -136,6 +136,12 @@ int vso_camera_matrix(const float *K, const float *R, const float *t, float *c2)
 /* triangulate(p1, p2, c1, c2, points_4d): src/helpers.cpp:37-80 */
 int vso_triangulate(const float *p1, const float *p2, int n, const float *c1, const float *c2, float *points_4d);
 
+/* map association: src/vslam.cpp:129-161 + orb_distance (src/PointMap.cpp:36-46) */
+int vso_associate_map_points(const float *map_points, int n_map, const float *c2, int img_w, int img_h,
+                             const int32_t *kd_nodes, const float *kp_xy, const uint8_t *kp_desc, int n_kp,
+                             const int32_t *obs_offsets, const uint8_t *obs_desc, float radius,
+                             uint32_t dist_threshold, int32_t *map_point_ids, int32_t *out_claim);
+
 /* ------------------------------------------------------------------ pipeline */
 /* match_features: src/Frame.cpp:82-105 with injected seed.  out_matches 2*n1 ints.   */
 int vso_match_features(const float *xy1, const uint8_t *d1, int n1,

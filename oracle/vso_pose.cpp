@@ -117,3 +117,51 @@ int vso_triangulate(const float *p1, const float *p2, int n, const float *c1, co
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Map association: src/vslam.cpp:129-161 + orb_distance, src/PointMap.cpp:36-46.
+//   projected = pm.points(N x 4) * c2.t()  -> GEMM_2_T: double products, four partial sums
+//   (k, k+1, k+2, k+3 of each 4-block), (s0+s1+s2+s3) rounded to float [OpenCV, from memory];
+//   x /= h, y /= h; in-view test; radius_search(frame.kdtree, frame.points, q, 2); the first hit that is
+//   still unassigned and whose orb_distance (min Hamming over the map point's observations) is < 64
+//   gets the map point.  The loop is sequential: an earlier map point's claim hides the keypoint from
+//   later ones.
+// obs_offsets[N+1] / obs_desc[total][32]: descriptors of each map point's observations (CSR).
+// map_point_ids (n_kp, in/out).  out_claim[i] = keypoint index claimed by map point i or -1.
+extern "C" int vso_associate_map_points(const float *map_points /*N x 4*/, int n_map, const float *c2 /*3x4*/,
+                                        int img_w, int img_h, const int32_t *kd_nodes, const float *kp_xy,
+                                        const uint8_t *kp_desc, int n_kp, const int32_t *obs_offsets,
+                                        const uint8_t *obs_desc, float radius, uint32_t dist_threshold,
+                                        int32_t *map_point_ids, int32_t *out_claim) {
+    for (int i = 0; i < n_map; i++) {
+        out_claim[i] = -1;
+        const float *P = map_points + (size_t)i * 4;
+        float pr[3];
+        for (int r = 0; r < 3; r++) {
+            const double s0 = (double)P[0] * (double)c2[r * 4 + 0], s1 = (double)P[1] * (double)c2[r * 4 + 1];
+            const double s2 = (double)P[2] * (double)c2[r * 4 + 2], s3 = (double)P[3] * (double)c2[r * 4 + 3];
+            pr[r] = (float)(((s0 + s1) + s2) + s3);
+        }
+        const float hh = pr[2];
+        const float x = pr[0] / hh, y = pr[1] / hh;                       // src/vslam.cpp:136-140
+        if (!(x >= 0 && x < img_w && y >= 0 && y < img_h)) continue;      // :141-143
+        int32_t hits[256];
+        int cnt = vso_kdtree_radius_frame(kd_nodes, kp_xy, n_kp, x, y, radius, hits, 256);   // :149
+        if (cnt > 256) cnt = 256;
+        for (int h = 0; h < cnt; h++) {
+            const int idx = hits[h];
+            if (map_point_ids[idx] >= 0) continue;                         // :151
+            uint32_t mn = 0xFFFFFFFFu;                                     // orb_distance, PointMap.cpp:37-45
+            for (int o = obs_offsets[i]; o < obs_offsets[i + 1]; o++) {
+                const uint32_t cur = vso_hamming256(kp_desc + (size_t)idx * 32, obs_desc + (size_t)o * 32);
+                if (cur < mn) mn = cur;
+            }
+            if (mn < dist_threshold) {                                     // :153
+                map_point_ids[idx] = i;
+                out_claim[i] = idx;
+                break;                                                     // :157
+            }
+        }
+    }
+    return 0;
+}

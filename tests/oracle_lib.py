@@ -247,3 +247,16 @@ class Oracle:
         out = np.zeros((max(n, 1), 4), np.float32)
         assert self.lib.vso_triangulate(_p(p1, C.c_float), _p(p2, C.c_float), n, _p(c1, C.c_float), _p(c2, C.c_float), _p(out, C.c_float)) == 0
         return out[:n]
+
+    def associate(self, map_points, c2, w, h, nodes, kp_xy, kp_desc, obs_offsets, obs_desc, ids, radius=2.0, thr=64):
+        mp = np.ascontiguousarray(map_points, dtype=np.float32); c2 = np.ascontiguousarray(c2, dtype=np.float32).reshape(12)
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32); kp_xy = np.ascontiguousarray(kp_xy, dtype=np.float32)
+        kp_desc = np.ascontiguousarray(kp_desc, dtype=np.uint8); oo = np.ascontiguousarray(obs_offsets, dtype=np.int32)
+        od = np.ascontiguousarray(obs_desc, dtype=np.uint8)
+        ids = np.ascontiguousarray(ids, dtype=np.int32).copy()
+        claim = np.zeros(max(len(mp), 1), np.int32)
+        assert self.lib.vso_associate_map_points(_p(mp, C.c_float), len(mp), _p(c2, C.c_float), w, h, _p(nodes, C.c_int32),
+                                                 _p(kp_xy, C.c_float), _p(kp_desc, C.c_uint8), len(kp_xy), _p(oo, C.c_int32),
+                                                 _p(od, C.c_uint8), C.c_float(radius), C.c_uint32(thr), _p(ids, C.c_int32),
+                                                 _p(claim, C.c_int32)) == 0
+        return ids, claim[:len(mp)]

@@ -1,0 +1,72 @@
+"""Map association (src/vslam.cpp:129-161 + orb_distance) on the device vs the oracle: the claimed
+keypoint of every map point and the updated map_point_ids, bit-exact, including contended keypoints."""
+import numpy as np
+import pytest
+import torch
+
+from vslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenario(oracle, seed, w, h, n_kp, n_map):
+    rng = np.random.default_rng(seed)
+    kp = np.unique(np.rint(np.stack([rng.uniform(0, w - 1, n_kp), rng.uniform(0, h - 1, n_kp)], 1)), axis=0).astype(np.float32)
+    rng.shuffle(kp)
+    n_kp = len(kp)
+    desc = rng.integers(0, 256, (n_kp, 32), dtype=np.uint8)
+    nodes = oracle.kdtree_build_frame(kp)
+    K = np.array([[525, 0, w // 2], [0, 525, h // 2], [0, 0, 1]], np.float64)
+    ang = np.deg2rad(1.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([0.05, -0.02, 0.1])
+    c2 = (K @ np.c_[R, t]).astype(np.float32)
+    # map points: back-project keypoints (some several times -> contention), some random / out of view
+    src = rng.integers(0, n_kp, n_map)
+    src[: n_map // 6] = src[n_map // 6: 2 * (n_map // 6)]                 # duplicates claim the same keypoint
+    depth = rng.uniform(2, 10, n_map)
+    pix = kp[src].astype(np.float64) + rng.uniform(-1.6, 1.6, (n_map, 2))
+    pix[rng.random(n_map) < 0.1] += 5000                                  # projects outside the image
+    cam = np.linalg.inv(K) @ np.c_[pix, np.ones(n_map)].T * depth
+    X = (R.T @ (cam - t[:, None])).T
+    mp = np.c_[X, np.ones(n_map)].astype(np.float32)
+    n_obs = rng.integers(0, 4, n_map)                                     # 0 observations -> distance u32_max
+    offs = np.zeros(n_map + 1, np.int32); offs[1:] = np.cumsum(n_obs)
+    od = rng.integers(0, 256, (max(int(offs[-1]), 1), 32), dtype=np.uint8)
+    for i in range(n_map):
+        for o in range(offs[i], offs[i + 1]):
+            if rng.random() < 0.8:                                        # near-copy of the keypoint's descriptor
+                flips = rng.random(256) < rng.choice([0.02, 0.1, 0.3])
+                od[o] = desc[src[i]] ^ np.packbits(flips)
+    ids = np.full(n_kp, -1, np.int32)
+    ids[rng.integers(0, n_kp, n_kp // 5)] = rng.integers(0, 50, n_kp // 5)   # already propagated by matching
+    return dict(kp=kp, desc=desc, nodes=nodes, c2=c2, mp=mp, offs=offs, od=od, ids=ids)
+
+
+def test_association_bit_exact(ctx, oracle):
+    w, h = 640, 480
+    items = [_scenario(oracle, 1, w, h, 1500, 3000), _scenario(oracle, 2, w, h, 400, 90), _scenario(oracle, 3, w, h, 2000, 10)]
+    B = len(items)
+    Kp = max(len(s["kp"]) for s in items); Mp = max(len(s["mp"]) for s in items); Os = max(len(s["od"]) for s in items)
+    xy = np.zeros((B, Kp, 2), np.float32); desc = np.zeros((B, Kp, 32), np.uint8); nodes = np.zeros((B, Kp), np.int32)
+    n = np.zeros(B, np.int32); mp = np.zeros((B, Mp, 4), np.float32); nm = np.zeros(B, np.int32)
+    offs = np.zeros((B, Mp + 1), np.int32); od = np.zeros((B, Os, 32), np.uint8); ids = np.full((B, Kp), -1, np.int32)
+    c2 = np.zeros((B, 12), np.float32)
+    for b, s in enumerate(items):
+        k, m = len(s["kp"]), len(s["mp"])
+        xy[b, :k], desc[b, :k], nodes[b, :k], n[b] = s["kp"], s["desc"], s["nodes"], k
+        mp[b, :m], nm[b], offs[b, :m + 1], od[b, :len(s["od"])] = s["mp"], m, s["offs"], s["od"]
+        ids[b, :k], c2[b] = s["ids"], s["c2"].reshape(12)
+    t = lambda a: torch.from_numpy(a).cuda()
+    d_ids = t(ids)
+    claim = ctx.associate(t(mp), t(nm), t(c2), w, h, t(nodes), t(xy), t(desc), t(n), t(offs), t(od), d_ids)
+    ctx.synchronize()
+    claim, got_ids = claim.cpu().numpy(), d_ids.cpu().numpy()
+    total = 0
+    for b, s in enumerate(items):
+        k, m = len(s["kp"]), len(s["mp"])
+        ref_ids, ref_claim = oracle.associate(s["mp"], s["c2"], w, h, s["nodes"], s["kp"], s["desc"], s["offs"], s["od"], s["ids"])
+        assert np.array_equal(claim[b, :m], ref_claim), b
+        assert np.array_equal(got_ids[b, :k], ref_ids), b
+        total += int((ref_claim >= 0).sum())
+    assert total > 300, "scenario should produce associations"

@@ -22,7 +22,7 @@ SYMBOLS = [
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
     "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_extract_features_grid", "vslam_bgr2gray", "vslam_min_eigen",
-    "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate",
+    "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points",
     "vslam_match_features",
     "vslam_frontend_pairs",
 ]
@@ -316,6 +316,17 @@ class Context:
         self._check(self.lib.vslam_triangulate(self.handle, _ptr(xy1), _ptr(xy2), _ptr(matches), _ptr(best), C.c_int(B),
                                                C.c_int(Kp), Kh.ctypes.data_as(C.c_void_p), _ptr(c2), _ptr(pts)))
         return pts
+
+    def associate(self, map_points, n_map, c2, w, h, nodes, xy, desc, n, obs_offsets, obs_desc, ids, radius=2.0, thr=64):
+        torch = self.torch
+        B, Mp, _ = map_points.shape
+        Kp = xy.shape[1]
+        claim = torch.full((B, Mp), -3, dtype=torch.int32, device=xy.device)
+        self._check(self.lib.vslam_associate_map_points(
+            self.handle, _ptr(map_points), _ptr(n_map), C.c_int(B), C.c_int(Mp), _ptr(c2), C.c_int(w), C.c_int(h), _ptr(nodes),
+            _ptr(xy), _ptr(desc), _ptr(n), C.c_int(Kp), _ptr(obs_offsets), _ptr(obs_desc), C.c_int(obs_desc.shape[1]),
+            C.c_float(radius), C.c_uint32(thr), _ptr(ids), _ptr(claim)))
+        return claim
 
     def match_features(self, xy1, desc1, n1, xy2, desc2, n2, seeds, hyp, threshold, out=None):
         torch = self.torch

@@ -24,6 +24,14 @@ int vs_arena_get(vslam_ctx *ctx, const char *name, size_t bytes, void **out) {
     return VSLAM_OK;
 }
 
+int vs_device_errflag(vslam_ctx *ctx, int32_t **out) {
+    const bool fresh = ctx->arena.find("ctx.errflag") == ctx->arena.end();
+    int rc = vs_arena_get(ctx, "ctx.errflag", sizeof(int32_t), (void **)out);
+    if (rc) return rc;
+    if (fresh) VS_HIP(ctx, hipMemsetAsync(*out, 0, sizeof(int32_t), ctx->stream));
+    return VSLAM_OK;
+}
+
 static hipEvent_t vs_event_take(vslam_ctx *ctx) {
     if (!ctx->event_pool.empty()) {
         hipEvent_t e = ctx->event_pool.back();
@@ -161,6 +169,16 @@ int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream) {
 int vslam_ctx_synchronize(vslam_ctx *ctx) {
     if (!ctx) return VSLAM_ERR_INVALID;
     VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto it = ctx->arena.find("ctx.errflag");
+    if (it != ctx->arena.end() && it->second.ptr) {
+        int32_t flag = 0;
+        VS_HIP(ctx, hipMemcpy(&flag, it->second.ptr, sizeof(flag), hipMemcpyDeviceToHost));
+        if (flag) {
+            VS_HIP(ctx, hipMemset(it->second.ptr, 0, sizeof(flag)));
+            ctx->err = "a fixed-size device list overflowed (flag " + std::to_string(flag) + ")";
+            return VSLAM_ERR_CAPACITY;
+        }
+    }
     return VSLAM_OK;
 }
 
@@ -380,6 +398,18 @@ int vslam_triangulate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, co
                       float *d_points4d) {
     if (!ctx) return VSLAM_ERR_INVALID;
     return vs_launch_triangulate(ctx, d_xy1, d_xy2, d_matches, d_best, batch, kp_stride, h_K, d_c2, d_points4d);
+}
+
+// map association, src/vslam.cpp:129-161 + orb_distance (src/PointMap.cpp:36-46)
+int vslam_associate_map_points(vslam_ctx *ctx, const float *d_map_points, const int32_t *d_n_map, int batch, int map_stride,
+                               const float *d_c2, int img_w, int img_h, const int32_t *d_nodes, const float *d_xy,
+                               const uint8_t *d_desc, const int32_t *d_n, int kp_stride, const int32_t *d_obs_offsets,
+                               const uint8_t *d_obs_desc, int obs_stride, float radius, uint32_t dist_threshold,
+                               int32_t *d_map_point_ids, int32_t *d_claim) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_associate(ctx, d_map_points, d_n_map, batch, map_stride, d_c2, img_w, img_h, d_nodes, d_xy, d_desc, d_n,
+                               kp_stride, d_obs_offsets, d_obs_desc, obs_stride, radius, dist_threshold, d_map_point_ids,
+                               d_claim);
 }
 
 // match_features, src/Frame.cpp:82-105

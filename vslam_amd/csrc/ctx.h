@@ -63,6 +63,10 @@ struct vslam_ctx {
         }                                                                                   \
     } while (0)
 
+// sticky device-side error word (bit 0: a fixed-size candidate list overflowed); vslam_ctx_synchronize
+// reads and clears it and reports VSLAM_ERR_CAPACITY
+int vs_device_errflag(vslam_ctx *ctx, int32_t **out);
+
 // grow-only named workspace
 int vs_arena_get(vslam_ctx *ctx, const char *name, size_t bytes, void **out);
 
@@ -133,3 +137,7 @@ int vs_launch_extract_Rt(vslam_ctx *ctx, const float *F, const int32_t *best, in
 int vs_launch_triangulate(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *matches,
                           const int32_t *best, int batch, int kp_stride, const float *h_K, const float *c2,
                           float *points4d);
+int vs_launch_associate(vslam_ctx *ctx, const float *map_points, const int32_t *n_map, int batch, int map_stride,
+                        const float *c2, int img_w, int img_h, const int32_t *nodes, const float *xy, const uint8_t *desc,
+                        const int32_t *n_kp, int kp_stride, const int32_t *obs_offsets, const uint8_t *obs_desc,
+                        int obs_stride, float radius, uint32_t dist_threshold, int32_t *map_point_ids, int32_t *claim);
