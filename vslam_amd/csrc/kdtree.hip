@@ -54,6 +54,82 @@ struct LdsStore {
     __device__ bool less(float a, float b) const { return a < b; }
 };
 
+// ---- wave-cooperative replay of std::nth_element ---------------------------------------------
+// introselect's unguarded Hoare partition is a fixed pairing: with L_k the k-th position (ascending)
+// whose key is not < pivot and R_k the k-th position (descending, the pivot slot itself being the
+// last one) whose key is not > pivot, the loop swaps (L_k, R_k) for every k with L_k < R_k and returns
+// min(L_K, R_{K-1}) for the first K with L_K >= R_K.  That is two ballot prefix scans, one parallel
+// swap and no data-dependent serial chain, so one wave does a 2000-element partition in a few
+// hundred cycles instead of a lane walking it element by element.  Median-of-three, the <= 3 element
+// insertion sort and the (rare) heap-select fallback stay on lane 0.  Same permutation as
+// vs_sel::nth_element, hence as libstdc++.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ int wave_partition(LdsStore &s, int a, int b, float pv, int *sl, int *sr) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nL = 0, nR = 0;
+    for (int p0 = a; p0 < b; p0 += 64) {   // left stoppers, ascending
+        const int p = p0 + lane;
+        const bool st = p < b && !s.less(s.key(p), pv);
+        const unsigned long long bal = __ballot(st);
+        if (st) sl[a + nL + (int)__popcll(bal & lt)] = p;
+        nL += (int)__popcll(bal);
+    }
+    for (int p0 = b - 1; p0 >= a - 1; p0 -= 64) {   // right stoppers, descending, pivot slot a-1 included
+        const int p = p0 - lane;
+        const bool st = p >= a - 1 && !s.less(pv, s.key(p));
+        const unsigned long long bal = __ballot(st);
+        if (st) sr[a + nR + (int)__popcll(bal & lt)] = p;
+        nR += (int)__popcll(bal);
+    }
+    wave_sync_lds();
+    const int m = nL < nR ? nL : nR;
+    int K = 0;
+    for (int k0 = 0; k0 < m; k0 += 64) {   // pairs are monotone: count the leading L_k < R_k
+        const int k = k0 + lane;
+        const bool sw = k < m && sl[a + k] < sr[a + k];
+        const unsigned long long bal = __ballot(sw);
+        if (sw) s.swap(sl[a + k], sr[a + k]);
+        K += (int)__popcll(bal);
+        if (bal != ~0ull) break;
+    }
+    const int cl = K < nL ? sl[a + K] : 0x7FFFFFFF;
+    const int cr = K > 0 ? sr[a + K - 1] : 0x7FFFFFFF;
+    wave_sync_lds();
+    return cl < cr ? cl : cr;
+}
+
+__device__ void wave_nth_element(LdsStore &s, int first, int nth, int last, int *sl, int *sr) {
+    const int lane = threadIdx.x & 63;
+    if (first == last || nth == last) return;
+    int depth_limit = vs_sel::floor_lg(last - first) * 2;
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            if (lane == 0) {
+                vs_sel::heap_select(s, first, nth + 1, last);
+                s.swap(first, nth);
+            }
+            wave_sync_lds();
+            return;
+        }
+        --depth_limit;
+        if (lane == 0) vs_sel::move_median_to_first(s, first, first + 1, first + (last - first) / 2, last - 1);
+        wave_sync_lds();
+        const int cut = wave_partition(s, first + 1, last, s.key(first), sl, sr);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (lane == 0) vs_sel::insertion_sort(s, first, last);
+    wave_sync_lds();
+}
+
+constexpr int kWaveMinLen = 48;   // shorter ranges: one lane per subtree is cheaper than a wave each
+
 __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float *__restrict__ xy,
                                                                      const int32_t *__restrict__ n_arr,
                                                                      int kp_stride,
@@ -65,6 +141,8 @@ __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float
     float *kx = reinterpret_cast<float *>(smem);
     float *ky = kx + kp_stride;
     int *id = reinterpret_cast<int *>(ky + kp_stride);
+    int *sl = id + kp_stride;            // stopper lists of the wave-cooperative partition
+    int *sr = sl + kp_stride + 1;
     const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)b * kp_stride;
     int32_t *out = nodes + (size_t)b * kp_stride;
     for (int i = tid; i < n; i += kBuildThreads) {
@@ -77,9 +155,12 @@ __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float
 
     int height = 0;
     for (int t = n; t > 0; t >>= 1) height++;   // floor(log2 n) + 1, :119
+    const int wave = tid >> 6, lane = tid & 63;
     for (int depth = 0; depth < height; depth++) {
         const int tasks = 1 << depth;
-        for (int t = tid; t < tasks; t += kBuildThreads) {
+        const bool by_wave = (n >> depth) >= kWaveMinLen;   // subtree sizes at this depth are n/2^depth (+-1)
+        const int step = by_wave ? kBuildThreads / 64 : kBuildThreads;
+        for (int t = by_wave ? wave : tid; t < tasks; t += step) {
             int first = 0, last = n, pos = 0;
             for (int bit = depth - 1; bit >= 0 && last > first; bit--) {
                 const int len = last - first, mid = first + len / 2;
@@ -94,8 +175,13 @@ __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float
             if (last > first) {
                 LdsStore s(kx, ky, id, depth & 1);
                 const int mid = first + (last - first) / 2;
-                vs_sel::nth_element(s, first, mid, last);
-                out[pos] = id[mid];
+                if (by_wave) {
+                    wave_nth_element(s, first, mid, last, sl, sr);
+                    if (lane == 0) out[pos] = id[mid];
+                } else {
+                    vs_sel::nth_element(s, first, mid, last);
+                    out[pos] = id[mid];
+                }
             }
         }
         __syncthreads();
@@ -220,7 +306,7 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
                            int32_t *nodes) {
     VS_REQUIRE(ctx, xy && n && nodes, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
-    const size_t lds = (size_t)kp_stride * 12;
+    const size_t lds = (size_t)kp_stride * 20 + 8;
     VS_REQUIRE(ctx, lds <= 160 * 1024 - 512, VSLAM_ERR_CAPACITY);
     static bool attr_set = false;
     if (!attr_set) {
