@@ -30,3 +30,23 @@ def test_grid_orb_bit_exact(ctx, oracle, w, h, nrows, ncols):
         assert np.array_equal(out["xy"][f, :n].view(np.uint32), xy.view(np.uint32)), f
         assert np.array_equal(out["desc"][f, :n], desc), f
         assert np.all(np.diff(ao[:, 1]) >= 0)                     # ORB::compute groups by level
+
+
+def test_grid_orb_long_lists_use_global_scratch(ctx, oracle):
+    """One 640x480 cell of pure noise gives FAST lists far longer than the 4095 entries the LDS
+    selection buffers hold, so retainBest's replay runs out of the per-slot global scratch."""
+    rng = np.random.default_rng(3)
+    bgr = rng.integers(0, 256, (1, 480, 640, 3), dtype=np.uint8)
+    pat = synth.brief_pattern()
+    gray = oracle.bgr2gray(bgr[0])
+    assert len(oracle.fast9_16(gray, 20)) > 6000
+    dev = torch.from_numpy(bgr.copy()).cuda()
+    out = ctx.extract_features_grid(dev, 1, 1, torch.from_numpy(pat).cuda(), 4096)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    ref_img, xy, desc, ao = oracle.extract_features_grid(bgr[0], 1, 1, pat)
+    n = len(xy)
+    assert out["n"][0] == n and n >= 400
+    assert np.array_equal(out["xy"][0, :n].view(np.uint32), xy.view(np.uint32))
+    assert np.array_equal(out["angle_octave"][0, :n].view(np.uint32), ao.view(np.uint32))
+    assert np.array_equal(out["desc"][0, :n], desc)

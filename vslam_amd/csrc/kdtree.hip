@@ -54,80 +54,6 @@ struct LdsStore {
     __device__ bool less(float a, float b) const { return a < b; }
 };
 
-// ---- wave-cooperative replay of std::nth_element ---------------------------------------------
-// introselect's unguarded Hoare partition is a fixed pairing: with L_k the k-th position (ascending)
-// whose key is not < pivot and R_k the k-th position (descending, the pivot slot itself being the
-// last one) whose key is not > pivot, the loop swaps (L_k, R_k) for every k with L_k < R_k and returns
-// min(L_K, R_{K-1}) for the first K with L_K >= R_K.  That is two ballot prefix scans, one parallel
-// swap and no data-dependent serial chain, so one wave does a 2000-element partition in a few
-// hundred cycles instead of a lane walking it element by element.  Median-of-three, the <= 3 element
-// insertion sort and the (rare) heap-select fallback stay on lane 0.  Same permutation as
-// vs_sel::nth_element, hence as libstdc++.
-__device__ __forceinline__ void wave_sync_lds() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ int wave_partition(LdsStore &s, int a, int b, float pv, int *sl, int *sr) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int nL = 0, nR = 0;
-    for (int p0 = a; p0 < b; p0 += 64) {   // left stoppers, ascending
-        const int p = p0 + lane;
-        const bool st = p < b && !s.less(s.key(p), pv);
-        const unsigned long long bal = __ballot(st);
-        if (st) sl[a + nL + (int)__popcll(bal & lt)] = p;
-        nL += (int)__popcll(bal);
-    }
-    for (int p0 = b - 1; p0 >= a - 1; p0 -= 64) {   // right stoppers, descending, pivot slot a-1 included
-        const int p = p0 - lane;
-        const bool st = p >= a - 1 && !s.less(pv, s.key(p));
-        const unsigned long long bal = __ballot(st);
-        if (st) sr[a + nR + (int)__popcll(bal & lt)] = p;
-        nR += (int)__popcll(bal);
-    }
-    wave_sync_lds();
-    const int m = nL < nR ? nL : nR;
-    int K = 0;
-    for (int k0 = 0; k0 < m; k0 += 64) {   // pairs are monotone: count the leading L_k < R_k
-        const int k = k0 + lane;
-        const bool sw = k < m && sl[a + k] < sr[a + k];
-        const unsigned long long bal = __ballot(sw);
-        if (sw) s.swap(sl[a + k], sr[a + k]);
-        K += (int)__popcll(bal);
-        if (bal != ~0ull) break;
-    }
-    const int cl = K < nL ? sl[a + K] : 0x7FFFFFFF;
-    const int cr = K > 0 ? sr[a + K - 1] : 0x7FFFFFFF;
-    wave_sync_lds();
-    return cl < cr ? cl : cr;
-}
-
-__device__ void wave_nth_element(LdsStore &s, int first, int nth, int last, int *sl, int *sr) {
-    const int lane = threadIdx.x & 63;
-    if (first == last || nth == last) return;
-    int depth_limit = vs_sel::floor_lg(last - first) * 2;
-    while (last - first > 3) {
-        if (depth_limit == 0) {
-            if (lane == 0) {
-                vs_sel::heap_select(s, first, nth + 1, last);
-                s.swap(first, nth);
-            }
-            wave_sync_lds();
-            return;
-        }
-        --depth_limit;
-        if (lane == 0) vs_sel::move_median_to_first(s, first, first + 1, first + (last - first) / 2, last - 1);
-        wave_sync_lds();
-        const int cut = wave_partition(s, first + 1, last, s.key(first), sl, sr);
-        if (cut <= nth) first = cut;
-        else last = cut;
-    }
-    if (lane == 0) vs_sel::insertion_sort(s, first, last);
-    wave_sync_lds();
-}
-
 constexpr int kWaveMinLen = 48;   // shorter ranges: one lane per subtree is cheaper than a wave each
 
 __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float *__restrict__ xy,
@@ -176,7 +102,7 @@ __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float
                 LdsStore s(kx, ky, id, depth & 1);
                 const int mid = first + (last - first) / 2;
                 if (by_wave) {
-                    wave_nth_element(s, first, mid, last, sl, sr);
+                    vs_sel::wave_nth_element(s, first, mid, last, sl, sr);
                     if (lane == 0) out[pos] = id[mid];
                 } else {
                     vs_sel::nth_element(s, first, mid, last);

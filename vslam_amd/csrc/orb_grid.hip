@@ -310,32 +310,50 @@ struct RespStore {
     __device__ bool less(float a, float b) const { return a > b; }   // KeypointResponseGreater
 };
 
-__global__ __launch_bounds__(64) void retain_best_kernel(PyrLayout L, SlotLayout SL, int mult, short2 *__restrict__ kp_xy,
-                                                         float *__restrict__ kp_resp, int32_t *__restrict__ kp_cnt) {
+// xy_in -> xy_out (permuted when a selection happens, copied otherwise); responses permuted in place.
+// Work arrays live in LDS when the list fits (the usual case) and in a per-slot global scratch otherwise.
+__global__ __launch_bounds__(64) void retain_best_kernel(PyrLayout L, SlotLayout SL, int mult, const short2 *__restrict__ xy_in,
+                                                         short2 *__restrict__ xy_out, float *__restrict__ kp_resp,
+                                                         int32_t *__restrict__ kp_cnt, int lds_entries,
+                                                         float *__restrict__ g_key, int *__restrict__ g_pay,
+                                                         int *__restrict__ g_sl, int *__restrict__ g_sr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int u = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
     int32_t *cnt = kp_cnt + (size_t)u * kMaxLevels + l;
     const int n = *cnt;
     const int n_points = mult * SL.per_level[l];
-    if (!(n_points >= 0 && n > n_points)) return;
+    const size_t slot = (size_t)u * SL.off[L.nlevels] + SL.off[l];
+    if (!(n_points >= 0 && n > n_points)) {
+        for (int i = tid; i < n; i += 64) xy_out[slot + i] = xy_in[slot + i];
+        return;
+    }
     if (n_points == 0) {
         if (tid == 0) *cnt = 0;
         return;
     }
-    const size_t slot = (size_t)u * SL.off[L.nlevels] + SL.off[l];
-    float *key = reinterpret_cast<float *>(smem);
-    int *pay = reinterpret_cast<int *>(key + SL.cap[0]);
-    short2 *xy = reinterpret_cast<short2 *>(pay + SL.cap[0]);
+    float *key;
+    int *pay, *sl, *sr;
+    if (n + 1 <= lds_entries) {
+        key = reinterpret_cast<float *>(smem);
+        pay = reinterpret_cast<int *>(key + lds_entries);
+        sl = pay + lds_entries;
+        sr = sl + lds_entries;
+    } else {
+        key = g_key + slot;
+        pay = g_pay + slot;
+        sl = g_sl + slot;
+        sr = g_sr + slot + ((size_t)u * kMaxLevels + l);   // one spare element per slot
+    }
     for (int i = tid; i < n; i += 64) {
         key[i] = kp_resp[slot + i];
         pay[i] = i;
-        xy[i] = kp_xy[slot + i];
     }
     __syncthreads();
     __shared__ int s_new_n;
+    RespStore s{key, pay};
+    vs_sel::wave_nth_element(s, 0, n_points - 1, n, sl, sr);   // the block is one wave
+    __syncthreads();
     if (tid == 0) {
-        RespStore s{key, pay};
-        vs_sel::nth_element(s, 0, n_points - 1, n);
         const float ambiguous = key[n_points - 1];
         // std::partition (bidirectional), pred: response >= ambiguous
         int first = n_points, last = n;
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(64) void retain_best_kernel(PyrLayout L, SlotLayout
     const int m = s_new_n;
     for (int i = tid; i < m; i += 64) {
         kp_resp[slot + i] = key[i];
-        kp_xy[slot + i] = xy[pay[i]];
+        xy_out[slot + i] = xy_in[slot + pay[i]];
     }
     if (tid == 0) *cnt = m;
 }
@@ -681,22 +699,27 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
         VsProfScope ps(ctx, "fast_score_kernel");
         fast_score_kernel<<<dim3(vs_div_up(LC.roi_prefix[nlevels], 256), units), 256, 0, st>>>(LC, pyrc, mmap);
     }
-    const size_t sel_lds = (size_t)SL.cap[0] * 12;
-    VS_REQUIRE(ctx, sel_lds <= 150 * 1024, VSLAM_ERR_CAPACITY);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(retain_best_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    // selection work arrays: LDS for lists of up to 4095 keypoints, a per-slot global scratch beyond that
+    const int lds_entries = std::min(SL.cap[0] + 1, 4096);
+    const size_t sel_lds = (size_t)lds_entries * 16;
+    short2 *kxy_tmp = nullptr;
+    float *g_key = nullptr;
+    int *g_pay = nullptr, *g_sl = nullptr, *g_sr = nullptr;
+    if ((rc = vs_arena_get(ctx, "grid.kxy_tmp", sizeof(short2) * slots, (void **)&kxy_tmp))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.sel_key", sizeof(float) * slots, (void **)&g_key))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.sel_pay", sizeof(int) * slots, (void **)&g_pay))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.sel_sl", sizeof(int) * slots, (void **)&g_sl))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.sel_sr", sizeof(int) * (slots + (size_t)units * kMaxLevels + 1), (void **)&g_sr))) return rc;
     const int thr[2] = {20, 5};   // src/Frame.cpp:22-23
     for (int t = 0; t < 2; t++) {
         VsProfScope ps(ctx, t ? "orb_detect_t5_kernels" : "orb_detect_t20_kernels");
         fast_collect_kernel<<<dim3(nlevels, units), 256, 0, st>>>(LC, SL, mmap, thr[t], kxy[t], kresp[t], kcnt[t]);
-        retain_best_kernel<<<dim3(nlevels, units), 64, sel_lds, st>>>(LC, SL, 2, kxy[t], kresp[t], kcnt[t]);
+        retain_best_kernel<<<dim3(nlevels, units), 64, sel_lds, st>>>(LC, SL, 2, kxy[t], kxy_tmp, kresp[t], kcnt[t], lds_entries,
+                                                                      g_key, g_pay, g_sl, g_sr);
         const int maxk = vs_div_up(SL.cap[0], 256);
-        harris_kernel<<<dim3(maxk, nlevels, units), 256, 0, st>>>(LC, SL, pyrc, kxy[t], kresp[t], kcnt[t]);
-        retain_best_kernel<<<dim3(nlevels, units), 64, sel_lds, st>>>(LC, SL, 1, kxy[t], kresp[t], kcnt[t]);
+        harris_kernel<<<dim3(maxk, nlevels, units), 256, 0, st>>>(LC, SL, pyrc, kxy_tmp, kresp[t], kcnt[t]);
+        retain_best_kernel<<<dim3(nlevels, units), 64, sel_lds, st>>>(LC, SL, 1, kxy_tmp, kxy[t], kresp[t], kcnt[t], lds_entries,
+                                                                      g_key, g_pay, g_sl, g_sr);
         ic_angle_kernel<<<dim3(maxk, nlevels, units), 256, 0, st>>>(LC, SL, U, pyrc, kxy[t], kcnt[t], kfin[t]);
     }
     {
