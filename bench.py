@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch)")
     ap.add_argument("--cpu-pairs", type=int, default=150, help="pairs the CPU baseline times (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="split each GPU's batch over this many contexts (own stream + workspaces) that run concurrently")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also run two 1 GiB streaming copies (4 B and 16 B per lane) so FETCH_SIZE/WRITE_SIZE can be calibrated")
     args = ap.parse_args()
@@ -139,6 +141,10 @@ def main():
     thr = 10.0                                    # RansacFilter rf(8, 100, 10), src/vslam.cpp:19
     seed = 0x5EED0000 + sorted(WORKLOADS).index(args.workload)
     ctx = Context(local_rank)
+    lanes = max(1, args.lanes)
+    assert P % lanes == 0
+    PL = P // lanes
+    lane_ctx = [ctx] if lanes == 1 else [Context(local_rank, use_torch_stream=False) for _ in range(lanes)]
     bgr = synth.frames_torch(seed + 1000 * rank, P, w, h, dev)
     pat = torch.from_numpy(synth.brief_pattern()).to(dev)
     ca, sa = synth.keypoint_rotation()
@@ -147,8 +153,21 @@ def main():
     out = None
     gathered = torch.empty((world * P, shard.REC_HEAD + 2 * K), dtype=torch.int32, device=dev) if world > 1 else None
 
+    if lanes > 1:   # lane l owns pairs [l*PL, (l+1)*PL): its "last" and "current" frames made contiguous
+        lane_bgr = [torch.cat([bgr[l * PL:(l + 1) * PL], bgr[P + l * PL:P + (l + 1) * PL]]).contiguous() for l in range(lanes)]
+        lane_seeds = [seeds[l * PL:(l + 1) * PL].contiguous() for l in range(lanes)]
+        lane_out = [None] * lanes
+        torch.cuda.synchronize(dev)
+
     def step():
         nonlocal out
+        if lanes > 1:
+            for l in range(lanes):
+                lane_out[l] = lane_ctx[l].frontend_pairs(lane_bgr[l], PL, K, ca, sa, pat, lane_seeds[l], H, thr, out=lane_out[l])
+            for l in range(lanes):
+                lane_ctx[l].synchronize()
+            out = {k: torch.cat([lo[k] for lo in lane_out]) for k in ("best", "n", "F", "matches")}
+            return
         out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
         if world > 1:
             # the only exchange on the path: fixed-size per-pair result records to every rank

@@ -224,27 +224,30 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
     const float k1 = (float)scale, k0 = 2.0f * k1;
     const float ninf = -__builtin_inff();
     const bool own_lane = !FUSED || (lane >= 1 && lane <= 62);
-    uint32_t kmax = 0;
+    // tiles whose 6-wide / 3-tall product windows never leave the image skip the mirror-sign logic
+    const bool interior = x0 >= 4 && x0 + kE4W + 4 <= w && y0 >= 2 && y0 + kE4H + 2 <= h;
+    float emax = ninf;
     if (x >= 0 && x < w) {
-        // column c of the 6-wide window is image column x - 1 + c; mirrored columns flip the xy sign
         bool colflip[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) colflip[c] = (x - 1 + c < 0) || (x - 1 + c >= w);
         float hx[3][6], rr[3][6];
-        double rs[3][12];   // rolling row sums: [slot][channel * 4 + i]
+        // column sums S(y) = (r(y-1) + r(y)) + r(y+1) carried as: prev = r(y), pair = r(y-1) + r(y)
+        double prev[12], pair[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             const int t = grp * 8 + k;   // tile row; raw image row y0 - 2 + t
             const uint32_t d0 = G[t][lane], d1 = G[t][lane + 1], d2 = G[t][lane + 2];
-            int g[8];   // gray at columns x-2 .. x+5 = bytes 2..9 of the 12-byte window
-            g[0] = (d0 >> 16) & 0xFF; g[1] = d0 >> 24;
-            g[2] = d1 & 0xFF; g[3] = (d1 >> 8) & 0xFF; g[4] = (d1 >> 16) & 0xFF; g[5] = d1 >> 24;
-            g[6] = d2 & 0xFF; g[7] = (d2 >> 8) & 0xFF;
+            float g[8];   // gray at columns x-2 .. x+5 = bytes 2..9 of the 12-byte window (the compiler emits v_cvt_f32_ubyteN)
+            g[0] = (float)((d0 >> 16) & 0xFFu); g[1] = (float)(d0 >> 24);
+            g[2] = (float)((d1 >> 0) & 0xFFu); g[3] = (float)((d1 >> 8) & 0xFFu);
+            g[4] = (float)((d1 >> 16) & 0xFFu); g[5] = (float)(d1 >> 24);
+            g[6] = (float)((d2 >> 0) & 0xFFu); g[7] = (float)((d2 >> 8) & 0xFFu);
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                hx[k % 3][c] = (float)(g[c + 2] - g[c]);
-                const float a = (float)g[c + 1] * k0;
-                const float b = (float)(g[c] + g[c + 2]) * k1;
+                hx[k % 3][c] = g[c + 2] - g[c];          // small integers: exact in float
+                const float a = g[c + 1] * k0;
+                const float b = (g[c] + g[c + 2]) * k1;  // the integer sum is exact in float
                 rr[k % 3][c] = a + b;
             }
             if (k >= 2) {
@@ -260,50 +263,51 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
                     const float dy = rr[k % 3][c] - rr[(k - 2) % 3][c];
                     cxx[c] = dx * dx;
                     const float xy = dx * dy;
-                    cxy[c] = (rowflip != colflip[c]) ? -xy : xy;
+                    cxy[c] = (!interior && (rowflip != colflip[c])) ? -xy : xy;
                     cyy[c] = dy * dy;
                 }
-                double *cur = rs[k % 3];
+                double cur[12];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     cur[i] = ((double)cxx[i] + (double)cxx[i + 1]) + (double)cxx[i + 2];
                     cur[4 + i] = ((double)cxy[i] + (double)cxy[i + 1]) + (double)cxy[i + 2];
                     cur[8 + i] = ((double)cyy[i] + (double)cyy[i + 1]) + (double)cyy[i + 2];
                 }
-            }
-            if (k >= 4) {
-                const int lr = grp * 8 + (k - 4);   // row inside the tile
-                const int y = y0 + lr;
-                float e4[4] = {ninf, ninf, ninf, ninf};
-                if (y >= 0 && y < h) {
-                    const double *up = rs[(k - 2) % 3], *mid = rs[(k - 1) % 3], *dn = rs[k % 3];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float sxx = (float)((up[i] + mid[i]) + dn[i]);
-                        const float sxy = (float)((up[4 + i] + mid[4 + i]) + dn[4 + i]);
-                        const float syy = (float)((up[8 + i] + mid[8 + i]) + dn[8 + i]);
-                        const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
-                        const float amc = a - c;
-                        const float tt = amc * amc + b * b;
-                        e4[i] = (a + c) - sqrtf(tt);
-                    }
-                    const bool own = own_lane && (!FUSED || (lr >= 1 && lr <= kE4H - 2));
-                    if (own) {
+                if (k >= 4) {
+                    const int lr = grp * 8 + (k - 4);   // row inside the tile
+                    const int y = y0 + lr;
+                    float e4[4] = {ninf, ninf, ninf, ninf};
+                    if (y >= 0 && y < h) {
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const uint32_t ke = f2ord(e4[i]);
-                            kmax = ke > kmax ? ke : kmax;
+                            const float sxx = (float)(pair[i] + cur[i]);
+                            const float sxy = (float)(pair[4 + i] + cur[4 + i]);
+                            const float syy = (float)(pair[8 + i] + cur[8 + i]);
+                            const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
+                            const float amc = a - c;
+                            const float tt = amc * amc + b * b;
+                            e4[i] = (a + c) - sqrtf(tt);
                         }
-                        *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                        const bool own = own_lane && (!FUSED || (lr >= 1 && lr <= kE4H - 2));
+                        if (own) {
+                            emax = fmaxf(emax, fmaxf(fmaxf(e4[0], e4[1]), fmaxf(e4[2], e4[3])));
+                            *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                        }
                     }
+                    if (FUSED) *reinterpret_cast<float4 *>(&ET[lr][4 * lane + 4]) = make_float4(e4[0], e4[1], e4[2], e4[3]);
                 }
-                if (FUSED) *reinterpret_cast<float4 *>(&ET[lr][4 * lane + 4]) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    if (k >= 3) pair[i] = prev[i] + cur[i];
+                    prev[i] = cur[i];
+                }
             }
         }
     } else if (FUSED) {
 #pragma unroll
         for (int k = 0; k < 8; k++) *reinterpret_cast<float4 *>(&ET[grp * 8 + k][4 * lane + 4]) = make_float4(ninf, ninf, ninf, ninf);
     }
+    const uint32_t kmax = emax == ninf ? 0u : f2ord(emax);   // 0 is the identity of the ordered-key max
     if (frame_max) {
         uint32_t k = kmax;
 #pragma unroll
@@ -344,14 +348,9 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const float v = mid[i + 1];
-                        float m = up[i];
-                        m = up[i + 1] > m ? up[i + 1] : m;
-                        m = up[i + 2] > m ? up[i + 2] : m;
-                        m = mid[i] > m ? mid[i] : m;
-                        m = mid[i + 2] > m ? mid[i + 2] : m;
-                        m = dn[i] > m ? dn[i] : m;
-                        m = dn[i + 1] > m ? dn[i + 1] : m;
-                        m = dn[i + 2] > m ? dn[i + 2] : m;
+                        // no NaNs here, so fmaxf (v_max3_f32) is the plain maximum of the 8 neighbours
+                        const float m = fmaxf(fmaxf(fmaxf(up[i], up[i + 1]), fmaxf(up[i + 2], mid[i])),
+                                              fmaxf(fmaxf(mid[i + 2], dn[i]), fmaxf(dn[i + 1], dn[i + 2])));
                         const int xx = x + i;
                         const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v > thr_p && !(m > v);
                         if (cand) {
@@ -506,14 +505,9 @@ __global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const float v = mid[i + 1];
-                        float m = up[i];
-                        m = up[i + 1] > m ? up[i + 1] : m;
-                        m = up[i + 2] > m ? up[i + 2] : m;
-                        m = mid[i] > m ? mid[i] : m;
-                        m = mid[i + 2] > m ? mid[i + 2] : m;
-                        m = dn[i] > m ? dn[i] : m;
-                        m = dn[i + 1] > m ? dn[i + 1] : m;
-                        m = dn[i + 2] > m ? dn[i + 2] : m;
+                        // no NaNs here, so fmaxf (v_max3_f32) is the plain maximum of the 8 neighbours
+                        const float m = fmaxf(fmaxf(fmaxf(up[i], up[i + 1]), fmaxf(up[i + 2], mid[i])),
+                                              fmaxf(fmaxf(mid[i + 2], dn[i]), fmaxf(dn[i + 1], dn[i + 2])));
                         const int xx = x + i;
                         const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v != 0.f && !(m > v);
                         if (cand) {
