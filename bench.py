@@ -74,6 +74,24 @@ def pmc_traffic(kernel):
     return None
 
 
+def _cpu_worker(args):
+    wl, n_pairs, seed = args
+    return cpu_baseline(wl, n_pairs, seed)["value"]
+
+
+def cpu_baseline_all_cores(wl, pairs_per_proc, seed):
+    """The same oracle as independent pairs on every host core: one process per core."""
+    import multiprocessing as mp
+    procs = max(1, min(len(os.sched_getaffinity(0)), 16))   # a one-GPU box's CPU share is 16 cores
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(procs) as pool:
+        rates = pool.map(_cpu_worker, [(wl, pairs_per_proc, seed + 17 * i) for i in range(procs)])
+    dt = time.perf_counter() - t0
+    return {"value": float(sum(rates)), "unit": "frame-pairs/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} concurrent processes x {pairs_per_proc} pairs of {wl}, oracle; sum of per-process rates "
+                      f"(input generation excluded), {dt:.1f} s wall"}
+
+
 def cpu_baseline(wl, sample_pairs, seed):
     """The oracle (oracle/, a CPU port of the reference path; the reference itself cannot be built
     here) on `sample_pairs` pairs of the same workload, one thread."""
@@ -104,6 +122,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch)")
     ap.add_argument("--cpu-pairs", type=int, default=150, help="pairs the CPU baseline times (0 = skip)")
+    ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
+                    help="pairs per process for the all-host-cores CPU figure (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--lanes", type=int, default=1,
                     help="split each GPU's batch over this many contexts (own stream + workspaces) that run concurrently")
@@ -262,6 +282,8 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
         result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_pairs, seed)
+        if args.cpu_all_cores_pairs > 0:
+            result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, args.cpu_all_cores_pairs, seed)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
