@@ -73,8 +73,10 @@ def keypoint_rotation(angle_deg=-1.0):
 
 def frames_numpy(seed, n_pairs, width, height):
     """BGR uint8 frames, shape (2*n_pairs, H, W, 3): frames [0,n) are 'last', [n,2n) 'current'.
-    Blocky random texture (two cell sizes) so corner detectors find thousands of junctions,
-    low-amplitude noise, and frame B = frame A translated by a few pixels with fresh noise."""
+    Blocky random texture (three cell sizes) so corner detectors find thousands of junctions,
+    low-amplitude noise, and frame B = frame A translated by a few pixels with fresh noise, except for
+    an independently moving block (about a fifth of the image) whose matches are outliers to the
+    dominant epipolar geometry."""
     rng = np.random.default_rng(seed)
     out = np.zeros((2 * n_pairs, height, width, 3), dtype=np.uint8)
     for p in range(n_pairs):
@@ -88,7 +90,11 @@ def frames_numpy(seed, n_pairs, width, height):
         base = np.clip(128 + base, 8, 247)
         dx, dy = rng.integers(-12, 13, size=2)
         a = base[16:16 + height, 16:16 + width]
-        b = base[16 + dy:16 + dy + height, 16 + dx:16 + dx + width]
+        b = base[16 + dy:16 + dy + height, 16 + dx:16 + dx + width].copy()
+        dx2, dy2 = rng.integers(-12, 13, size=2)
+        bw, bh = int(width * 0.45), int(height * 0.45)
+        bx, by = rng.integers(0, width - bw), rng.integers(0, height - bh)
+        b[by:by + bh, bx:bx + bw] = base[16 + dy2 + by:16 + dy2 + by + bh, 16 + dx2 + bx:16 + dx2 + bx + bw]
         for f, img in ((p, a), (n_pairs + p, b)):
             for c in range(3):
                 noise = rng.integers(-6, 7, size=(height, width))
@@ -111,11 +117,16 @@ def frames_torch(seed, n_pairs, width, height, device):
         base += up[:, 3:3 + H2, 5:5 + W2]
     base = torch.clamp(128 + base, 8, 247)
     out = torch.empty((2 * n_pairs, height, width, 3), dtype=torch.uint8, device=device)
-    shifts = torch.randint(-12, 13, (n_pairs, 2), generator=g, device=device).cpu()
+    shifts = torch.randint(-12, 13, (n_pairs, 4), generator=g, device=device).cpu()
+    bw, bh = int(width * 0.45), int(height * 0.45)
+    corner = torch.stack([torch.randint(0, width - bw, (n_pairs,), generator=g, device=device),
+                          torch.randint(0, height - bh, (n_pairs,), generator=g, device=device)], 1).cpu()
     for p in range(n_pairs):
-        dx, dy = int(shifts[p, 0]), int(shifts[p, 1])
+        dx, dy, dx2, dy2 = (int(v) for v in shifts[p])
+        bx, by = int(corner[p, 0]), int(corner[p, 1])
         a = base[p, 16:16 + height, 16:16 + width]
-        b = base[p, 16 + dy:16 + dy + height, 16 + dx:16 + dx + width]
+        b = base[p, 16 + dy:16 + dy + height, 16 + dx:16 + dx + width].clone()
+        b[by:by + bh, bx:bx + bw] = base[p, 16 + dy2 + by:16 + dy2 + by + bh, 16 + dx2 + bx:16 + dx2 + bx + bw]
         for f, img in ((p, a), (n_pairs + p, b)):
             noise = torch.randint(-6, 7, (height, width, 3), generator=g, device=device).float()
             tint = torch.tensor([-4.0, 0.0, 4.0], device=device)
