@@ -168,3 +168,28 @@ def test_good_features_tiny_max_corners_forces_slow_path(ctx, oracle):
             ref = oracle.good_features(gray[f], maxc)
             assert n[f] == len(ref), (maxc, f, n[f], len(ref))
             assert np.array_equal(xy[f, :n[f]], ref), (maxc, f)
+
+
+def test_frontend_headline_size_one_pair(ctx, oracle):
+    """One frame pair at BASELINE.json's headline shape (1280x720, 2000 keypoints, 4096 hypotheses):
+    every output of the whole path equals the oracle's, bit for bit."""
+    w, h, maxc, Hy, thr = 1280, 720, 2000, 4096, 10.0
+    bgr = synth.frames_numpy(0x5EED0002, 1, w, h)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    seeds = np.array([0x5EED0002], np.uint32)
+    out = ctx.frontend_pairs(torch.from_numpy(bgr).cuda(), 1, maxc, ca, sa, torch.from_numpy(pat).cuda(),
+                             torch.from_numpy(seeds.view(np.int32)).cuda(), Hy, thr)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    ex = [oracle.extract_features(bgr[f], maxc, ca, sa, pat) for f in range(2)]
+    for f in range(2):
+        k = ex[f]["n"]
+        assert out["n"][f] == k and k > 1500
+        assert np.array_equal(out["xy"][f, :k], ex[f]["xy"]) and np.array_equal(out["desc"][f, :k], ex[f]["desc"])
+        assert np.array_equal(out["nodes"][f, :k], ex[f]["nodes"])
+    ref = oracle.match_features(ex[0]["xy"], ex[0]["desc"], ex[1]["xy"], ex[1]["desc"], int(seeds[0]), Hy, thr)
+    k = len(ref["matches"])
+    assert ref["rc"] == 0 and out["best"][0, 3] == k and k > 500
+    assert np.array_equal(out["matches"][0, :k], ref["matches"])
+    assert np.array_equal(out["F"][0].view(np.uint32), ref["F"].view(np.uint32))
