@@ -200,6 +200,17 @@ int vslam_triangulate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, co
                       const int32_t *d_best, int batch, int kp_stride, const float *h_K,
                       const float *d_c2, float *d_points4d);
 
+/* Replaces the reprojection-error filter of src/vslam.cpp:192-251, reproducing the reference exactly,
+ * including its two indexing quirks (the de-homogenise loop strides the flat N x 3 array by 3 up to N, and
+ * map_point_ids is tested at the MATCH index).  d_points4d from vslam_triangulate; d_map_point_ids
+ * [batch][kp_stride] of the current frame; threshold_sq = 4 in the reference (src/vslam.cpp:50).
+ * d_inlier_idx [batch][kp_stride] kept match indices (ascending), d_n_inliers [batch], d_error [batch] f64. */
+int vslam_reprojection_filter(vslam_ctx *ctx, const float *d_points4d, const float *d_xy1, const float *d_xy2,
+                              const int32_t *d_matches, const int32_t *d_best, int batch, int kp_stride,
+                              const float *h_K, const float *d_c2, const int32_t *d_map_point_ids,
+                              float threshold_sq, int32_t *d_inlier_idx, int32_t *d_n_inliers,
+                              double *d_error);
+
 /* Replaces the map-association loop of src/vslam.cpp:129-161 and orb_distance (src/PointMap.cpp:36-46):
  * project each map point with c2, radius_search (r = 2 in the reference) in the frame's k-d tree, and
  * give it the first hit that is unassigned and within `dist_threshold` (64) Hamming of the map point's

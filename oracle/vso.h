@@ -136,6 +136,11 @@ int vso_camera_matrix(const float *K, const float *R, const float *t, float *c2)
 /* triangulate(p1, p2, c1, c2, points_4d): src/helpers.cpp:37-80 */
 int vso_triangulate(const float *p1, const float *p2, int n, const float *c1, const float *c2, float *points_4d);
 
+/* reprojection-error filter: src/vslam.cpp:192-251 (bug-for-bug: flat stride-3 de-homogenise, match-indexed
+ * map_point_ids test).  p1/p2: the matched coordinates (n x 2).  out_idx: kept match indices. */
+int vso_reprojection_filter(const float *points_4d, const float *p1, const float *p2, int n, const float *c1,
+                            const float *c2, const int32_t *map_point_ids, float threshold_sq,
+                            int32_t *out_idx, int32_t *out_n, double *out_err);
 /* map association: src/vslam.cpp:129-161 + orb_distance (src/PointMap.cpp:36-46) */
 int vso_associate_map_points(const float *map_points, int n_map, const float *c2, int img_w, int img_h,
                              const int32_t *kd_nodes, const float *kp_xy, const uint8_t *kp_desc, int n_kp,

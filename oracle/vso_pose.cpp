@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -163,5 +164,54 @@ extern "C" int vso_associate_map_points(const float *map_points /*N x 4*/, int n
             }
         }
     }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Reprojection-error filter, src/vslam.cpp:192-251, restated bug for bug:
+//   reproj = points_4d (N x 4) * c.t()  (GEMM_2_T: double products, (s0+s1+s2+s3), one rounding);
+//   the de-homogenise loop walks the FLAT N x 3 array with `i += 3` while `i < rows`, so only the first
+//   ceil(N/3) points are divided by their third coordinate (:201-211);
+//   d = reproj(:, 0:2) - initial_points; re = d.row(i).dot(d.row(i)) (double accumulate, stored as f32);
+//   a match is skipped when frame.map_point_ids[i] > 0 — indexed by the MATCH index i (:240);
+//   kept when re1 <= thresholdSq and re2 <= thresholdSq; reproj_error += re1 + re2 in double.
+extern "C" int vso_reprojection_filter(const float *points_4d, const float *p1, const float *p2, int n, const float *c1,
+                                       const float *c2, const int32_t *map_point_ids, float threshold_sq,
+                                       int32_t *out_idx, int32_t *out_n, double *out_err) {
+    std::vector<float> r1((size_t)n * 3), r2((size_t)n * 3);
+    for (int i = 0; i < n; i++) {
+        const float *P = points_4d + (size_t)i * 4;
+        for (int r = 0; r < 3; r++) {
+            r1[(size_t)i * 3 + r] = (float)((((double)P[0] * c1[r * 4 + 0] + (double)P[1] * c1[r * 4 + 1]) + (double)P[2] * c1[r * 4 + 2]) +
+                                            (double)P[3] * c1[r * 4 + 3]);
+            r2[(size_t)i * 3 + r] = (float)((((double)P[0] * c2[r * 4 + 0] + (double)P[1] * c2[r * 4 + 1]) + (double)P[2] * c2[r * 4 + 2]) +
+                                            (double)P[3] * c2[r * 4 + 3]);
+        }
+    }
+    for (int i = 0; i < n; i += 3) {          // flat index, stride 3, bound = rows (:201)
+        float &h1 = r1[i + 2];
+        r1[i] /= h1;
+        r1[i + 1] /= h1;
+        h1 = 1;
+        float &h2 = r2[i + 2];
+        r2[i] /= h2;
+        r2[i + 1] /= h2;
+        h2 = 1;
+    }
+    int k = 0;
+    double err = 0;
+    for (int i = 0; i < n; i++) {
+        if (map_point_ids[i] > 0) continue;                                     // :240
+        const float d1x = r1[(size_t)i * 3] - p1[2 * i], d1y = r1[(size_t)i * 3 + 1] - p1[2 * i + 1];
+        const float re1 = (float)((double)d1x * d1x + (double)d1y * d1y);
+        if (re1 > threshold_sq) continue;
+        const float d2x = r2[(size_t)i * 3] - p2[2 * i], d2y = r2[(size_t)i * 3 + 1] - p2[2 * i + 1];
+        const float re2 = (float)((double)d2x * d2x + (double)d2y * d2y);
+        if (re2 > threshold_sq) continue;
+        out_idx[k++] = i;
+        err += re1 + re2;                                                       // float sum promoted, :249
+    }
+    *out_n = k;
+    *out_err = err;
     return 0;
 }

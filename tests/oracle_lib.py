@@ -260,3 +260,14 @@ class Oracle:
                                                  _p(od, C.c_uint8), C.c_float(radius), C.c_uint32(thr), _p(ids, C.c_int32),
                                                  _p(claim, C.c_int32)) == 0
         return ids, claim[:len(mp)]
+
+    def reprojection_filter(self, pts4d, p1, p2, c1, c2, ids, thr_sq=4.0):
+        pts4d = np.ascontiguousarray(pts4d, dtype=np.float32); p1 = np.ascontiguousarray(p1, dtype=np.float32)
+        p2 = np.ascontiguousarray(p2, dtype=np.float32); ids = np.ascontiguousarray(ids, dtype=np.int32)
+        c1 = np.ascontiguousarray(c1, dtype=np.float32).reshape(12); c2 = np.ascontiguousarray(c2, dtype=np.float32).reshape(12)
+        n = len(pts4d)
+        idx = np.zeros(max(n, 1), np.int32); k = C.c_int32(); err = C.c_double()
+        assert self.lib.vso_reprojection_filter(_p(pts4d, C.c_float), _p(p1, C.c_float), _p(p2, C.c_float), n, _p(c1, C.c_float),
+                                                _p(c2, C.c_float), _p(ids, C.c_int32), C.c_float(thr_sq), _p(idx, C.c_int32),
+                                                C.byref(k), C.byref(err)) == 0
+        return idx[:k.value].copy(), err.value

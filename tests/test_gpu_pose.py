@@ -26,7 +26,11 @@ def test_pose_chain_bit_exact(ctx, oracle):
     out = ctx.ransac_fundamental(t(xy1), t(xy2), t(pairs), t(m), t(sets), thr)
     R, tv, c2 = ctx.extract_Rt(out["F"], out["best"], Kmat)
     pts = ctx.triangulate(t(xy1), t(xy2), out["matches"], out["best"], Kmat, c2)
+    ids = np.full((B, K), -1, np.int32)
+    ids[:, ::7] = 3                                   # some matches are skipped through the match-indexed id test
+    ridx, rn, rerr = ctx.reprojection_filter(pts, t(xy1), t(xy2), out["matches"], out["best"], Kmat, c2, t(ids), 4.0)
     ctx.synchronize()
+    ridx, rn, rerr = ridx.cpu().numpy(), rn.cpu().numpy(), rerr.cpu().numpy()
     Fh, best, matches = out["F"].cpu().numpy(), out["best"].cpu().numpy(), out["matches"].cpu().numpy()
     R, tv, c2, pts = R.cpu().numpy(), tv.cpu().numpy(), c2.cpu().numpy(), pts.cpu().numpy()
     c1 = np.c_[Kmat, np.zeros(3, np.float32)]
@@ -43,6 +47,9 @@ def test_pose_chain_bit_exact(ctx, oracle):
         mm = matches[b, :k]
         ref = oracle.triangulate(xy1[b][mm[:, 0]], xy2[b][mm[:, 1]], c1, c2r)
         assert np.array_equal(bits(pts[b, :k]), bits(ref)), b
+        kept, err = oracle.reprojection_filter(ref, xy1[b][mm[:, 0]], xy2[b][mm[:, 1]], c1, c2r, ids[b, :k], 4.0)
+        assert rn[b] == len(kept) and np.array_equal(ridx[b, :rn[b]], kept), b
+        assert rerr[b] == err, b
         # and it is a rotation with unit translation
         assert abs(np.linalg.det(Rr.astype(np.float64)) - 1) < 1e-4 and abs(np.linalg.norm(tr) - 1) < 1e-5
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
     "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_extract_features_grid", "vslam_bgr2gray", "vslam_min_eigen",
-    "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points",
+    "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points", "vslam_reprojection_filter",
     "vslam_match_features",
     "vslam_frontend_pairs",
 ]
@@ -316,6 +316,19 @@ class Context:
         self._check(self.lib.vslam_triangulate(self.handle, _ptr(xy1), _ptr(xy2), _ptr(matches), _ptr(best), C.c_int(B),
                                                C.c_int(Kp), Kh.ctypes.data_as(C.c_void_p), _ptr(c2), _ptr(pts)))
         return pts
+
+    def reprojection_filter(self, pts4d, xy1, xy2, matches, best, K, c2, ids, thr_sq=4.0):
+        import numpy as np
+        torch = self.torch
+        B, Kp, _ = xy1.shape
+        Kh = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        idx = torch.full((B, Kp), -1, dtype=torch.int32, device=xy1.device)
+        n = torch.zeros((B,), dtype=torch.int32, device=xy1.device)
+        err = torch.zeros((B,), dtype=torch.float64, device=xy1.device)
+        self._check(self.lib.vslam_reprojection_filter(self.handle, _ptr(pts4d), _ptr(xy1), _ptr(xy2), _ptr(matches), _ptr(best),
+                                                       C.c_int(B), C.c_int(Kp), Kh.ctypes.data_as(C.c_void_p), _ptr(c2), _ptr(ids),
+                                                       C.c_float(thr_sq), _ptr(idx), _ptr(n), _ptr(err)))
+        return idx, n, err
 
     def associate(self, map_points, n_map, c2, w, h, nodes, xy, desc, n, obs_offsets, obs_desc, ids, radius=2.0, thr=64):
         torch = self.torch

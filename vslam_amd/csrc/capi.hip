@@ -400,6 +400,16 @@ int vslam_triangulate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, co
     return vs_launch_triangulate(ctx, d_xy1, d_xy2, d_matches, d_best, batch, kp_stride, h_K, d_c2, d_points4d);
 }
 
+// reprojection-error filter, src/vslam.cpp:192-251
+int vslam_reprojection_filter(vslam_ctx *ctx, const float *d_points4d, const float *d_xy1, const float *d_xy2,
+                              const int32_t *d_matches, const int32_t *d_best, int batch, int kp_stride, const float *h_K,
+                              const float *d_c2, const int32_t *d_map_point_ids, float threshold_sq, int32_t *d_inlier_idx,
+                              int32_t *d_n_inliers, double *d_error) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_reproj_filter(ctx, d_points4d, d_xy1, d_xy2, d_matches, d_best, batch, kp_stride, h_K, d_c2,
+                                   d_map_point_ids, threshold_sq, d_inlier_idx, d_n_inliers, d_error);
+}
+
 // map association, src/vslam.cpp:129-161 + orb_distance (src/PointMap.cpp:36-46)
 int vslam_associate_map_points(vslam_ctx *ctx, const float *d_map_points, const int32_t *d_n_map, int batch, int map_stride,
                                const float *d_c2, int img_w, int img_h, const int32_t *d_nodes, const float *d_xy,

@@ -141,3 +141,7 @@ int vs_launch_associate(vslam_ctx *ctx, const float *map_points, const int32_t *
                         const float *c2, int img_w, int img_h, const int32_t *nodes, const float *xy, const uint8_t *desc,
                         const int32_t *n_kp, int kp_stride, const int32_t *obs_offsets, const uint8_t *obs_desc,
                         int obs_stride, float radius, uint32_t dist_threshold, int32_t *map_point_ids, int32_t *claim);
+int vs_launch_reproj_filter(vslam_ctx *ctx, const float *points4d, const float *xy1, const float *xy2, const int32_t *matches,
+                            const int32_t *best, int batch, int kp_stride, const float *h_K, const float *c2,
+                            const int32_t *map_point_ids, float threshold_sq, int32_t *out_idx, int32_t *out_n,
+                            double *out_err);

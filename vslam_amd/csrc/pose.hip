@@ -308,7 +308,125 @@ __global__ __launch_bounds__(128) void triangulate_kernel(const float *__restric
     reinterpret_cast<float4 *>(points4d)[(size_t)b * kp_stride + i] = o;
 }
 
+// Reprojection-error filter of src/vslam.cpp:192-251, bug for bug (see oracle/vso_pose.cpp): one workgroup per pair.
+// rp1 / rp2: [batch][kp_stride][3] scratch for the reprojected homogeneous points.
+__global__ __launch_bounds__(256) void reproj_filter_kernel(const float *__restrict__ points4d, const float *__restrict__ xy1,
+                                                            const float *__restrict__ xy2, const int32_t *__restrict__ matches,
+                                                            const int32_t *__restrict__ best, int kp_stride, Mat3 Kc,
+                                                            const float *__restrict__ c2_all,
+                                                            const int32_t *__restrict__ map_point_ids, float threshold_sq,
+                                                            float *__restrict__ rp1, float *__restrict__ rp2,
+                                                            int32_t *__restrict__ out_idx, int32_t *__restrict__ out_n,
+                                                            double *__restrict__ out_err, float *__restrict__ kept_err) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int n = best[(size_t)b * 4] < 0 ? 0 : best[(size_t)b * 4 + 3];
+    float *R1 = rp1 + (size_t)b * kp_stride * 3, *R2 = rp2 + (size_t)b * kp_stride * 3;
+    float c1[12], c2[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        c1[r * 4 + 0] = Kc.v[r * 3 + 0];
+        c1[r * 4 + 1] = Kc.v[r * 3 + 1];
+        c1[r * 4 + 2] = Kc.v[r * 3 + 2];
+        c1[r * 4 + 3] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) c2[k] = c2_all[(size_t)b * 12 + k];
+    for (int i = tid; i < n; i += 256) {   // points_4d * c.t(): exact double products, (s0+s1+s2+s3), one rounding
+        const float4 P = reinterpret_cast<const float4 *>(points4d)[(size_t)b * kp_stride + i];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            R1[(size_t)i * 3 + r] = (float)((((double)P.x * (double)c1[r * 4] + (double)P.y * (double)c1[r * 4 + 1]) +
+                                             (double)P.z * (double)c1[r * 4 + 2]) + (double)P.w * (double)c1[r * 4 + 3]);
+            R2[(size_t)i * 3 + r] = (float)((((double)P.x * (double)c2[r * 4] + (double)P.y * (double)c2[r * 4 + 1]) +
+                                             (double)P.z * (double)c2[r * 4 + 2]) + (double)P.w * (double)c2[r * 4 + 3]);
+        }
+    }
+    __syncthreads();
+    for (int i = 3 * tid; i < n; i += 3 * 256) {   // flat stride-3 walk bounded by rows, :201-211
+        const float h1 = R1[i + 2];
+        R1[i] = R1[i] / h1;
+        R1[i + 1] = R1[i + 1] / h1;
+        R1[i + 2] = 1.f;
+        const float h2 = R2[i + 2];
+        R2[i] = R2[i] / h2;
+        R2[i + 1] = R2[i + 1] / h2;
+        R2[i + 2] = 1.f;
+    }
+    __syncthreads();
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const int32_t *ids = map_point_ids + (size_t)b * kp_stride;
+    const int2 *M = reinterpret_cast<const int2 *>(matches) + (size_t)b * kp_stride;
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    int32_t *O = out_idx + (size_t)b * kp_stride;
+    float *KE = kept_err + (size_t)b * kp_stride;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        bool keep = false;
+        float e = 0.f;
+        if (i < n && !(ids[i] > 0)) {   // indexed by the match index, :240
+            const int2 m = M[i];
+            const float2 a = P1[m.x], c = P2[m.y];
+            const float d1x = R1[(size_t)i * 3] - a.x, d1y = R1[(size_t)i * 3 + 1] - a.y;
+            const float re1 = (float)__builtin_fma((double)d1y, (double)d1y, (double)d1x * (double)d1x);
+            if (!(re1 > threshold_sq)) {
+                const float d2x = R2[(size_t)i * 3] - c.x, d2y = R2[(size_t)i * 3 + 1] - c.y;
+                const float re2 = (float)__builtin_fma((double)d2y, (double)d2y, (double)d2x * (double)d2x);
+                if (!(re2 > threshold_sq)) {
+                    keep = true;
+                    e = re1 + re2;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wave] = (int)__popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int wv = 0; wv < wave; wv++) off += s_wave[wv];
+        off += (int)__popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) {
+            O[off] = i;
+            KE[off] = e;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double err = 0;   // reproj_error += re1 + re2, in match order
+        for (int k = 0; k < s_base; k++) err += (double)KE[k];
+        out_n[b] = s_base;
+        out_err[b] = err;
+    }
+}
+
 }  // namespace
+
+int vs_launch_reproj_filter(vslam_ctx *ctx, const float *points4d, const float *xy1, const float *xy2, const int32_t *matches,
+                            const int32_t *best, int batch, int kp_stride, const float *h_K, const float *c2,
+                            const int32_t *map_point_ids, float threshold_sq, int32_t *out_idx, int32_t *out_n,
+                            double *out_err) {
+    VS_REQUIRE(ctx, points4d && xy1 && xy2 && matches && best && h_K && c2 && map_point_ids && out_idx && out_n && out_err,
+               VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
+    Mat3 K;
+    for (int i = 0; i < 9; i++) K.v[i] = h_K[i];
+    float *rp1 = nullptr, *rp2 = nullptr, *ke = nullptr;
+    int rc;
+    const size_t bk = (size_t)batch * kp_stride;
+    if ((rc = vs_arena_get(ctx, "pose.rp1", sizeof(float) * 3 * bk + 16, (void **)&rp1))) return rc;
+    if ((rc = vs_arena_get(ctx, "pose.rp2", sizeof(float) * 3 * bk + 16, (void **)&rp2))) return rc;
+    if ((rc = vs_arena_get(ctx, "pose.kept_err", sizeof(float) * bk, (void **)&ke))) return rc;
+    VsProfScope ps(ctx, "reproj_filter_kernel");
+    reproj_filter_kernel<<<batch, 256, 0, ctx->stream>>>(points4d, xy1, xy2, matches, best, kp_stride, K, c2, map_point_ids,
+                                                         threshold_sq, rp1, rp2, out_idx, out_n, out_err, ke);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
 
 int vs_launch_extract_Rt(vslam_ctx *ctx, const float *F, const int32_t *best, int batch, const float *h_K, float *R,
                          float *t, float *c2) {
