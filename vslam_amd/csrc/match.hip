@@ -21,16 +21,24 @@ constexpr int kThreads = 256;
 constexpr int kQueriesPerLane = 2;
 constexpr int kTile = 256;   // train rows per LDS tile (8 KiB)
 
+// v_bcnt_u32_b32 d, x, acc = popcount(x) + acc: the accumulate form keeps a 256-bit Hamming distance at
+// 8 xor + 8 bcnt (hipcc otherwise emits bare popcounts plus an add3 tree).  Plain asm (no memory, no
+// waits): a pure register instruction.
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 __device__ __forceinline__ uint32_t ham256(const uint4 &qa, const uint4 &qb, const uint4 &ta,
                                            const uint4 &tb) {
-    uint32_t d = __builtin_popcount(qa.x ^ ta.x);
-    d += __builtin_popcount(qa.y ^ ta.y);
-    d += __builtin_popcount(qa.z ^ ta.z);
-    d += __builtin_popcount(qa.w ^ ta.w);
-    d += __builtin_popcount(qb.x ^ tb.x);
-    d += __builtin_popcount(qb.y ^ tb.y);
-    d += __builtin_popcount(qb.z ^ tb.z);
-    d += __builtin_popcount(qb.w ^ tb.w);
+    uint32_t d = bcnt_acc(qa.x ^ ta.x, 0u);
+    d = bcnt_acc(qa.y ^ ta.y, d);
+    d = bcnt_acc(qa.z ^ ta.z, d);
+    d = bcnt_acc(qa.w ^ ta.w, d);
+    d = bcnt_acc(qb.x ^ tb.x, d);
+    d = bcnt_acc(qb.y ^ tb.y, d);
+    d = bcnt_acc(qb.z ^ tb.z, d);
+    d = bcnt_acc(qb.w ^ tb.w, d);
     return d;
 }
 
@@ -65,8 +73,24 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
         const int rows = min(kTile, nt - t0);
         for (int i = threadIdx.x; i < rows * 2; i += kThreads) tile[i] = t4[2 * t0 + i];
         __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < rows; j++) {
+        int j = 0;
+        for (; j + 4 <= rows; j += 4) {   // four train rows per trip: eight independent distance chains in flight
+            uint4 ta[4], tb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ta[u] = tile[2 * (j + u)];
+                tb[u] = tile[2 * (j + u) + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int s = 0; s < kQueriesPerLane; s++) {
+                    const uint32_t key = (ham256(qa[s], qb[s], ta[u], tb[u]) << 16) | (uint32_t)(t0 + j + u);
+                    k2[s] = min(k2[s], max(k1[s], key));
+                    k1[s] = min(k1[s], key);
+                }
+        }
+        for (; j < rows; j++) {
             const uint4 ta = tile[2 * j], tb = tile[2 * j + 1];
 #pragma unroll
             for (int s = 0; s < kQueriesPerLane; s++) {
