@@ -187,9 +187,8 @@ __global__ __launch_bounds__(kSetThreads) void ransac_sets_kernel(const uint32_t
 // ------------------------------------------------------------------------------------------
 // compute_fundamental: OpenCV JacobiSVDImpl_<float> on per-lane matrices held in LDS
 // ------------------------------------------------------------------------------------------
-constexpr int kSolveThreads = 128;
+constexpr int kSolveThreads = 64;
 constexpr int kSolveFloats = 81;    // 9 rows x 9 (row 8 is the FULL_UV null-space row)
-constexpr int kSolveDoubles = 8;
 
 __device__ __forceinline__ uint32_t cvrng_next(uint64_t &state) {   // cv::RNG (MWC)
     state = (uint64_t)(uint32_t)state * 4164903690ull + (uint32_t)(state >> 32);
@@ -199,26 +198,22 @@ __device__ __forceinline__ uint32_t cvrng_next(uint64_t &state) {   // cv::RNG (
 // Element (r,k) of this lane's matrix; lanes are interleaved so every ds access is conflict-free.
 #define VS_A(r, k) sA[((r) * M + (k)) * kSolveThreads + tid]
 #define VS_V(r, k) sV[((r) * N + (k)) * kSolveThreads + tid]
-#define VS_W(i) sW[(i) * kSolveThreads + tid]
 
 // JacobiSVDImpl_(At, astep, W, Vt, vstep, m = M, n = N, n1 = N1, FLT_MIN, FLT_EPSILON*2).
 // Rows 0..N-1 of A are orthogonalised; rows up to N1-1 are normalised / generated.
 // wout receives (float)W[i].
+// OpenCV keeps the squared row norms W[] between rotations; every W[i] it reads is the k-ordered double
+// sum of squares of the CURRENT row i (set so at start-up and after each rotation of that row), so the
+// norms are recomputed from the rows where needed instead of being stored: same bits, and the LDS
+// footprint per lane drops by 64 B, which is what bounds this kernel's occupancy.
 template <int M, int N, int N1, bool HASV>
-__device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, float *wout) {
+__device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout) {
     const double minval = FLT_MIN;
     const float eps = FLT_EPSILON * 2;
     constexpr int max_iter = M > 30 ? M : 30;
 
-    for (int i = 0; i < N; i++) {
-        double sd = 0;
-#pragma unroll
-        for (int k = 0; k < M; k++) {
-            const float t = VS_A(i, k);
-            sd = __builtin_fma((double)t, (double)t, sd);
-        }
-        VS_W(i) = sd;
-        if (HASV) {
+    if (HASV) {
+        for (int i = 0; i < N; i++) {
 #pragma unroll
             for (int k = 0; k < N; k++) VS_V(i, k) = (i == k) ? 1.f : 0.f;
         }
@@ -229,12 +224,15 @@ __device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, floa
         for (int i = 0; i < N - 1; i++)
             for (int j = i + 1; j < N; j++) {
                 float ai[M], aj[M];
-                double a = VS_W(i), p = 0, b = VS_W(j);
+                double a = 0, p = 0, b = 0;
 #pragma unroll
                 for (int k = 0; k < M; k++) {
                     ai[k] = VS_A(i, k);
                     aj[k] = VS_A(j, k);
-                    p = __builtin_fma((double)ai[k], (double)aj[k], p);
+                    const double di = (double)ai[k], dj = (double)aj[k];
+                    p = __builtin_fma(di, dj, p);
+                    a = __builtin_fma(di, di, a);   // W[i]
+                    b = __builtin_fma(dj, dj, b);   // W[j]
                 }
                 if (fabs(p) <= (double)eps * sqrt(a * b)) continue;
 
@@ -250,18 +248,13 @@ __device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, floa
                     c = (float)sqrt((gamma + beta) / (gamma * 2));
                     s = (float)(p / (gamma * (double)c * 2));
                 }
-                a = b = 0;
 #pragma unroll
                 for (int k = 0; k < M; k++) {
                     const float t0 = c * ai[k] + s * aj[k];
                     const float t1 = (-s) * ai[k] + c * aj[k];
                     VS_A(i, k) = t0;
                     VS_A(j, k) = t1;
-                    a = __builtin_fma((double)t0, (double)t0, a);
-                    b = __builtin_fma((double)t1, (double)t1, b);
                 }
-                VS_W(i) = a;
-                VS_W(j) = b;
                 changed = true;
                 if (HASV) {
 #pragma unroll
@@ -277,6 +270,8 @@ __device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, floa
         if (!changed) break;
     }
 
+    double W[N];   // singular values: registers, every index below is compile-time
+#pragma unroll
     for (int i = 0; i < N; i++) {
         double sd = 0;
 #pragma unroll
@@ -284,17 +279,24 @@ __device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, floa
             const float t = VS_A(i, k);
             sd = __builtin_fma((double)t, (double)t, sd);
         }
-        VS_W(i) = sqrt(sd);
+        W[i] = sqrt(sd);
     }
 
+#pragma unroll
     for (int i = 0; i < N - 1; i++) {   // selection sort, descending, rows travel with W
         int j = i;
+        double wj = W[i];
+#pragma unroll
         for (int k = i + 1; k < N; k++)
-            if (VS_W(j) < VS_W(k)) j = k;
+            if (wj < W[k]) {
+                j = k;
+                wj = W[k];
+            }
         if (i != j) {
-            const double wi = VS_W(i), wj = VS_W(j);
-            VS_W(i) = wj;
-            VS_W(j) = wi;
+#pragma unroll
+            for (int jj = i + 1; jj < N; jj++)
+                if (jj == j) W[jj] = W[i];
+            W[i] = wj;
 #pragma unroll
             for (int k = 0; k < M; k++) {
                 const float x = VS_A(i, k), y = VS_A(j, k);
@@ -313,11 +315,19 @@ __device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, floa
     }
 
 #pragma unroll
-    for (int i = 0; i < N; i++) wout[i] = (float)VS_W(i);
+    for (int i = 0; i < N; i++) wout[i] = (float)W[i];
 
     uint64_t rng = 0x12345678ull;
     for (int i = 0; i < N1; i++) {
-        double sd = i < N ? VS_W(i) : 0;
+        double sd = 0;
+        if (i < N) {   // W[i] again: the sorted row's norm
+#pragma unroll
+            for (int k = 0; k < M; k++) {
+                const float t = VS_A(i, k);
+                sd = __builtin_fma((double)t, (double)t, sd);
+            }
+            sd = sqrt(sd);
+        }
         for (int ii = 0; ii < 100 && sd <= minval; ii++) {
             const float val0 = (float)(1. / M);
 #pragma unroll
@@ -358,7 +368,7 @@ __device__ void jacobi_svd_lanes(float *sA, double *sW, float *sV, int tid, floa
     }
 }
 
-// One lane per hypothesis.  grid = (ceil(hyp / 128), batch).
+// One lane per hypothesis, one wave per workgroup.  grid = (ceil(hyp / 64), batch).
 __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, const int32_t *__restrict__ sets, int kp_stride, int hyp,
@@ -368,7 +378,6 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
     if (m_arr[b] < VSLAM_SET_SIZE) return;   // uniform per workgroup
 
     __shared__ float sA[kSolveFloats * kSolveThreads];
-    __shared__ double sW[kSolveDoubles * kSolveThreads];
 
     const bool live = h < hyp;
     const int hc = live ? h : hyp - 1;   // idle lanes redo the last hypothesis; no divergence in barriers
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
     }
 
     float w8[8];
-    jacobi_svd_lanes<9, 8, 9, false>(sA, sW, nullptr, tid, w8);   // SVDecomp(A 8x9), :94
+    jacobi_svd_lanes<9, 8, 9, false>(sA, nullptr, tid, w8);   // SVDecomp(A 8x9), :94
 
     float f0[9];
     {
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
             for (int k = 0; k < 3; k++) VS_A(i, k) = f0[3 * k + i];
     }
     float d3[3];
-    jacobi_svd_lanes<3, 3, 3, true>(sA, sW, sV, tid, d3);
+    jacobi_svd_lanes<3, 3, 3, true>(sA, sV, tid, d3);
     d3[2] = 0.f;   // :99
 
     float U[9], Vt[9];
@@ -454,7 +463,6 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
 }
 #undef VS_A
 #undef VS_V
-#undef VS_W
 
 // ------------------------------------------------------------------------------------------
 // compute_fundamental_residual
