@@ -64,7 +64,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/, C3 batch of 256 pairs);
     bench.py cannot collect PMC counters on itself."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic_tuned.csv")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic_final.csv")
     if not os.path.exists(path):
         return None
     with open(path) as f:
