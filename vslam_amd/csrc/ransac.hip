@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kSetThreads) void ransac_sets_kernel(const uint32_t
 // compute_fundamental: OpenCV JacobiSVDImpl_<float> on per-lane matrices held in LDS
 // ------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 64;
-constexpr int kSolveFloats = 81;    // 9 rows x 9 (row 8 is the FULL_UV null-space row)
+constexpr int kSolveFloats = 72;    // 8 rows x 9 (the FULL_UV null-space row stays in registers)
 
 __device__ __forceinline__ uint32_t cvrng_next(uint64_t &state) {   // cv::RNG (MWC)
     state = (uint64_t)(uint32_t)state * 4164903690ull + (uint32_t)(state >> 32);
@@ -207,7 +207,8 @@ __device__ __forceinline__ uint32_t cvrng_next(uint64_t &state) {   // cv::RNG (
 // norms are recomputed from the rows where needed instead of being stored: same bits, and the LDS
 // footprint per lane drops by 64 B, which is what bounds this kernel's occupancy.
 template <int M, int N, int N1, bool HASV>
-__device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout) {
+__device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, float *extra_row) {
+    static_assert(N1 == N || N1 == N + 1, "FULL_UV asks for at most one row beyond the rank here");
     const double minval = FLT_MIN;
     const float eps = FLT_EPSILON * 2;
     constexpr int max_iter = M > 30 ? M : 30;
@@ -318,16 +319,14 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout) {
     for (int i = 0; i < N; i++) wout[i] = (float)W[i];
 
     uint64_t rng = 0x12345678ull;
-    for (int i = 0; i < N1; i++) {
-        double sd = 0;
-        if (i < N) {   // W[i] again: the sorted row's norm
+    for (int i = 0; i < N; i++) {
+        double sd = 0;   // W[i] again: the sorted row's norm
 #pragma unroll
-            for (int k = 0; k < M; k++) {
-                const float t = VS_A(i, k);
-                sd = __builtin_fma((double)t, (double)t, sd);
-            }
-            sd = sqrt(sd);
+        for (int k = 0; k < M; k++) {
+            const float t = VS_A(i, k);
+            sd = __builtin_fma((double)t, (double)t, sd);
         }
+        sd = sqrt(sd);
         for (int ii = 0; ii < 100 && sd <= minval; ii++) {
             const float val0 = (float)(1. / M);
 #pragma unroll
@@ -366,6 +365,45 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout) {
 #pragma unroll
         for (int k = 0; k < M; k++) VS_A(i, k) = VS_A(i, k) * s;
     }
+    if (N1 > N) {
+        // the row beyond the rank (FULL_UV): same procedure with i = N, W = 0; it lives in registers,
+        // which keeps the per-lane LDS footprint at N rows
+        float v[M];
+        double sd = 0;
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const float val0 = (float)(1. / M);
+#pragma unroll
+            for (int k = 0; k < M; k++) v[k] = (cvrng_next(rng) & 256) != 0 ? val0 : -val0;
+            for (int iter = 0; iter < 2; iter++) {
+                for (int j = 0; j < N; j++) {
+                    float vj[M];
+                    sd = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        vj[k] = VS_A(j, k);
+                        sd += (double)(v[k] * vj[k]);
+                    }
+                    float asum = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        const float t = (float)((double)v[k] - sd * (double)vj[k]);
+                        v[k] = t;
+                        asum += fabsf(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) v[k] = v[k] * asum;
+                }
+            }
+            sd = 0;
+#pragma unroll
+            for (int k = 0; k < M; k++) sd = __builtin_fma((double)v[k], (double)v[k], sd);
+            sd = sqrt(sd);
+        }
+        const float s = (float)(sd > minval ? 1 / sd : 0.);
+#pragma unroll
+        for (int k = 0; k < M; k++) extra_row[k] = v[k] * s;
+    }
 }
 
 // One lane per hypothesis, one wave per workgroup.  grid = (ceil(hyp / 64), batch).
@@ -403,19 +441,10 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
             VS_A(r, 7) = v1;
             VS_A(r, 8) = 1.f;
         }
-#pragma unroll
-        for (int k = 0; k < 9; k++) VS_A(8, k) = 0.f;   // temp_u = Scalar::all(0) for the extra row
     }
 
-    float w8[8];
-    jacobi_svd_lanes<9, 8, 9, false>(sA, nullptr, tid, w8);   // SVDecomp(A 8x9), :94
-
-    float f0[9];
-    {
-        constexpr int M = 9;
-#pragma unroll
-        for (int k = 0; k < 9; k++) f0[k] = VS_A(8, k);   // V_t.row(8), :95
-    }
+    float w8[8], f0[9];
+    jacobi_svd_lanes<9, 8, 9, false>(sA, nullptr, tid, w8, f0);   // SVDecomp(A 8x9), :94; f0 = V_t.row(8), :95
 
     // second SVD on the 3x3 (:98): working rows are the COLUMNS of F0 (m == n -> transpose)
     float *sV = sA + 9 * kSolveThreads;
@@ -427,7 +456,7 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
             for (int k = 0; k < 3; k++) VS_A(i, k) = f0[3 * k + i];
     }
     float d3[3];
-    jacobi_svd_lanes<3, 3, 3, true>(sA, sV, tid, d3);
+    jacobi_svd_lanes<3, 3, 3, true>(sA, sV, tid, d3, nullptr);
     d3[2] = 0.f;   // :99
 
     float U[9], Vt[9];
