@@ -511,12 +511,11 @@ __device__ __forceinline__ void residual_prepare(ResidualF &R) {
     R.ft[4] = (double)R.f[4];
     R.ft[5] = (double)R.f[7];
 }
-__device__ __forceinline__ float residual_e(const ResidualF &R, const float4 c) {
+__device__ __forceinline__ float residual_e(const ResidualF &R, const float4 c, const double dx2, const double dy2) {
     const float x1 = c.x, y1 = c.y, x2 = c.z, y2 = c.w;
     const float a0 = R.f[0] * x1 + R.f[1] * y1 + R.f[2];
     const float a1 = R.f[3] * x1 + R.f[4] * y1 + R.f[5];
     const float a2 = R.f[6] * x1 + R.f[7] * y1 + R.f[8];
-    const double dx2 = (double)x2, dy2 = (double)y2;
     // products of two floats are exact in double: fma(a,b,c) == a*b + c rounded once
     const float t0 = (float)(__builtin_fma(R.ft[1], dy2, R.ft[0] * dx2) + R.ft[2]);
     const float t1 = (float)(__builtin_fma(R.ft[4], dy2, R.ft[3] * dx2) + R.ft[5]);
@@ -526,7 +525,7 @@ __device__ __forceinline__ float residual_e(const ResidualF &R, const float4 c) 
 }
 
 constexpr int kScoreThreads = 256;
-constexpr int kScoreTile = 2048;   // correspondences per LDS tile (32 KiB)
+constexpr int kScoreTile = 1024;   // correspondences per LDS tile (16 B floats + 16 B doubles each: 32 KiB)
 
 // One lane per hypothesis; correspondences gathered once per workgroup into LDS as float4
 // (x1,y1,x2,y2) and read back as wave-uniform broadcasts.  grid = (ceil(hyp/256), batch).
@@ -540,6 +539,7 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
     if (m < VSLAM_SET_SIZE) return;
 
     __shared__ float4 corr[kScoreTile];
+    __shared__ double2 corrd[kScoreTile];   // (double)x2, (double)y2: converted once per match, not once per hypothesis
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
     const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
     const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
@@ -560,11 +560,13 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
             const int2 pr = PR[base + i];
             const float2 a = P1[pr.x], c = P2[pr.y];
             corr[i] = make_float4(a.x, a.y, c.x, c.y);
+            corrd[i] = make_double2((double)c.x, (double)c.y);
         }
         __syncthreads();
 #pragma unroll 4
         for (int i = 0; i < rows; i++) {
-            const float e = residual_e(R, corr[i]);
+            const double2 d2 = corrd[i];
+            const float e = residual_e(R, corr[i], d2.x, d2.y);
             count += (e <= threshold) ? 1 : 0;   // NaN <= thr is false, :130
             total += (double)e;                  // cv::sum in index order, :138
         }
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
             pr = PR[i];
             if (winner >= 0) {
                 const float2 a = P1[pr.x], c = P2[pr.y];
-                in = residual_e(R, make_float4(a.x, a.y, c.x, c.y)) <= threshold;
+                in = residual_e(R, make_float4(a.x, a.y, c.x, c.y), (double)c.x, (double)c.y) <= threshold;
             }
             MK[i] = in ? 1 : 0;
         }
