@@ -38,6 +38,7 @@ struct vslam_ctx {
         size_t bytes = 0;
     };
     std::map<std::string, Buf> arena;
+    std::map<std::string, bool> attr_done;   // hipFuncSetAttribute is per device: remembered per context
 
     bool prof = false;
     std::vector<vslam_prof_slot> prof_slots;

@@ -1116,11 +1116,10 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         while (sort_cap < max_corners) sort_cap <<= 1;   // at least max_corners slots
         const size_t lds = sizeof(unsigned long long) * (size_t)sort_cap;
         VS_REQUIRE(ctx, lds <= 128 * 1024, VSLAM_ERR_CAPACITY);
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!ctx->attr_done["corner_select"]) {
             VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corner_select_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set = true;
+            ctx->attr_done["corner_select"] = true;
         }
         const float md = (float)min_distance;
         const float md2 = (float)(min_distance * min_distance);   // `minDistance *= minDistance` in double, compared as float

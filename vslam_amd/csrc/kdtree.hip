@@ -234,11 +234,10 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
     const size_t lds = (size_t)kp_stride * 20 + 8;
     VS_REQUIRE(ctx, lds <= 160 * 1024 - 512, VSLAM_ERR_CAPACITY);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->attr_done["kdtree_build"]) {
         VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kdtree_build_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-        attr_set = true;
+        ctx->attr_done["kdtree_build"] = true;
     }
     VsProfScope ps(ctx, "kdtree_build_kernel");
     kdtree_build_kernel<<<batch, kBuildThreads, lds, ctx->stream>>>(xy, n, kp_stride, nodes);
