@@ -1,0 +1,47 @@
+"""The C ABI fails loudly and specifically: bad arguments, capacity limits, undefined-in-the-reference inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from vslam_amd import VslamError, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_null_and_range_arguments_are_rejected(ctx):
+    lib, h = ctx.lib, ctx.handle
+    z = C.c_void_p(0)
+    assert lib.vslam_match_knn2_ratio(h, z, z, z, z, 1, 16, z, z, z) == -1          # VSLAM_ERR_INVALID
+    assert lib.vslam_kdtree_build(h, z, z, 1, 16, z) == -1
+    assert lib.vslam_ransac_sets(h, z, z, 1, 16, z, z) == -1
+    assert lib.vslam_match_knn2_ratio(C.c_void_p(0), z, z, z, z, 1, 16, z, z, z) == -1   # null context
+    assert b"requirement failed" in lib.vslam_last_error(h)
+    d = torch.zeros((1, 20000, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    with pytest.raises(VslamError, match="CAPACITY"):                                # > VSLAM_MAX_KP slots
+        ctx.match_knn2_ratio(d, n, d, n)
+
+
+def test_undefined_reference_inputs_are_defined_here(ctx):
+    """< 2 train rows (src/Frame.cpp:91 reads m[1]) and < 8 matches (src/RansacFilter.cpp:24) are UB in the
+    reference; here they produce 'no matches' / 'no model' without touching the outputs."""
+    K = 64
+    d1, d2, _ = synth.descriptors_pair(1, K, K)
+    t = lambda a: torch.from_numpy(a).cuda()
+    n1 = torch.tensor([K], dtype=torch.int32).cuda()
+    pairs, m = ctx.match_knn2_ratio(t(d1[None]), n1, t(d2[None]), torch.tensor([1], dtype=torch.int32).cuda())
+    assert int(m[0]) == 0
+    xy = torch.rand((1, K, 2), device="cuda") * 100
+    seeds = torch.tensor([5], dtype=torch.int32).cuda()
+    F0 = torch.full((1, 9), 7.0, device="cuda")
+    out = dict(matches=torch.zeros((1, K, 2), dtype=torch.int32, device="cuda"), best=torch.zeros((1, 4), dtype=torch.int32, device="cuda"),
+               F=F0.clone(), prelim_m=torch.zeros((1,), dtype=torch.int32, device="cuda"))
+    # random descriptors against each other: (almost) nothing survives the ratio test -> fewer than 8 matches
+    r1 = torch.randint(0, 256, (1, K, 32), dtype=torch.uint8, device="cuda")
+    r2 = torch.randint(0, 256, (1, K, 32), dtype=torch.uint8, device="cuda")
+    ctx.match_features(xy, r1, n1, xy, r2, n1, seeds, 32, 10.0, out=out)
+    ctx.synchronize()
+    assert int(out["prelim_m"][0]) < 8
+    assert out["best"][0].tolist() == [-1, 0, 0, 0] and torch.equal(out["F"], F0)     # `fundamental` left untouched
