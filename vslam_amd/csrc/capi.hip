@@ -1,6 +1,7 @@
 // C ABI (include/vslam_amd.h): context, memory, event timing, and the entry points that chain
 // the stage launchers.  No CPU fallback anywhere: every entry point needs a live HIP device.
 #include "ctx.h"
+#include <cstdlib>
 
 #include <cstring>
 
@@ -129,6 +130,7 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
+    if (const char *e = getenv("VSLAM_OVERLAP_BLUR")) ctx->overlap_blur = e[0] - '0';
     *out = ctx;
     return VSLAM_OK;
 }
@@ -364,10 +366,29 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     else if ((rc = vs_arena_get(ctx, "extract.n_det", sizeof(int32_t) * (size_t)frames, (void **)&n_det))) return rc;
 
     if ((rc = vs_launch_bgr2gray(ctx, d_bgr, frames, width, height, row_stride, gray))) return rc;      // :56
-    if ((rc = vs_launch_good_features(ctx, gray, frames, width, height, params->max_corners,             // :61
-                                      params->quality, params->min_distance, kp_stride, xy_det, n_det)))
-        return rc;
-    if ((rc = vs_launch_gaussian7(ctx, gray, frames, width, height, blur))) return rc;                   // ORB::compute
+    // The blur needs only the gray image: run it on the auxiliary stream beside corner detection, whose
+    // selection stage is latency-bound and leaves most of the chip idle (not while per-kernel timing is on).
+    const bool overlap = ctx->overlap_blur > 0 && !ctx->prof;
+    if (overlap && ctx->overlap_blur == 1) {
+        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    }
+    ctx->fork_after_eigen = overlap && ctx->overlap_blur == 2;
+    rc = vs_launch_good_features(ctx, gray, frames, width, height, params->max_corners,                  // :61
+                                 params->quality, params->min_distance, kp_stride, xy_det, n_det);
+    ctx->fork_after_eigen = false;
+    if (rc) return rc;
+    {
+        hipStream_t main_stream = ctx->stream;
+        if (overlap) ctx->stream = ctx->aux_stream;
+        rc = vs_launch_gaussian7(ctx, gray, frames, width, height, blur);                                // ORB::compute
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        if (overlap) {
+            VS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+            VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+    }
     if ((rc = vs_launch_orb_describe(ctx, blur, frames, width, height, xy_det, n_det, kp_stride,         // :68-72
                                      params->cos_a, params->sin_a, params->d_pattern, d_xy, d_desc, d_n)))
         return rc;

@@ -15,6 +15,7 @@
 // All of these are streaming stencils over 8-bit / 32-bit images: HBM-bound by design, so each
 // kernel reads its input tile once into LDS with coalesced loads and writes each output once.
 #include "ctx.h"
+#include <cstdlib>
 
 namespace {
 
@@ -175,6 +176,39 @@ __global__ __launch_bounds__(kET) void min_eigen_kernel(const uint8_t *__restric
 // rounding, so flipping the sign of the xy product of mirrored rows/columns is bit-exact.
 constexpr int kE4W = 256, kE4H = 32, kE4C = kE4W / 4 + 2;
 
+// v_max3_f32 on values that are never NaN: fmaxf() would first canonicalise every operand (one extra
+// v_max_f32 each).  Pure register instruction.
+__device__ __forceinline__ float max3_nonan(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// Correctly rounded sqrt of four non-negative finite floats.  Fast path: v_sqrt_f32 (1 ulp) plus the
+// two-sided fma residual test; valid for 0 and for inputs >= 2^-96 (v_sqrt_f32 flushes denormal inputs, which
+// is why the general sequence rescales).  If any lane of the wave holds a smaller non-zero input the whole
+// wave takes sqrtf().  Both paths return the IEEE result, so which one runs never shows in the output.
+__device__ __forceinline__ float sqrt_rn_fast1(float t) {
+    const float r = __builtin_amdgcn_sqrtf(t);
+    const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
+    const float e_dn = __builtin_fmaf(-r_dn, r, t), e_up = __builtin_fmaf(-r_up, r, t);
+    float o = e_dn <= 0.f ? r_dn : r;   // t == 0: r_dn is NaN, the comparison is false
+    o = e_up > 0.f ? r_up : o;
+    return o;
+}
+__device__ __forceinline__ void sqrt_rn4(const float t[4], float out[4]) {
+    // bits - 1 < 0x0F800000 - 1  <=>  0 < t < 2^-96  (t >= 0, so the bit pattern orders like the value)
+    const uint32_t a = __float_as_uint(t[0]) - 1u, b = __float_as_uint(t[1]) - 1u, c = __float_as_uint(t[2]) - 1u,
+                   d = __float_as_uint(t[3]) - 1u;
+    const uint32_t lo = min(min(a, b), min(c, d));
+    if (__builtin_expect(__any(lo < 0x0F800000u - 1u), 0)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = sqrtf(t[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = sqrt_rn_fast1(t[i]);
+    }
+}
+
 // FUSED = false: plain cornerMinEigenVal (tile owns all 256x32 pixels it computes).
 // FUSED = true : the same strip computation, but tiles overlap by one lane / one row on every side
 //   (owned region 248x30), the responses also go to an LDS tile, and after one barrier every owned
@@ -188,7 +222,6 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__restrict__ gray, int w, int h,
                                                            float *__restrict__ eig,
                                                            uint32_t *__restrict__ frame_max, double quality,
-                                                           uint8_t *__restrict__ state,
                                                            unsigned long long *__restrict__ keys,
                                                            uint32_t *__restrict__ counts, size_t key_cap) {
     __shared__ uint32_t G[kE4H + 4][kE4C];   // bytes x0-4 .. x0+259 of raw rows y0-2 .. y0+33
@@ -278,6 +311,7 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
                     const int y = y0 + lr;
                     float e4[4] = {ninf, ninf, ninf, ninf};
                     if (y >= 0 && y < h) {
+                        float apc[4], tt[4], rt[4];
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const float sxx = (float)(pair[i] + cur[i]);
@@ -285,12 +319,15 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
                             const float syy = (float)(pair[8 + i] + cur[8 + i]);
                             const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
                             const float amc = a - c;
-                            const float tt = amc * amc + b * b;
-                            e4[i] = (a + c) - sqrtf(tt);
+                            tt[i] = amc * amc + b * b;
+                            apc[i] = a + c;
                         }
+                        sqrt_rn4(tt, rt);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) e4[i] = apc[i] - rt[i];
                         const bool own = own_lane && (!FUSED || (lr >= 1 && lr <= kE4H - 2));
                         if (own) {
-                            emax = fmaxf(emax, fmaxf(fmaxf(e4[0], e4[1]), fmaxf(e4[2], e4[3])));
+                            emax = max3_nonan(max3_nonan(e4[0], e4[1], e4[2]), e4[3], emax);
                             *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
                         }
                     }
@@ -328,37 +365,33 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
     const float thr_p = (float)((double)ord2f(run_max) * quality);
     uint32_t cmask = 0;   // bit (8 rows x 4 pixels) set where this lane found a candidate
     if (own_lane && x >= 0 && x < w) {
-        float win[3][6];   // rolling rows, columns x-1 .. x+4: one b128 + two b32 LDS reads per row
+        // rolling rows: the centre values (columns x .. x+3) and the horizontal 3-maxima around them; the
+        // 3x3 maximum (centre included) is then one more max3 down the three rows.  No NaNs in ET.
+        float ctr[3][4], hm[3][4];
 #pragma unroll
         for (int k = 0; k < 10; k++) {
             const int lr = grp * 8 + k - 1;   // tile row being loaded (0 .. 31 where it exists)
-            float *dst = win[k % 3];
             if (lr >= 0 && lr < kE4H) {
                 const float4 c4 = *reinterpret_cast<const float4 *>(&ET[lr][4 * lane + 4]);
-                dst[0] = ET[lr][4 * lane + 3];
-                dst[1] = c4.x; dst[2] = c4.y; dst[3] = c4.z; dst[4] = c4.w;
-                dst[5] = ET[lr][4 * lane + 8];
+                const float lf = ET[lr][4 * lane + 3], rg = ET[lr][4 * lane + 8];
+                ctr[k % 3][0] = c4.x; ctr[k % 3][1] = c4.y; ctr[k % 3][2] = c4.z; ctr[k % 3][3] = c4.w;
+                hm[k % 3][0] = max3_nonan(lf, c4.x, c4.y);
+                hm[k % 3][1] = max3_nonan(c4.x, c4.y, c4.z);
+                hm[k % 3][2] = max3_nonan(c4.y, c4.z, c4.w);
+                hm[k % 3][3] = max3_nonan(c4.z, c4.w, rg);
             }
             if (k >= 2) {
                 const int tr = lr - 1;   // row under test
                 const int y = y0 + tr;
                 if (tr >= 1 && tr <= kE4H - 2 && y >= 0 && y < h) {
-                    const float *up = win[(k - 2) % 3], *mid = win[(k - 1) % 3], *dn = win[k % 3];
-                    uint32_t st = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const float v = mid[i + 1];
-                        // no NaNs here, so fmaxf (v_max3_f32) is the plain maximum of the 8 neighbours
-                        const float m = fmaxf(fmaxf(fmaxf(up[i], up[i + 1]), fmaxf(up[i + 2], mid[i])),
-                                              fmaxf(fmaxf(mid[i + 2], dn[i]), fmaxf(dn[i + 1], dn[i + 2])));
+                        const float v = ctr[(k - 1) % 3][i];
+                        const float m = max3_nonan(hm[(k - 2) % 3][i], hm[(k - 1) % 3][i], hm[k % 3][i]);
                         const int xx = x + i;
                         const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v > thr_p && !(m > v);
-                        if (cand) {
-                            st |= 1u << (8 * i);
-                            cmask |= 1u << (4 * (k - 2) + i);
-                        }
+                        if (cand) cmask |= 1u << (4 * (k - 2) + i);
                     }
-                    *reinterpret_cast<uint32_t *>(state + ((size_t)f * h + y) * w + x) = st;
                 }
             }
         }
@@ -388,14 +421,13 @@ __global__ void negative_max_reset_kernel(const uint32_t *__restrict__ frame_max
 }
 
 // ------------------------------------------------------------------------------------------
-// threshold + 3x3 local maximum -> candidate keys and a per-pixel state map
+// threshold + 3x3 local maximum -> candidate keys (response << 32 | pixel offset)
 // ------------------------------------------------------------------------------------------
-// state: 0 none, 1 candidate (undecided), 2 accepted, 3 rejected
 constexpr int kCT = 256, kCTW = 64, kCTH = 16;
 
 __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
     const float *__restrict__ eig, int w, int h, const uint32_t *__restrict__ frame_max, double quality,
-    uint8_t *__restrict__ state, unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
+    unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
     size_t key_cap) {
     __shared__ float E[kCTH + 2][kCTW + 2];
     __shared__ uint32_t s_cnt, s_base;
@@ -437,7 +469,6 @@ __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
                     }
                 cand = (m == v);   // val == dilate(val) on the thresholded image
             }
-            state[((size_t)f * h + y) * w + x] = cand ? 1 : 0;
             if (cand) mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + x);
         }
     }
@@ -453,12 +484,12 @@ __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
 }
 
 // Vectorised form (width % 4 == 0): 256x16 tile, one lane = 4 adjacent pixels x 4 rows, response
-// rows staged in LDS with float4 loads, state written as one dword per lane and row.
+// rows staged in LDS with float4 loads.
 constexpr int kC4W = 256, kC4H = 16, kC4C = kC4W + 8;
 
 __global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
     const float *__restrict__ eig, int w, int h, const uint32_t *__restrict__ frame_max, double quality,
-    uint8_t *__restrict__ state, unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
+    unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
     size_t key_cap, int only_negative_max) {
     __shared__ __align__(16) float E[kC4H + 2][kC4C];   // columns x0-4 .. x0+259
     __shared__ uint32_t s_cnt, s_base;
@@ -501,7 +532,6 @@ __global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
                 const int y = y0 + grp * 4 + (k - 2);
                 if (y < h) {
                     const float *up = win[(k - 2) % 3], *mid = win[(k - 1) % 3], *dn = win[k % 3];
-                    uint32_t st = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const float v = mid[i + 1];
@@ -510,12 +540,8 @@ __global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
                                               fmaxf(fmaxf(mid[i + 2], dn[i]), fmaxf(dn[i + 1], dn[i + 2])));
                         const int xx = x + i;
                         const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v != 0.f && !(m > v);
-                        if (cand) {
-                            st |= 1u << (8 * i);
-                            mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + xx);
-                        }
+                        if (cand) mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + xx);
                     }
-                    *reinterpret_cast<uint32_t *>(state + ((size_t)f * h + y) * w + x) = st;
                 }
             }
         }
@@ -548,7 +574,7 @@ constexpr int kST = 1024;
 struct SelectShared {
     uint32_t wave_cnt[kST / 64];
     uint32_t hist[256];
-    uint32_t flag, fill, need;
+    uint32_t flag, fill, need, d_star, above;
     unsigned long long prefix;
 };
 
@@ -621,7 +647,7 @@ __device__ unsigned long long radix_select_nth(const unsigned long long *K, uint
     return prefix;
 }
 
-__device__ void bitonic_sort_desc(unsigned long long *buf, int cap) {
+__device__ void bitonic_sort_desc_lds(unsigned long long *buf, int cap) {
     const int tid = threadIdx.x;
     for (int k = 2; k <= cap; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -638,6 +664,79 @@ __device__ void bitonic_sort_desc(unsigned long long *buf, int cap) {
             }
             __syncthreads();
         }
+}
+
+// The same network for cap = EPT * kST keys with EPT consecutive keys per thread held in registers:
+// strides below EPT are compare-exchanges inside a thread, strides below 64 * EPT are wave shuffles, and
+// only the strides that cross waves (10 of the 78 stages at cap = 4096) go through LDS and barriers.
+template <int EPT>
+__device__ void bitonic_sort_desc_regs(unsigned long long *buf) {
+    const int tid = threadIdx.x;
+    constexpr int cap = EPT * kST;
+    unsigned long long v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) v[e] = buf[EPT * tid + e];
+    for (int k = 2; k <= cap; k <<= 1) {
+        int j = k >> 1;
+        for (; j >= 64 * EPT; j >>= 1) {   // partner in another wave
+            const int tj = j / EPT;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EPT; e++) buf[EPT * tid + e] = v[e];
+            __syncthreads();
+            const bool lower = (tid & tj) == 0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const unsigned long long p = buf[EPT * (tid ^ tj) + e];
+                const bool desc = ((EPT * tid + e) & k) == 0;
+                const bool keep_max = desc == lower;
+                v[e] = keep_max ? (v[e] > p ? v[e] : p) : (v[e] < p ? v[e] : p);
+            }
+        }
+        for (; j >= EPT; j >>= 1) {   // partner in another lane of this wave
+            const int tj = j / EPT;
+            const bool lower = (tid & tj) == 0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const unsigned long long p = __shfl_xor(v[e], tj, 64);
+                const bool desc = ((EPT * tid + e) & k) == 0;
+                const bool keep_max = desc == lower;
+                v[e] = keep_max ? (v[e] > p ? v[e] : p) : (v[e] < p ? v[e] : p);
+            }
+        }
+#pragma unroll
+        for (int jj = EPT / 2; jj > 0; jj >>= 1) {   // partner in this thread
+            if (jj < k) {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    if ((e & jj) == 0) {
+                        const bool desc = ((EPT * tid + e) & k) == 0;
+                        const unsigned long long a = v[e], b = v[e | jj];
+                        const bool swap = desc ? (a < b) : (a > b);
+                        v[e] = swap ? b : a;
+                        v[e | jj] = swap ? a : b;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; e++) buf[EPT * tid + e] = v[e];
+    __syncthreads();
+}
+
+// buf[0 .. cap) sorted descending, cap a power of two; every thread of the workgroup calls it
+__device__ void bitonic_sort_desc(unsigned long long *buf, int cap) {
+    __syncthreads();
+    switch (cap / kST) {
+        case 1: bitonic_sort_desc_regs<1>(buf); break;
+        case 2: bitonic_sort_desc_regs<2>(buf); break;
+        case 4: bitonic_sort_desc_regs<4>(buf); break;
+        case 8: bitonic_sort_desc_regs<8>(buf); break;
+        case 16: bitonic_sort_desc_regs<16>(buf); break;
+        default: bitonic_sort_desc_lds(buf, cap); break;   // cap < kST
+    }
 }
 
 // Gather the keys >= T into LDS (unordered) and sort them descending; returns how many.
@@ -660,6 +759,202 @@ __device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsig
     return sh.fill < (uint32_t)sort_cap ? sh.fill : (uint32_t)sort_cap;
 }
 
+// ---- rank window in two passes over the candidate list ---------------------------------------
+// Every kept key has thr < response <= max, both known, so the ordered responses share the top
+// L = clz(ord(thr) ^ ord(max)) bits; the next log2(bins) bits form a monotone digit.  Pass 1 histograms the
+// digits of the kept keys (the histogram borrows the sort buffer), a suffix scan finds the digit d* in
+// whose bin the N-th best key lies, pass 2 gathers every kept key with digit >= d* into the sort buffer,
+// which is then sorted: its first N entries are the N best-ranked candidates.  Returns false when the
+// gathered set would not fit the buffer (heavy ties); the caller then uses the generic radix select.
+// n_kept receives the number of keys above the threshold, N_io is clamped to it.
+__device__ bool rank_window_2pass(const unsigned long long *K, uint32_t n, unsigned long long tkey, uint32_t t32,
+                                  uint32_t m32, uint32_t &N_io, unsigned long long *sortbuf, int sort_cap,
+                                  SelectShared &sh, uint32_t &n_kept) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(sortbuf);
+    const int bins = 2 * sort_cap < 4096 ? 2 * sort_cap : 4096;
+    const int db = 31 - __clz(bins);
+    const int L = (t32 ^ m32) ? __clz(t32 ^ m32) : 32;
+    const int shift = 32 - L - db > 0 ? 32 - L - db : 0;
+    const uint32_t dmask = (uint32_t)bins - 1u;
+    __syncthreads();
+    for (int i = tid; i < bins; i += kST) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 4 * kST) {   // four independent loads in flight per thread
+        unsigned long long key[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * kST + tid;
+            key[u] = i < n ? K[i] : 0ull;   // 0 never passes the threshold test
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (key[u] > tkey) atomicAdd(&hist[((uint32_t)(key[u] >> 32) >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    // suffix scan: thread t owns `per` consecutive bins; above = keys in bins owned by higher threads
+    const int per = bins > kST ? bins / kST : 1;
+    const int lo = tid * per;
+    uint32_t own = 0;
+    if (lo < bins)
+        for (int b = 0; b < per; b++) own += hist[lo + b];
+    uint32_t incl = own;   // becomes the sum over lanes >= lane of this wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_down(incl, off, 64);
+        if (lane + off < 64) incl += o;
+    }
+    if (lane == 0) sh.wave_cnt[wave] = incl;
+    __syncthreads();
+    uint32_t higher = 0, total = 0;
+    for (int wv = 0; wv < kST / 64; wv++) {
+        const uint32_t c = sh.wave_cnt[wv];
+        if (wv > wave) higher += c;
+        total += c;
+    }
+    n_kept = total;
+    uint32_t N = N_io;
+    if (N > total) N = total;
+    if (N > (uint32_t)sort_cap) N = (uint32_t)sort_cap;
+    N_io = N;
+    if (N == 0) {
+        __syncthreads();
+        return true;
+    }
+    uint32_t run = higher + incl - own;
+    if (lo < bins)
+        for (int b = per - 1; b >= 0; b--) {
+            const uint32_t mine = hist[lo + b];
+            if (run < N && N <= run + mine) {   // exactly one bin satisfies this
+                sh.d_star = (uint32_t)(lo + b);
+                sh.above = run;
+                sh.need = mine;
+            }
+            run += mine;
+        }
+    __syncthreads();
+    const uint32_t d_star = sh.d_star;
+    const uint32_t gathered = sh.above + sh.need;
+    __syncthreads();   // every thread is done with the histogram (and sh.*) before the buffer is reused
+    if (gathered > (uint32_t)sort_cap) return false;
+    if (tid == 0) sh.fill = 0;
+    for (int i = tid; i < sort_cap; i += kST) sortbuf[i] = 0ull;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 4 * kST) {
+        unsigned long long key[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * kST + tid;
+            key[u] = i < n ? K[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (key[u] > tkey && (((uint32_t)(key[u] >> 32) >> shift) & dmask) >= d_star)
+                sortbuf[atomicAdd(&sh.fill, 1u)] = key[u];
+    }
+    __syncthreads();
+    bitonic_sort_desc(sortbuf, sort_cap);
+    return true;
+}
+
+// ---- suppression on the rank window, entirely in LDS ---------------------------------------------
+// After the sort the responses are no longer needed (rank == index), so the window is compacted to
+// offs[i] = pixel offset | status << 30 (status 0 undecided, 1 accepted, 2 rejected) in the first half of
+// the buffer, and the second half becomes an open-addressing table of 2 * sort_cap 16-bit slots
+// (pixel offset -> rank, verified against offs[]; 0xFFFF = empty; load factor <= 1/2).
+constexpr uint32_t kOffMask = 0x3FFFFFFFu;
+
+__device__ __forceinline__ uint32_t slot_hash(uint32_t q, int hshift) { return (q * 2654435761u) >> hshift; }
+
+__device__ __forceinline__ void slot_insert(uint32_t *slot32, uint32_t smask, int hshift, uint32_t q, uint32_t rank) {
+    uint32_t hs = slot_hash(q, hshift);
+    while (true) {
+        const int sh16 = (hs & 1u) * 16;
+        const uint32_t old = slot32[hs >> 1];
+        if (((old >> sh16) & 0xFFFFu) == 0xFFFFu) {
+            const uint32_t upd = (old & ~(0xFFFFu << sh16)) | (rank << sh16);
+            if (atomicCAS(&slot32[hs >> 1], old, upd) == old) return;
+            continue;   // the word changed under us (its other half, or this slot): look again
+        }
+        hs = (hs + 1u) & smask;
+    }
+}
+
+// The better-ranked window entries (rank < i) within the distance of entry i: their count, and the ranks
+// of the first four in list[] (padded with 0xFFFF).  Every candidate that can decide entry i's fate is in
+// the table, so this list is all a later visit needs.
+__device__ __forceinline__ int nms_collect(const uint32_t *offs, const uint32_t *slot32, uint32_t smask, int hshift,
+                                           int w, int h, uint32_t i, int R, float min_dist_sq, uint32_t list[4]) {
+    const uint32_t off = offs[i] & kOffMask;
+    const int y = off / w, x = off - y * w;
+    int cnt = 0;
+    list[0] = list[1] = list[2] = list[3] = 0xFFFFu;
+    for (int dy = -R; dy <= R; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -R; dx <= R; dx++) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+            const float fx = (float)dx, fy = (float)dy;
+            if (!(fx * fx + fy * fy < min_dist_sq)) continue;
+            const uint32_t q = (uint32_t)(yy * w + xx);
+            uint32_t hs = slot_hash(q, hshift);
+            while (true) {
+                const uint32_t r = (slot32[hs >> 1] >> ((hs & 1u) * 16)) & 0xFFFFu;
+                if (r == 0xFFFFu) break;
+                if ((offs[r] & kOffMask) == q) {
+                    if (r < i) {
+                        if (cnt == 0) list[0] = r;
+                        else if (cnt == 1) list[1] = r;
+                        else if (cnt == 2) list[2] = r;
+                        else if (cnt == 3) list[3] = r;
+                        cnt++;
+                    }
+                    break;
+                }
+                hs = (hs + 1u) & smask;
+            }
+        }
+    }
+    return cnt;
+}
+
+// One visit of window entry i through the table: 1 accepted, 2 rejected, 0 still blocked by an undecided
+// better-ranked neighbour.  Statuses are read as they are at this moment (other waves publish theirs
+// without a barrier); they only ever go from undecided to decided, so a stale read costs a later visit.
+__device__ __forceinline__ int nms_visit_lds(const volatile uint32_t *offs, const uint32_t *slot32, uint32_t smask,
+                                             int hshift, int w, int h, uint32_t i, int R, float min_dist_sq) {
+    const uint32_t off = offs[i] & kOffMask;
+    const int y = off / w, x = off - y * w;
+    bool blocked = false;
+    for (int dy = -R; dy <= R; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -R; dx <= R; dx++) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+            const float fx = (float)dx, fy = (float)dy;
+            if (!(fx * fx + fy * fy < min_dist_sq)) continue;
+            const uint32_t q = (uint32_t)(yy * w + xx);
+            uint32_t hs = slot_hash(q, hshift);
+            while (true) {
+                const uint32_t r = (slot32[hs >> 1] >> ((hs & 1u) * 16)) & 0xFFFFu;
+                if (r == 0xFFFFu) break;
+                const uint32_t e = offs[r];
+                if ((e & kOffMask) == q) {
+                    if (r < i) {
+                        const uint32_t st = e >> 30;
+                        if (st == 1u) return 2;
+                        if (st == 0u) blocked = true;
+                    }
+                    break;
+                }
+                hs = (hs + 1u) & smask;
+            }
+        }
+    }
+    return blocked ? 0 : 1;
+}
+
 // One workgroup per frame.
 //  fast path: only the first maxCorners ACCEPTED corners in rank order are wanted, and a
 //    candidate's fate depends on higher-ranked candidates only, so suppression is run on the N
@@ -671,7 +966,7 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
     unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
     int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
     int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow,
-    const uint32_t *__restrict__ frame_max, double quality) {
+    const uint32_t *__restrict__ frame_max, double quality, int use_lists) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(smem_raw);
     __shared__ SelectShared sh;
@@ -690,12 +985,15 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
     const int R = min_dist >= 1.f ? (int)ceilf(min_dist) : 0;
     const uint32_t want_max = (uint32_t)max_corners;
 
-    // ---- exact threshold: the fused detector prefilters with a running maximum, so drop keys
-    //      whose response is not > (float)(max * quality)  (a no-op for exactly-thresholded lists)
-    {
-        float thr = (float)((double)ord2f(frame_max[f]) * quality);
-        if (thr == 0.f) thr = 0.f;   // -0 -> +0 so the ordered-key compare equals the float compare
-        const unsigned long long tkey = ((unsigned long long)f2ord(thr) << 32) | 0xFFFFFFFFull;
+    // exact threshold: the fused detector prefilters with a running maximum, so only keys whose response is
+    // > (float)(max * quality) count (every key of an exactly-thresholded list passes)
+    float thr = (float)((double)ord2f(frame_max[f]) * quality);
+    if (thr == 0.f) thr = 0.f;   // -0 -> +0 so the ordered-key compare equals the float compare
+    const uint32_t t32 = f2ord(thr), m32 = frame_max[f];
+    unsigned long long tkey = ((unsigned long long)t32 << 32) | 0xFFFFFFFFull;
+    bool compacted = false;
+    // drop the keys at or below the threshold from K (generic paths only; the two-pass window filters on the fly)
+    auto compact_keys = [&]() {
         uint32_t kept = 0;
         for (uint32_t base = 0; base < n; base += kST) {
             const uint32_t i = base + tid;
@@ -719,38 +1017,112 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
             kept += tot;
         }
         n = kept;
+        tkey = 0ull;   // every remaining key passes (no key is 0: its response would be a NaN pattern)
+        compacted = true;
         __syncthreads();
-    }
+    };
 
     // ---------------------------------------------------------------- fast path
+    uint32_t *offs = reinterpret_cast<uint32_t *>(sortbuf);
+    uint32_t *slot32 = offs + sort_cap;
+    const uint32_t smask = 2u * (uint32_t)sort_cap - 1u;
+    const int hshift = 31 - (31 - __clz(sort_cap));   // 32 - log2(2 * sort_cap)
     bool done = false;
     {
         uint32_t N = want_max + want_max / 4 + 64;
         if (R == 0) N = want_max;
         while (true) {
-            if (N > n) N = n;
-            if (N > (uint32_t)sort_cap) N = (uint32_t)sort_cap;
-            const unsigned long long T = radix_select_nth(K, n, N, sh);
-            const uint32_t got = gather_sorted(K, n, T, sortbuf, sort_cap, sh);   // == N
-            if (R > 0) {
-                while (true) {   // suppression fixpoint over the N best-ranked candidates
-                    __syncthreads();
-                    if (tid == 0) sh.flag = 0;
-                    __syncthreads();
-                    bool pending = false;
-                    for (uint32_t i = tid; i < got; i += kST) {
-                        const uint32_t off = (uint32_t)sortbuf[i];
-                        if (S[off] != 1) continue;
-                        const int d = nms_visit(E, S, w, h, off, R, min_dist_sq);
-                        if (d == 1) pending = true;
-                        else S[off] = (uint8_t)d;
-                    }
-                    if (pending) sh.flag = 1;
-                    __syncthreads();
-                    if (!sh.flag) break;
-                }
+            uint32_t got = N, n_kept = 0;
+            if (!rank_window_2pass(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept)) {
+                if (!compacted) compact_keys();
+                n_kept = n;
+                got = N < n ? N : n;
+                if (got > (uint32_t)sort_cap) got = (uint32_t)sort_cap;
+                const unsigned long long T = radix_select_nth(K, n, got, sh);
+                got = gather_sorted(K, n, T, sortbuf, sort_cap, sh);
             }
-            // survivors in rank order: ordered scan over the sorted buffer
+            if (R > 0) {
+                // window -> offs[] (entries are read, then a barrier, then written: offs[i] overlays sortbuf[i / 2])
+                for (uint32_t c0 = 0; c0 < got; c0 += kST) {
+                    const uint32_t i = c0 + tid;
+                    const uint32_t v = i < got ? (uint32_t)sortbuf[i] : 0u;
+                    __syncthreads();
+                    if (i < got) offs[i] = v;
+                }
+                __syncthreads();
+                for (int i = tid; i < sort_cap; i += kST) slot32[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                uint32_t pend = 0;   // bit k: window entry tid + k * kST is undecided (sort_cap <= 16 * kST)
+                {
+                    int k = 0;
+                    for (uint32_t i = tid; i < got; i += kST, k++) {
+                        slot_insert(slot32, smask, hshift, offs[i], i);
+                        pend |= 1u << k;
+                    }
+                }
+                __syncthreads();
+                // first visit: who can decide my fate?  Nobody -> accepted; up to four -> remember their
+                // ranks (when the launch provides the list region); more -> table visits every time.
+                uint2 *nbr = use_lists ? reinterpret_cast<uint2 *>(smem_raw + sizeof(unsigned long long) * (size_t)sort_cap) : nullptr;
+                uint32_t full = 0;
+                {
+                    int k = 0;
+                    for (uint32_t i = tid; i < got; i += kST, k++) {
+                        uint32_t list[4];
+                        const int cnt = nms_collect(offs, slot32, smask, hshift, w, h, i, R, min_dist_sq, list);
+                        if (cnt == 0) {
+                            offs[i] |= 1u << 30;
+                            pend &= ~(1u << k);
+                        } else if (nbr && cnt <= 4) {
+                            nbr[i] = make_uint2(list[0] | (list[1] << 16), list[2] | (list[3] << 16));
+                        } else {
+                            full |= 1u << k;
+                        }
+                    }
+                }
+                __syncthreads();
+                // Suppression fixpoint.  An entry's fate needs its better-ranked neighbours decided first, and chains
+                // of such dependencies run along image edges, so the number of rounds is the longest chain: each
+                // wave therefore polls on its own, without workgroup barriers (statuses live in LDS, every wave of the
+                // workgroup is resident, and the rank order makes the dependency graph acyclic).
+                {
+                    volatile uint32_t *voffs = offs;
+                    int spins = 0;
+                    while (__any(pend != 0)) {
+                        int k = 0;
+                        for (uint32_t i = tid; i < got; i += kST, k++) {
+                            if (!((pend >> k) & 1u)) continue;
+                            int d;
+                            if ((full >> k) & 1u) {
+                                d = nms_visit_lds(voffs, slot32, smask, hshift, w, h, i, R, min_dist_sq);
+                            } else {
+                                const uint2 l = nbr[i];
+                                const uint32_t r[4] = {l.x & 0xFFFFu, l.x >> 16, l.y & 0xFFFFu, l.y >> 16};
+                                bool blocked = false, rejected = false;
+#pragma unroll
+                                for (int t = 0; t < 4; t++) {
+                                    if (r[t] == 0xFFFFu) continue;
+                                    const uint32_t st = voffs[r[t]] >> 30;
+                                    rejected |= st == 1u;
+                                    blocked |= st == 0u;
+                                }
+                                d = rejected ? 2 : (blocked ? 0 : 1);
+                            }
+                            if (d) {
+                                voffs[i] = voffs[i] | ((uint32_t)d << 30);
+                                pend &= ~(1u << k);
+                            }
+                        }
+                        if (++spins > (1 << 22)) {   // cannot happen (acyclic); never hang the device on a defect
+                            if (lane == 0) atomicAdd(overflow, 1);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __syncthreads();
+            }
+            // survivors in rank order: ordered scan over the window
             __syncthreads();
             uint32_t base = 0;
             for (uint32_t i0 = 0; i0 < got; i0 += kST) {
@@ -758,8 +1130,14 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
                 uint32_t off = 0;
                 bool acc = false;
                 if (i < got) {
-                    off = (uint32_t)sortbuf[i];
-                    acc = (R == 0) || S[off] == 2;
+                    if (R == 0) {
+                        off = (uint32_t)sortbuf[i];
+                        acc = true;
+                    } else {
+                        const uint32_t e = offs[i];
+                        off = e & kOffMask;
+                        acc = (e >> 30) == 1u;
+                    }
                 }
                 const unsigned long long bal = __ballot(acc);
                 __syncthreads();
@@ -780,18 +1158,26 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
                 }
                 base += tot;
             }
-            if (base >= want_max || got == n) {
+            if (base >= want_max || got == n_kept) {
                 if (tid == 0) out_n[f] = (int32_t)(base < want_max ? base : want_max);
                 done = true;
                 break;
             }
-            if (N == (uint32_t)sort_cap) break;   // cannot widen in LDS: slow path
+            if (got == (uint32_t)sort_cap) break;   // cannot widen in LDS: slow path
             N *= 2;
         }
     }
     if (done) return;
 
     // ---------------------------------------------------------------- slow path (rare)
+    // suppression over every candidate through a per-pixel state map in global memory
+    // (0 none, 1 undecided, 2 accepted, 3 rejected), which this path initialises itself
+    if (!compacted) compact_keys();
+    if (R > 0) {
+        for (uint32_t i = tid; i < (uint32_t)(w * h); i += kST) S[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kST) S[(uint32_t)K[i]] = 1;
+    }
     if (R > 0) {
         while (true) {
             __syncthreads();
@@ -1056,7 +1442,7 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VsProfScope ps(ctx, "min_eigen_kernel");
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && ((reinterpret_cast<uintptr_t>(eig) & 15) == 0)) {
         dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), frames);
-        min_eigen_v4_kernel<false><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits, 0.0, nullptr, nullptr, nullptr, 0);
+        min_eigen_v4_kernel<false><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits, 0.0, nullptr, nullptr, 0);
     } else {
         dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
         min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
@@ -1072,6 +1458,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     VS_REQUIRE(ctx, frames > 0 && w >= 3 && h >= 3, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, max_corners > 0 && max_corners <= kp_stride, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, min_distance < 64.0, VSLAM_ERR_CAPACITY);
+    VS_REQUIRE(ctx, (size_t)w * h < (1u << 30), VSLAM_ERR_CAPACITY);   // pixel offsets carry 2 status bits in the selection
     const size_t px = (size_t)w * h;
     float *eig = nullptr;
     uint32_t *fmax = nullptr, *counts = nullptr;
@@ -1096,26 +1483,33 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         {
             VsProfScope ps(ctx, "min_eigen_kernel");
             dim3 grid(vs_div_up(w, kE4W - 8), vs_div_up(h, kE4H - 2), frames);
-            min_eigen_v4_kernel<true><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, state, keys, counts, key_cap);
+            min_eigen_v4_kernel<true><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, keys, counts, key_cap);
         }
         {   // frames with a negative maximum (not seen in practice) are redone the two-pass way
             VsProfScope ps(ctx, "corner_candidates_kernel");
             negative_max_reset_kernel<<<vs_div_up(frames, 256), 256, 0, ctx->stream>>>(fmax, counts, frames);
             dim3 grid(vs_div_up(w, kC4W), vs_div_up(h, kC4H), frames);
-            corner_candidates_v4_kernel<<<grid, 256, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap, 1);
+            corner_candidates_v4_kernel<<<grid, 256, 0, ctx->stream>>>(eig, w, h, fmax, quality, keys, counts, key_cap, 1);
         }
     } else {
         if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, fmax))) return rc;
         VsProfScope ps(ctx, "corner_candidates_kernel");
         dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
-        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, state, keys, counts, key_cap);
+        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, keys, counts, key_cap);
+    }
+    if (ctx->fork_after_eigen) {   // the caller runs an independent stage on the auxiliary stream beside the selection
+        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
     }
     {
         int sort_cap = 2;
         while (sort_cap < 2 * max_corners && sort_cap < 16384) sort_cap <<= 1;
         while (sort_cap < max_corners) sort_cap <<= 1;   // at least max_corners slots
-        const size_t lds = sizeof(unsigned long long) * (size_t)sort_cap;
+        size_t lds = sizeof(unsigned long long) * (size_t)sort_cap;
         VS_REQUIRE(ctx, lds <= 128 * 1024, VSLAM_ERR_CAPACITY);
+        // second region of the same size: per window entry the ranks of up to four candidates that can suppress it
+        const int use_lists = 2 * lds <= 128 * 1024;
+        if (use_lists) lds *= 2;
         if (!ctx->attr_done["corner_select"]) {
             VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corner_select_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -1125,7 +1519,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         const float md2 = (float)(min_distance * min_distance);   // `minDistance *= minDistance` in double, compared as float
         VsProfScope ps(ctx, "corner_select_kernel");
         corner_select_kernel<<<frames, kST, lds, ctx->stream>>>(eig, w, h, state, keys, counts, key_cap, max_corners, md,
-                                                                md2, sort_cap, xy, n, kp_stride, overflow, fmax, quality);
+                                                                md2, sort_cap, xy, n, kp_stride, overflow, fmax, quality, use_lists);
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;

@@ -524,11 +524,35 @@ __device__ __forceinline__ float residual_e(const ResidualF &R, const float4 c, 
     return ((q + a1 * a1) + t0 * t0) + t1 * t1;
 }
 
+// Two correspondences at once: the float multiplies and adds become v_pk_mul_f32 / v_pk_add_f32 (IEEE, same
+// roundings as the scalar forms), which halves the float instruction count of the hot loop; the double
+// part (F.t()*x2) and the division stay per element.  Lane .x is the lower correspondence index.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f residual_e2(const ResidualF &R, const v2f x1, const v2f y1, const v2f x2, const v2f y2,
+                                           const double2 da, const double2 db) {
+    const v2f a0 = (R.f[0] * x1 + R.f[1] * y1) + R.f[2];
+    const v2f a1 = (R.f[3] * x1 + R.f[4] * y1) + R.f[5];
+    const v2f a2 = (R.f[6] * x1 + R.f[7] * y1) + R.f[8];
+    v2f t0, t1;
+    t0.x = (float)(__builtin_fma(R.ft[1], da.y, R.ft[0] * da.x) + R.ft[2]);
+    t0.y = (float)(__builtin_fma(R.ft[1], db.y, R.ft[0] * db.x) + R.ft[2]);
+    t1.x = (float)(__builtin_fma(R.ft[4], da.y, R.ft[3] * da.x) + R.ft[5]);
+    t1.y = (float)(__builtin_fma(R.ft[4], db.y, R.ft[3] * db.x) + R.ft[5]);
+    const v2f n = (x2 * a0 + y2 * a1) + a2;
+    const v2f nn = n * n, dd = a0 * a0;
+    v2f q;
+    q.x = nn.x / dd.x;
+    q.y = nn.y / dd.y;
+    return ((q + a1 * a1) + t0 * t0) + t1 * t1;
+}
+
 constexpr int kScoreThreads = 256;
 constexpr int kScoreTile = 1024;   // correspondences per LDS tile (16 B floats + 16 B doubles each: 32 KiB)
 
-// One lane per hypothesis; correspondences gathered once per workgroup into LDS as float4
-// (x1,y1,x2,y2) and read back as wave-uniform broadcasts.  grid = (ceil(hyp/256), batch).
+// One lane per hypothesis; correspondences gathered once per workgroup into LDS and read back as wave-uniform
+// broadcasts, two at a time: corr[2j] = (x1a, x1b, y1a, y1b), corr[2j+1] = (x2a, x2b, y2a, y2b) for the
+// correspondences a = 2j, b = 2j+1 of the tile; corrd[i] = ((double)x2, (double)y2) of correspondence i
+// (converted once per match, not once per hypothesis).  grid = (ceil(hyp/256), batch).
 __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold,
@@ -538,8 +562,8 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
     const int m = m_arr[b];
     if (m < VSLAM_SET_SIZE) return;
 
-    __shared__ float4 corr[kScoreTile];
-    __shared__ double2 corrd[kScoreTile];   // (double)x2, (double)y2: converted once per match, not once per hypothesis
+    __shared__ __align__(16) float corr[kScoreTile * 4];
+    __shared__ double2 corrd[kScoreTile];
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
     const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
     const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
@@ -556,19 +580,38 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
     for (int base = 0; base < m; base += kScoreTile) {
         const int rows = min(kScoreTile, m - base);
         __syncthreads();
-        for (int i = tid; i < rows; i += kScoreThreads) {
-            const int2 pr = PR[base + i];
+        for (int i = tid; i < ((rows + 1) & ~1); i += kScoreThreads) {
+            const int2 pr = PR[base + min(i, rows - 1)];   // an odd tail is padded with its last correspondence
             const float2 a = P1[pr.x], c = P2[pr.y];
-            corr[i] = make_float4(a.x, a.y, c.x, c.y);
+            float *d = corr + (i >> 1) * 8 + (i & 1);
+            d[0] = a.x;
+            d[2] = a.y;
+            d[4] = c.x;
+            d[6] = c.y;
             corrd[i] = make_double2((double)c.x, (double)c.y);
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < rows; i++) {
+        const int full = rows >> 1;
+#pragma unroll 2
+        for (int j = 0; j < full; j++) {
+            const float4 p = *reinterpret_cast<const float4 *>(corr + j * 8);
+            const float4 r = *reinterpret_cast<const float4 *>(corr + j * 8 + 4);
+            v2f x1, y1, x2, y2;
+            x1.x = p.x; x1.y = p.y; y1.x = p.z; y1.y = p.w;
+            x2.x = r.x; x2.y = r.y; y2.x = r.z; y2.y = r.w;
+            const v2f e = residual_e2(R, x1, y1, x2, y2, corrd[2 * j], corrd[2 * j + 1]);
+            count += (e.x <= threshold) ? 1 : 0;   // NaN <= thr is false, :130
+            total += (double)e.x;                  // cv::sum in index order, :138
+            count += (e.y <= threshold) ? 1 : 0;
+            total += (double)e.y;
+        }
+        if (rows & 1) {
+            const int i = rows - 1;
+            const float *d = corr + (i >> 1) * 8;
             const double2 d2 = corrd[i];
-            const float e = residual_e(R, corr[i], d2.x, d2.y);
-            count += (e <= threshold) ? 1 : 0;   // NaN <= thr is false, :130
-            total += (double)e;                  // cv::sum in index order, :138
+            const float e = residual_e(R, make_float4(d[0], d[2], d[4], d[6]), d2.x, d2.y);
+            count += (e <= threshold) ? 1 : 0;
+            total += (double)e;
         }
     }
     if (h < hyp) {
