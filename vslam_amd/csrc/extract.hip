@@ -414,6 +414,272 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming form of the fused response + 3x3-maxima kernel (width % 4 == 0)
+// ------------------------------------------------------------------------------------------
+// One wave owns a column strip (64 lanes x 4 pixels, lanes 0 and 63 are halo for the maxima test) and walks
+// down a segment of rows.  Everything that the tile form recomputed at tile seams rolls in registers
+// instead: the two previous rows of horizontal Sobel parts, the two previous rows of horizontal product
+// sums, the two previous rows of responses and of their horizontal 3-maxima.  Gray rows come straight from
+// global memory (three coalesced dwords per lane and row, issued three rows ahead), responses of the
+// neighbouring lanes come through DPP wave shifts, so the kernel uses no LDS except the candidate queue
+// and has no barriers.  Arithmetic and its order are those of min_eigen_v4_kernel (see there).
+//
+// Step t of a segment owning rows [ys, ye):   gray row g = ys - 3 + t   (Sobel parts of row g)
+//   t >= 2: products and their horizontal sums on row p = g - 1
+//   t >= 4: response row y = p - 1 = ys - 5 + t  (stored when ys <= y < ye)
+//   t >= 6: 3x3-maxima test of row y - 1 = ys - 6 + t  -> candidates
+// so a segment takes (ye - ys) + 6 steps, 6 of them warm-up (7 % at 90 rows per segment).
+constexpr int kSOwn = 248;   // owned pixels per strip (lanes 1..62)
+constexpr int kSQ = 512;     // candidate queue entries per wave
+
+struct StreamState {
+    float hx[3][6], rr[3][6];      // per gray row: x-derivative parts and smoothed values, columns x-1 .. x+4
+    double S[3][12];               // per product row: horizontal 3-sums of xx, xy, yy for the lane's 4 pixels
+    float ctr[3][4], hm[3][4];     // per response row: the values and their horizontal 3-maxima
+    uint32_t raw[3][3];            // prefetched gray dwords (x-4, x, x+4) of the next three rows
+    float emax;
+};
+
+template <int B>
+__device__ __forceinline__ float cvt_ubyte(uint32_t d) {   // (float) of byte B of d
+    float r;
+    if (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(d));
+    else if (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(d));
+    else if (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(d));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(d));
+    return r;
+}
+__device__ __forceinline__ float dpp_wave_shr1(float v, float fill) {   // lane i <- lane i-1, lane 0 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float v, float fill) {   // lane i <- lane i+1, lane 63 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+struct StreamArgs {
+    const uint8_t *src;          // frame base
+    float *eig;                  // frame base
+    unsigned long long *queue;   // this wave's LDS queue
+    unsigned long long *keys;    // frame base
+    uint32_t *count;             // this frame's candidate counter
+    size_t key_cap;
+    int w, h, ys, ye, x, steps;
+    uint32_t voff_l, voff_c, voff_r;
+    bool edge, left_fix, right_fix, own_lane;
+    float k0, k1, thr_p;
+};
+
+__device__ __forceinline__ void stream_flush(const StreamArgs &a, int &qn, int lane) {
+    if (qn == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.count, (uint32_t)qn);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int i = lane; i < qn; i += 64) {
+        const size_t pos = (size_t)base + i;
+        if (pos < a.key_cap) a.keys[pos] = a.queue[i];
+    }
+    qn = 0;
+}
+
+template <int K>
+__device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a, int t, int &qn, int lane) {
+    constexpr int K1 = (K + 2) % 3, K2 = (K + 1) % 3;   // slots of the previous row and the one before
+    uint32_t d0 = st.raw[K][0];
+    const uint32_t d1 = st.raw[K][1];
+    uint32_t d2 = st.raw[K][2];
+    if (t + 3 < a.steps) {   // prefetch the row three steps ahead into the slot just consumed
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + t + 3, a.h) * a.w;
+        st.raw[K][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
+        st.raw[K][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
+        st.raw[K][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+    }
+    if (a.edge) {   // BORDER_REFLECT_101 in x: columns -2, -1 are columns 2, 1; columns w, w+1 are w-2, w-3
+        if (a.left_fix) d0 = (d1 & 0x00FF0000u) | ((d1 & 0x0000FF00u) << 16);
+        if (a.right_fix) d2 = ((d1 >> 16) & 0xFFu) | (d1 & 0xFF00u);
+    }
+    // gray at columns x-2 .. x+5.  The conversions are opaque to the compiler on purpose: it would otherwise
+    // rewrite float(a) - float(b) as float(a - b) with byte-select integer ops, which issue slower here
+    // than one v_cvt_f32_ubyteN per pixel plus plain float subtract / add (tools/valu_rate.hip).
+    float g[8];
+    g[0] = cvt_ubyte<2>(d0); g[1] = cvt_ubyte<3>(d0);
+    g[2] = cvt_ubyte<0>(d1); g[3] = cvt_ubyte<1>(d1); g[4] = cvt_ubyte<2>(d1); g[5] = cvt_ubyte<3>(d1);
+    g[6] = cvt_ubyte<0>(d2); g[7] = cvt_ubyte<1>(d2);
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        st.hx[K][c] = g[c + 2] - g[c];
+        const float p = g[c + 1] * a.k0;
+        const float q = (g[c] + g[c + 2]) * a.k1;
+        st.rr[K][c] = p + q;
+    }
+    if (t < 2) return;
+
+    // products on row p = g - 1
+    const int prow = a.ys - 4 + t;
+    const bool rowflip = prow < 0 || prow >= a.h;
+    float cxx[6], cxy[6], cyy[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const float p = st.hx[K1][c] * a.k0;
+        const float q = (st.hx[K2][c] + st.hx[K][c]) * a.k1;
+        const float dx = p + q;
+        const float dy = st.rr[K][c] - st.rr[K2][c];
+        cxx[c] = dx * dx;
+        cxy[c] = dx * dy;
+        cyy[c] = dy * dy;
+    }
+    if (a.edge) {    // mirrored column: the xy product changes sign (see min_eigen_v4_kernel)
+        if (a.left_fix) cxy[0] = -cxy[0];
+        if (a.right_fix) cxy[5] = -cxy[5];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        st.S[K][i] = ((double)cxx[i] + (double)cxx[i + 1]) + (double)cxx[i + 2];
+        st.S[K][4 + i] = ((double)cxy[i] + (double)cxy[i + 1]) + (double)cxy[i + 2];
+        st.S[K][8 + i] = ((double)cyy[i] + (double)cyy[i + 1]) + (double)cyy[i + 2];
+    }
+    if (rowflip) {   // mirrored row (two per frame): same rule; negating the sums equals summing the negated products
+        asm volatile("" ::: "memory");   // keep this a branch: as selects it would cost every row
+#pragma unroll
+        for (int i = 0; i < 4; i++) st.S[K][4 + i] = -st.S[K][4 + i];
+    }
+    if (t >= 4) {
+        const int y = a.ys - 5 + t;
+        float apc[4], tt[4], rt[4], e4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // column sums S(y) = (r(y-1) + r(y)) + r(y+1), rows in slots K2, K1, K
+            const float sxx = (float)((st.S[K2][i] + st.S[K1][i]) + st.S[K][i]);
+            const float sxy = (float)((st.S[K2][4 + i] + st.S[K1][4 + i]) + st.S[K][4 + i]);
+            const float syy = (float)((st.S[K2][8 + i] + st.S[K1][8 + i]) + st.S[K][8 + i]);
+            const float ea = sxx * 0.5f, eb = sxy, ec = syy * 0.5f;
+            const float amc = ea - ec;
+            tt[i] = amc * amc + eb * eb;
+            apc[i] = ea + ec;
+        }
+        sqrt_rn4(tt, rt);
+#pragma unroll
+        for (int i = 0; i < 4; i++) e4[i] = apc[i] - rt[i];
+        if (y >= a.ys && y < a.ye && a.own_lane) {
+            st.emax = max3_nonan(max3_nonan(e4[0], e4[1], e4[2]), e4[3], st.emax);
+            *reinterpret_cast<float4 *>(a.eig + (size_t)y * a.w + a.x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        }
+        // rows y < 0 or y >= h, and the pixels of lanes outside the image, are never a neighbour of a testable
+        // pixel (tests cover rows 1 .. h-2 and columns 1 .. w-2), so their values need no special marking
+        const float lf = dpp_wave_shr1(e4[3], e4[0]), rg = dpp_wave_shl1(e4[0], e4[3]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) st.ctr[K][i] = e4[i];
+        st.hm[K][0] = max3_nonan(lf, e4[0], e4[1]);
+        st.hm[K][1] = max3_nonan(e4[0], e4[1], e4[2]);
+        st.hm[K][2] = max3_nonan(e4[1], e4[2], e4[3]);
+        st.hm[K][3] = max3_nonan(e4[2], e4[3], rg);
+        if (t >= 6) {
+            const int ty = y - 1;   // ys <= ty < ye by construction
+            if (qn > kSQ - 256) stream_flush(a, qn, lane);
+            const bool row_ok = ty >= 1 && ty < a.h - 1 && a.own_lane;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float v = st.ctr[K1][i];
+                const float m = max3_nonan(st.hm[K2][i], st.hm[K1][i], st.hm[K][i]);
+                const int xx = a.x + i;
+                const bool cand = row_ok && xx >= 1 && xx < a.w - 1 && v > a.thr_p && !(m > v);
+                const unsigned long long bal = __ballot(cand);
+                if (bal) {
+                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (cand) a.queue[pos] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(ty * a.w + xx);
+                    qn += __popcll(bal);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
+                                                               float *__restrict__ eig, uint32_t *__restrict__ frame_max,
+                                                               double quality, unsigned long long *__restrict__ keys,
+                                                               uint32_t *__restrict__ counts, size_t key_cap, int seg_rows) {
+    __shared__ unsigned long long queue[4][kSQ];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.z;
+    StreamArgs a;
+    a.ys = (blockIdx.y * 4 + wave) * seg_rows;
+    if (a.ys >= h) return;   // whole wave; the kernel has no barriers
+    a.ye = a.ys + seg_rows < h ? a.ys + seg_rows : h;
+    a.steps = a.ye - a.ys + 6;
+    a.w = w;
+    a.h = h;
+    a.src = gray + (size_t)f * w * h;
+    a.eig = eig + (size_t)f * w * h;
+    a.queue = queue[wave];
+    a.keys = keys + (size_t)f * key_cap;
+    a.count = counts + f;
+    a.key_cap = key_cap;
+    const int x0 = blockIdx.x * kSOwn - 4;
+    a.x = x0 + 4 * lane;
+    const bool in_img = a.x >= 0 && a.x < w;
+    a.own_lane = in_img && lane >= 1 && lane <= 62;
+    a.edge = x0 < 4 || x0 + 256 + 4 > w;
+    a.left_fix = a.x == 0;
+    a.right_fix = a.x + 4 == w;
+    const int xc = a.x < 0 ? 0 : (a.x > w - 4 ? w - 4 : a.x);
+    a.voff_c = (uint32_t)xc;
+    a.voff_l = (uint32_t)(xc - 4 < 0 ? 0 : xc - 4);
+    a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
+    const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    a.k1 = (float)scale;
+    a.k0 = 2.0f * a.k1;
+    const float ninf = -__builtin_inff();
+
+    StreamState st;
+    st.emax = ninf;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 12; i++) st.S[k][i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
+        st.raw[k][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
+        st.raw[k][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
+        st.raw[k][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+    }
+    // candidate prefilter: the best maximum known so far (other waves publish theirs as they go); always <= the
+    // frame's final maximum, so the candidates are a superset and corner_select_kernel applies the exact threshold
+    uint32_t run_max = frame_max[f];
+    a.thr_p = (float)((double)ord2f(run_max) * quality);
+    if (run_max == 0u) a.thr_p = ninf;   // nothing published yet
+    int qn = 0;
+    for (int t0 = 0; t0 < a.steps; t0 += 3) {
+        stream_step<0>(st, a, t0, qn, lane);
+        if (t0 + 1 < a.steps) stream_step<1>(st, a, t0 + 1, qn, lane);
+        if (t0 + 2 < a.steps) stream_step<2>(st, a, t0 + 2, qn, lane);
+        if ((t0 % 12) == 9) {   // every 12 rows: tighten the prefilter with this wave's own maximum and publish it
+            uint32_t k = st.emax == ninf ? 0u : f2ord(st.emax);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(k, off, 64);
+                k = o > k ? o : k;
+            }
+            if (k > run_max) {   // fire and forget: later waves start from it (re-reading it here would stall the wave)
+                run_max = k;
+                if (lane == 0) atomicMax(&frame_max[f], k);
+            }
+            if (run_max != 0u) a.thr_p = (float)((double)ord2f(run_max) * quality);
+        }
+    }
+    {
+        uint32_t k = st.emax == ninf ? 0u : f2ord(st.emax);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(k, off, 64);
+            k = o > k ? o : k;
+        }
+        if (lane == 0 && k != 0u) atomicMax(&frame_max[f], k);
+    }
+    stream_flush(a, qn, lane);
+}
+
 // frames whose maximum response is negative cannot use the fused candidates: forget them
 __global__ void negative_max_reset_kernel(const uint32_t *__restrict__ frame_max, uint32_t *__restrict__ counts, int frames) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1482,8 +1748,10 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         VS_HIP(ctx, hipMemsetAsync(fmax, 0, sizeof(uint32_t) * (size_t)frames, ctx->stream));
         {
             VsProfScope ps(ctx, "min_eigen_kernel");
-            dim3 grid(vs_div_up(w, kE4W - 8), vs_div_up(h, kE4H - 2), frames);
-            min_eigen_v4_kernel<true><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, keys, counts, key_cap);
+            const int segs = h >= 135 ? (h + 45) / 90 : 1;   // about 90 rows per wave
+            const int seg_rows = vs_div_up(h, segs);
+            dim3 grid(vs_div_up(w, kSOwn), vs_div_up(segs, 4), frames);
+            min_eigen_stream_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, keys, counts, key_cap, seg_rows);
         }
         {   // frames with a negative maximum (not seen in practice) are redone the two-pass way
             VsProfScope ps(ctx, "corner_candidates_kernel");
