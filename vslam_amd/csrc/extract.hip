@@ -417,8 +417,7 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
 // ------------------------------------------------------------------------------------------
 // Streaming form of the fused response + 3x3-maxima kernel (width % 4 == 0)
 // ------------------------------------------------------------------------------------------
-// One wave owns a column strip (64 lanes x 4 pixels, lanes 0 and 63 are halo for the maxima test) and walks
-// down a segment of rows.  Everything that the tile form recomputed at tile seams rolls in registers
+// One wave owns a column strip (64 lanes x 4 pixels) and walks down a segment of rows.  Everything that the tile form recomputed at tile seams rolls in registers
 // instead: the two previous rows of horizontal Sobel parts, the two previous rows of horizontal product
 // sums, the two previous rows of responses and of their horizontal 3-maxima.  Gray rows come straight from
 // global memory (three coalesced dwords per lane and row, issued three rows ahead), responses of the
@@ -430,8 +429,13 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
 //   t >= 4: response row y = p - 1 = ys - 5 + t  (stored when ys <= y < ye)
 //   t >= 6: 3x3-maxima test of row y - 1 = ys - 6 + t  -> candidates
 // so a segment takes (ye - ys) + 6 steps, 6 of them warm-up (7 % at 90 rows per segment).
-constexpr int kSOwn = 248;   // owned pixels per strip (lanes 1..62)
+constexpr int kSW = 256;     // pixels per strip (64 lanes x 4), all owned
 constexpr int kSQ = 512;     // candidate queue entries per wave
+// Strips do not overlap, so the 3x3 test of a strip's first and last column lacks the neighbouring strip's
+// column.  Such candidates are emitted with a flag in the (otherwise unused) top bits of the pixel offset and
+// corner_select_kernel completes their test against the stored responses before anything else looks at them.
+constexpr uint32_t kKeyCheckLeft = 0x80000000u, kKeyCheckRight = 0x40000000u;
+constexpr uint32_t kOffMask = 0x3FFFFFFFu;   // pixel offset part of a key's low word
 
 struct StreamState {
     float hx[3][6], rr[3][6];      // per gray row: x-derivative parts and smoothed values, columns x-1 .. x+4
@@ -566,7 +570,8 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
         }
         // rows y < 0 or y >= h, and the pixels of lanes outside the image, are never a neighbour of a testable
         // pixel (tests cover rows 1 .. h-2 and columns 1 .. w-2), so their values need no special marking
-        const float lf = dpp_wave_shr1(e4[3], e4[0]), rg = dpp_wave_shl1(e4[0], e4[3]);
+        const float ninf = -__builtin_inff();   // what lane 0 / lane 63 see beyond the strip: resolved later (kKeyCheck*)
+        const float lf = dpp_wave_shr1(e4[3], ninf), rg = dpp_wave_shl1(e4[0], ninf);
 #pragma unroll
         for (int i = 0; i < 4; i++) st.ctr[K][i] = e4[i];
         st.hm[K][0] = max3_nonan(lf, e4[0], e4[1]);
@@ -586,7 +591,10 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
                 const unsigned long long bal = __ballot(cand);
                 if (bal) {
                     const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (cand) a.queue[pos] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(ty * a.w + xx);
+                    uint32_t lo = (uint32_t)(ty * a.w + xx);
+                    if (i == 0 && lane == 0) lo |= kKeyCheckLeft;     // xx >= 1 here, so a strip lies to the left
+                    if (i == 3 && lane == 63) lo |= kKeyCheckRight;   // xx < w - 1 here, so a strip lies to the right
+                    if (cand) a.queue[pos] = ((unsigned long long)f2ord(v) << 32) | lo;
                     qn += __popcll(bal);
                 }
             }
@@ -615,11 +623,10 @@ __global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__
     a.keys = keys + (size_t)f * key_cap;
     a.count = counts + f;
     a.key_cap = key_cap;
-    const int x0 = blockIdx.x * kSOwn - 4;
+    const int x0 = blockIdx.x * kSW;
     a.x = x0 + 4 * lane;
-    const bool in_img = a.x >= 0 && a.x < w;
-    a.own_lane = in_img && lane >= 1 && lane <= 62;
-    a.edge = x0 < 4 || x0 + 256 + 4 > w;
+    a.own_lane = a.x < w;
+    a.edge = x0 == 0 || x0 + kSW + 4 > w;
     a.left_fix = a.x == 0;
     a.right_fix = a.x + 4 == w;
     const int xc = a.x < 0 ? 0 : (a.x > w - 4 ? w - 4 : a.x);
@@ -1033,9 +1040,9 @@ __device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsig
 // which is then sorted: its first N entries are the N best-ranked candidates.  Returns false when the
 // gathered set would not fit the buffer (heavy ties); the caller then uses the generic radix select.
 // n_kept receives the number of keys above the threshold, N_io is clamped to it.
-__device__ bool rank_window_2pass(const unsigned long long *K, uint32_t n, unsigned long long tkey, uint32_t t32,
+__device__ bool rank_window_2pass(unsigned long long *K, uint32_t n, unsigned long long tkey, uint32_t t32,
                                   uint32_t m32, uint32_t &N_io, unsigned long long *sortbuf, int sort_cap,
-                                  SelectShared &sh, uint32_t &n_kept) {
+                                  SelectShared &sh, uint32_t &n_kept, const float *__restrict__ E, int w) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *hist = reinterpret_cast<uint32_t *>(sortbuf);
     const int bins = 2 * sort_cap < 4096 ? 2 * sort_cap : 4096;
@@ -1054,8 +1061,27 @@ __device__ bool rank_window_2pass(const unsigned long long *K, uint32_t n, unsig
             key[u] = i < n ? K[i] : 0ull;   // 0 never passes the threshold test
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 4; u++) {
+            const uint32_t lo = (uint32_t)key[u];
+            if (lo & (kKeyCheckLeft | kKeyCheckRight)) {
+                // candidate on the first / last column of a detector strip: finish its 3x3 test with the column the
+                // strip could not see, then store the key without the flag (or 0: never a candidate)
+                const uint32_t off = lo & kOffMask;
+                const float v = ord2f((uint32_t)(key[u] >> 32));
+                bool ok = true;
+                if (lo & kKeyCheckLeft) {
+                    const float *e = E + (size_t)off - w - 1;
+                    ok = ok && !(e[0] > v) && !(e[w] > v) && !(e[2 * (size_t)w] > v);
+                }
+                if (lo & kKeyCheckRight) {
+                    const float *e = E + (size_t)off - w + 1;
+                    ok = ok && !(e[0] > v) && !(e[w] > v) && !(e[2 * (size_t)w] > v);
+                }
+                key[u] = ok ? ((key[u] & 0xFFFFFFFF00000000ull) | off) : 0ull;
+                K[i0 + u * kST + tid] = key[u];
+            }
             if (key[u] > tkey) atomicAdd(&hist[((uint32_t)(key[u] >> 32) >> shift) & dmask], 1u);
+        }
     }
     __syncthreads();
     // suffix scan: thread t owns `per` consecutive bins; above = keys in bins owned by higher threads
@@ -1127,7 +1153,6 @@ __device__ bool rank_window_2pass(const unsigned long long *K, uint32_t n, unsig
 // offs[i] = pixel offset | status << 30 (status 0 undecided, 1 accepted, 2 rejected) in the first half of
 // the buffer, and the second half becomes an open-addressing table of 2 * sort_cap 16-bit slots
 // (pixel offset -> rank, verified against offs[]; 0xFFFF = empty; load factor <= 1/2).
-constexpr uint32_t kOffMask = 0x3FFFFFFFu;
 
 __device__ __forceinline__ uint32_t slot_hash(uint32_t q, int hshift) { return (q * 2654435761u) >> hshift; }
 
@@ -1299,7 +1324,7 @@ __global__ __launch_bounds__(kST) void corner_select_kernel(
         if (R == 0) N = want_max;
         while (true) {
             uint32_t got = N, n_kept = 0;
-            if (!rank_window_2pass(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept)) {
+            if (!rank_window_2pass(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept, E, w)) {
                 if (!compacted) compact_keys();
                 n_kept = n;
                 got = N < n ? N : n;
@@ -1750,7 +1775,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
             VsProfScope ps(ctx, "min_eigen_kernel");
             const int segs = h >= 135 ? (h + 45) / 90 : 1;   // about 90 rows per wave
             const int seg_rows = vs_div_up(h, segs);
-            dim3 grid(vs_div_up(w, kSOwn), vs_div_up(segs, 4), frames);
+            dim3 grid(vs_div_up(w, kSW), vs_div_up(segs, 4), frames);
             min_eigen_stream_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, keys, counts, key_cap, seg_rows);
         }
         {   // frames with a negative maximum (not seen in practice) are redone the two-pass way
