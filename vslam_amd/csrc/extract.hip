@@ -1707,6 +1707,114 @@ __global__ __launch_bounds__(kKT) void rbrief_kernel(const uint8_t *__restrict__
     desc[((size_t)f * kp_stride + kp) * VSLAM_DESC_BYTES + byte] = (uint8_t)val;
 }
 
+// The same descriptor with the keypoint's patch staged through LDS (width % 4 == 0).
+// The direct form is a chain of dependent round trips per workgroup of 8 keypoints (pattern, keypoint, 16
+// scattered byte loads per lane, each 64 separate addresses for the texture addresser).  Here
+//  * the pattern is rotated once per launch (rbrief_rotate_kernel) instead of once per workgroup,
+//  * a workgroup walks through 64 keypoints, 8 at a time; the 32 lanes of a keypoint copy its patch rows
+//    (2R+1 rows of 48 bytes, R = the largest rotated offset; dword loads, one or two cache lines per row) into
+//    LDS and take the 16 samples per lane from there,
+//  * the patch loads of the next 8 keypoints are in flight while the current 8 are sampled (two LDS buffers).
+// Sample offsets are kept transposed ([sample][byte]) so the 32 lanes of a keypoint read 32 consecutive words.
+constexpr int kRPitch = 48;     // bytes per staged patch row (12 dwords: 2 * 22 + 1 columns plus alignment slack)
+constexpr int kRMax = 22;       // largest |offset| of a 31x31 pattern under any rotation (15 * sqrt(2))
+constexpr int kRRows = 2 * kRMax + 1;
+constexpr int kRGroups = 8;     // groups of 8 keypoints per workgroup
+constexpr int kRLoads = (kRRows * (kRPitch / 4) + 31) / 32;   // patch dwords per lane, worst case
+
+// table[i] = (iy << 16) | (ix & 0xFFFF) for sample i (test i / 2, side i & 1), table[512] = max(|ix|, |iy|)
+__global__ __launch_bounds__(512) void rbrief_rotate_kernel(const int8_t *__restrict__ pattern, float ca, float sa,
+                                                            int32_t *__restrict__ table) {
+    __shared__ int s_R;
+    const int i = threadIdx.x;
+    if (i == 0) s_R = 0;
+    __syncthreads();
+    const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
+    const float a1 = px * ca, a2 = py * sa, b1 = px * sa, b2 = py * ca;
+    const float rx = a1 - a2, ry = b1 + b2;
+    const int ix = (int)rintf(rx), iy = (int)rintf(ry);
+    table[i] = (int32_t)(((uint32_t)iy << 16) | ((uint32_t)ix & 0xFFFFu));
+    atomicMax(&s_R, max(abs(ix), abs(iy)));
+    __syncthreads();
+    if (i == 0) table[512] = s_R;
+}
+
+__global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restrict__ blurred, int w, int h,
+                                                         const float *__restrict__ xy, const int32_t *__restrict__ n_arr,
+                                                         int kp_stride, const int32_t *__restrict__ table,
+                                                         uint8_t *__restrict__ desc, int frames, int per_frame) {
+    __shared__ int s_off[16][32];   // [2 * bit + side][byte]: offset relative to the centre, in the staged patch (or the image)
+    __shared__ uint32_t s_patch[2][kKT / 32][kRRows * (kRPitch / 4)];
+    const int tid = threadIdx.x;
+    int f, bx;
+    vs_xcd_item_block(blockIdx.x, per_frame, f, bx);
+    if (f >= frames) return;
+    const int n = n_arr[f];
+    const int kp0 = bx * (kRGroups * (kKT / 32));
+    if (kp0 >= n) return;   // whole workgroup
+    const int R = table[512];
+    const bool staged = R <= kRMax;
+    for (int i = tid; i < 512; i += kKT) {
+        const int32_t e = table[i];
+        const int ix = (int)(int16_t)(e & 0xFFFF), iy = e >> 16;
+        const int t = i >> 1, byte = t >> 3, bit = t & 7;
+        s_off[2 * bit + (i & 1)][byte] = staged ? iy * kRPitch + ix : iy * w + ix;
+    }
+    const int slot = tid >> 5, l32 = tid & 31;
+    const uint8_t *img = blurred + (size_t)f * w * h;
+    const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)f * kp_stride;
+    int cxs[kRGroups], cys[kRGroups];   // this slot's keypoint of every group (a group's 32 lanes read the same one)
+#pragma unroll
+    for (int g = 0; g < kRGroups; g++) {
+        const int kp = kp0 + g * (kKT / 32) + slot;
+        const float2 p = kp < n ? P[kp] : make_float2(31.f, 31.f);
+        cxs[g] = (int)rintf(p.x);
+        cys[g] = (int)rintf(p.y);
+    }
+    const int total = (2 * R + 1) * (kRPitch / 4);
+    uint32_t pre[kRLoads];
+    auto prefetch = [&](int cx, int cy, bool live) {
+        if (!staged || !live) return;
+        const uint8_t *src = img + (size_t)(cy - R) * w + ((cx - R) & ~3);
+#pragma unroll
+        for (int k = 0; k < kRLoads; k++) {
+            const int j = l32 + 32 * k;
+            if (j < total) {
+                const int r = j / (kRPitch / 4), c = j - r * (kRPitch / 4);
+                pre[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * w + 4 * c);
+            }
+        }
+    };
+    prefetch(cxs[0], cys[0], kp0 + slot < n);
+#pragma unroll
+    for (int g = 0; g < kRGroups; g++) {
+        const int kp = kp0 + g * (kKT / 32) + slot;
+        const bool live = kp < n;
+        if (staged && live) {
+#pragma unroll
+            for (int k = 0; k < kRLoads; k++) {
+                const int j = l32 + 32 * k;
+                if (j < total) s_patch[g & 1][slot][j] = pre[k];
+            }
+        }
+        __syncthreads();   // also orders the first s_off reads after their writes
+        if (g + 1 < kRGroups) prefetch(cxs[g + 1], cys[g + 1], kp + (kKT / 32) < n);
+        if (live) {
+            const int cx = cxs[g], cy = cys[g];
+            const uint8_t *pb = staged ? reinterpret_cast<const uint8_t *>(s_patch[g & 1][slot]) + R * kRPitch + (cx - ((cx - R) & ~3))
+                                       : img + (size_t)cy * w + cx;
+            uint32_t val = 0;
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const int t0 = pb[s_off[2 * bit][l32]];
+                const int t1 = pb[s_off[2 * bit + 1][l32]];
+                val |= (uint32_t)(t0 < t1) << bit;
+            }
+            desc[((size_t)f * kp_stride + kp) * VSLAM_DESC_BYTES + l32] = (uint8_t)val;
+        }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1845,8 +1953,18 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
     {
         VsProfScope ps(ctx, "rbrief_kernel");
         const int per_frame = vs_div_up(kp_stride, kKT / 32);
-        rbrief_kernel<<<vs_xcd_grid(frames, per_frame), kKT, 0, ctx->stream>>>(blurred, w, h, xy_out, n_out, kp_stride, ca,
-                                                                                sa, pattern, desc, frames, per_frame);
+        if (w % 4 == 0 && (reinterpret_cast<uintptr_t>(blurred) & 3) == 0) {
+            int32_t *table = nullptr;
+            int rc = vs_arena_get(ctx, "rbrief.table", sizeof(int32_t) * 513, (void **)&table);
+            if (rc) return rc;
+            rbrief_rotate_kernel<<<1, 512, 0, ctx->stream>>>(pattern, ca, sa, table);
+            const int per_frame_lds = vs_div_up(kp_stride, kRGroups * (kKT / 32));
+            rbrief_lds_kernel<<<vs_xcd_grid(frames, per_frame_lds), kKT, 0, ctx->stream>>>(
+                blurred, w, h, xy_out, n_out, kp_stride, table, desc, frames, per_frame_lds);
+        } else {
+            rbrief_kernel<<<vs_xcd_grid(frames, per_frame), kKT, 0, ctx->stream>>>(blurred, w, h, xy_out, n_out, kp_stride, ca,
+                                                                                    sa, pattern, desc, frames, per_frame);
+        }
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
