@@ -1621,6 +1621,101 @@ __global__ __launch_bounds__(256) void gaussian7_v4_kernel(const uint8_t *__rest
     }
 }
 
+// Streaming form (width % 4 == 0, height >= 4): one wave per 256-pixel column strip and row segment, the last
+// seven horizontally filtered rows rolling in registers, gray rows loaded straight from global memory three
+// rows ahead (no LDS, no barriers, no tile seams: the tile form filters 14 rows to produce 8).
+// Step t of a segment owning rows [ys, ye): filter gray row ys - 3 + t horizontally; from t = 6 on, output
+// row ys - 6 + t.  Same Q8 taps, Q16 accumulate and rounding as gaussian7_v4_kernel.
+struct BlurState {
+    uint32_t rp[7][4];    // horizontally filtered rows (Q8, < 2^16)
+    uint32_t raw[3][3];   // prefetched gray dwords x-4, x, x+4
+};
+struct BlurArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    int w, h, ys, steps, x;
+    uint32_t voff_l, voff_c, voff_r;
+    bool edge, left_fix, right_fix, own_lane;
+};
+
+template <int K, int P>   // K = t % 7 (ring slot), P = t % 3 (prefetch slot)
+__device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int t) {
+    constexpr uint32_t W0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // taps 0..3
+    constexpr uint32_t W1 = 48u | (34u << 8) | (18u << 16);                 // taps 4..6
+    uint32_t d0 = st.raw[P][0];
+    const uint32_t d1 = st.raw[P][1];
+    uint32_t d2 = st.raw[P][2];
+    if (t + 3 < a.steps) {
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + t + 3, a.h) * a.w;
+        st.raw[P][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
+        st.raw[P][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
+        st.raw[P][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+    }
+    if (a.edge) {   // BORDER_REFLECT_101: columns -3..-1 are 3..1, columns w..w+2 are w-2..w-4
+        if (a.left_fix) d0 = __builtin_amdgcn_perm(d1, d1, 0x01020300u);
+        if (a.right_fix) d2 = __builtin_amdgcn_perm(d1, d1, 0x00000102u);
+    }
+    st.rp[K][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), W0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), W1, 0u, false), false);
+    st.rp[K][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), W0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), W1, 0u, false), false);
+    st.rp[K][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), W0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), W1, 0u, false), false);
+    st.rp[K][3] = __builtin_amdgcn_udot4(d1, W0, __builtin_amdgcn_udot4(d2, W1, 0u, false), false);
+    if (t < 6) return;
+    const int y = a.ys - 6 + t;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t sum = 18u * (st.rp[(K + 1) % 7][i] + st.rp[K][i]) + 34u * (st.rp[(K + 2) % 7][i] + st.rp[(K + 6) % 7][i]) +
+                             48u * (st.rp[(K + 3) % 7][i] + st.rp[(K + 5) % 7][i]) + 56u * st.rp[(K + 4) % 7][i];
+        packed |= ((sum + (1u << 15)) >> 16) << (8 * i);
+    }
+    if (a.own_lane) *reinterpret_cast<uint32_t *>(a.dst + (size_t)y * a.w + a.x) = packed;
+}
+
+__global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
+                                                               uint8_t *__restrict__ out, int seg_rows) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.z;
+    BlurArgs a;
+    a.ys = (blockIdx.y * 4 + wave) * seg_rows;
+    if (a.ys >= h) return;   // whole wave; no barriers in this kernel
+    const int ye = a.ys + seg_rows < h ? a.ys + seg_rows : h;
+    a.steps = ye - a.ys + 6;
+    a.w = w;
+    a.h = h;
+    a.src = gray + (size_t)f * w * h;
+    a.dst = out + (size_t)f * w * h;
+    const int x0 = blockIdx.x * 256;
+    a.x = x0 + 4 * lane;
+    a.own_lane = a.x < w;
+    a.edge = x0 == 0 || x0 + 256 + 4 > w;
+    a.left_fix = a.x == 0;
+    a.right_fix = a.x + 4 == w;
+    const int xc = a.x > w - 4 ? w - 4 : a.x;
+    a.voff_c = (uint32_t)xc;
+    a.voff_l = (uint32_t)(xc - 4 < 0 ? 0 : xc - 4);
+    a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
+    BlurState st;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
+        st.raw[k][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
+        st.raw[k][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
+        st.raw[k][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+    }
+    // 21 = lcm(7, 3) steps per trip keeps every ring index a compile-time constant
+    for (int t0 = 0; t0 < a.steps; t0 += 21) {
+#define VS_BLUR_STEP(J) if (t0 + (J) < a.steps) blur_step<(J) % 7, (J) % 3>(st, a, t0 + (J));
+        VS_BLUR_STEP(0) VS_BLUR_STEP(1) VS_BLUR_STEP(2) VS_BLUR_STEP(3) VS_BLUR_STEP(4) VS_BLUR_STEP(5) VS_BLUR_STEP(6)
+        VS_BLUR_STEP(7) VS_BLUR_STEP(8) VS_BLUR_STEP(9) VS_BLUR_STEP(10) VS_BLUR_STEP(11) VS_BLUR_STEP(12) VS_BLUR_STEP(13)
+        VS_BLUR_STEP(14) VS_BLUR_STEP(15) VS_BLUR_STEP(16) VS_BLUR_STEP(17) VS_BLUR_STEP(18) VS_BLUR_STEP(19) VS_BLUR_STEP(20)
+#undef VS_BLUR_STEP
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ORB::compute for provided keypoints: border filter (ordered) + steered BRIEF
 // ------------------------------------------------------------------------------------------
@@ -1771,17 +1866,23 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
         cxs[g] = (int)rintf(p.x);
         cys[g] = (int)rintf(p.y);
     }
-    const int total = (2 * R + 1) * (kRPitch / 4);
+    // dwords per staged row: columns (cx - R) & ~3 .. cx + R, at most 2R + 4 bytes; rows keep the 48-byte pitch
+    const int nd = staged ? (2 * R + 3) / 4 + 1 : 1;
+    const int total = (2 * R + 1) * nd;
+    const int r0 = l32 / nd, c0 = l32 - r0 * nd, dq = 32 / nd, dr = 32 - dq * nd;   // dword l32 + 32k = row r, column c
     uint32_t pre[kRLoads];
     auto prefetch = [&](int cx, int cy, bool live) {
         if (!staged || !live) return;
         const uint8_t *src = img + (size_t)(cy - R) * w + ((cx - R) & ~3);
+        int r = r0, c = c0;
 #pragma unroll
         for (int k = 0; k < kRLoads; k++) {
-            const int j = l32 + 32 * k;
-            if (j < total) {
-                const int r = j / (kRPitch / 4), c = j - r * (kRPitch / 4);
-                pre[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * w + 4 * c);
+            if (l32 + 32 * k < total) pre[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * w + 4 * c);
+            r += dq;
+            c += dr;
+            if (c >= nd) {
+                c -= nd;
+                r++;
             }
         }
     };
@@ -1791,10 +1892,16 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
         const int kp = kp0 + g * (kKT / 32) + slot;
         const bool live = kp < n;
         if (staged && live) {
+            int r = r0, c = c0;
 #pragma unroll
             for (int k = 0; k < kRLoads; k++) {
-                const int j = l32 + 32 * k;
-                if (j < total) s_patch[g & 1][slot][j] = pre[k];
+                if (l32 + 32 * k < total) s_patch[g & 1][slot][r * (kRPitch / 4) + c] = pre[k];
+                r += dq;
+                c += dr;
+                if (c >= nd) {
+                    c -= nd;
+                    r++;
+                }
             }
         }
         __syncthreads();   // also orders the first s_off reads after their writes
@@ -1931,8 +2038,10 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VS_REQUIRE(ctx, frames > 0 && w >= 4 && h >= 4, VSLAM_ERR_INVALID);
     VsProfScope ps(ctx, "gaussian7_kernel");
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
-        dim3 grid(vs_div_up(w, kG4W), vs_div_up(h, kG4H), frames);
-        gaussian7_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, out);
+        const int segs = h >= 135 ? (h + 45) / 90 : 1;   // about 90 rows per wave
+        const int seg_rows = vs_div_up(h, segs);
+        dim3 grid(vs_div_up(w, 256), vs_div_up(segs, 4), frames);
+        gaussian7_stream_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, out, seg_rows);
     } else {
         dim3 grid(vs_div_up(w, kBTW), vs_div_up(h, kBTH), frames);
         gaussian7_kernel<<<grid, kBT, 0, ctx->stream>>>(gray, w, h, out);
