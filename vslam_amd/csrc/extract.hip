@@ -209,33 +209,17 @@ __device__ __forceinline__ void sqrt_rn4(const float t[4], float out[4]) {
     }
 }
 
-// FUSED = false: plain cornerMinEigenVal (tile owns all 256x32 pixels it computes).
-// FUSED = true : the same strip computation, but tiles overlap by one lane / one row on every side
-//   (owned region 248x30), the responses also go to an LDS tile, and after one barrier every owned
-//   pixel is tested for being a 3x3 maximum, which replaces a second pass over the response image.
-//   The corner threshold needs the frame's maximum, which is not known yet, so candidates are
-//   prefiltered with the running maximum (always <= the final one, hence a superset) and
-//   corner_select_kernel applies the exact threshold.  Valid when the final maximum is >= 0 (then
-//   "3x3 maximum of the thresholded image" == "3x3 maximum of the raw image and above threshold");
-//   frames with a negative maximum are redone by corner_candidates_v4_kernel.
-template <bool FUSED>
+// Plain cornerMinEigenVal for vslam_min_eigen (the front-end path uses min_eigen_stream_kernel below, which
+// follows this kernel's arithmetic): a 256x32 tile per workgroup, every pixel of it owned.
 __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__restrict__ gray, int w, int h,
                                                            float *__restrict__ eig,
-                                                           uint32_t *__restrict__ frame_max, double quality,
-                                                           unsigned long long *__restrict__ keys,
-                                                           uint32_t *__restrict__ counts, size_t key_cap) {
+                                                           uint32_t *__restrict__ frame_max) {
     __shared__ uint32_t G[kE4H + 4][kE4C];   // bytes x0-4 .. x0+259 of raw rows y0-2 .. y0+33
-    __shared__ uint32_t s_max, s_cnt, s_base;
-    __shared__ __align__(16) float ET[FUSED ? kE4H : 1][FUSED ? kE4W + 8 : 4];   // responses, columns x0-4 .. x0+259
+    __shared__ uint32_t s_max;
     const int f = blockIdx.z, tid = threadIdx.x;
-    const int x0 = FUSED ? blockIdx.x * (kE4W - 8) - 4 : blockIdx.x * kE4W;
-    const int y0 = FUSED ? blockIdx.y * (kE4H - 2) - 1 : blockIdx.y * kE4H;
+    const int x0 = blockIdx.x * kE4W, y0 = blockIdx.y * kE4H;
     const uint8_t *src = gray + (size_t)f * w * h;
-    const uint32_t seen_max = (FUSED && frame_max) ? frame_max[f] : 0u;   // loaded early, used after the strip loop
-    if (tid == 0) {
-        s_max = 0;
-        s_cnt = 0;
-    }
+    if (tid == 0) s_max = 0;
     for (int i = tid; i < (kE4H + 4) * kE4C; i += 256) {
         const int r = i / kE4C, c = i - r * kE4C;
         const int xs = x0 - 4 + 4 * c;
@@ -256,7 +240,6 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
     const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0);
     const float k1 = (float)scale, k0 = 2.0f * k1;
     const float ninf = -__builtin_inff();
-    const bool own_lane = !FUSED || (lane >= 1 && lane <= 62);
     // tiles whose 6-wide / 3-tall product windows never leave the image skip the mirror-sign logic
     const bool interior = x0 >= 4 && x0 + kE4W + 4 <= w && y0 >= 2 && y0 + kE4H + 2 <= h;
     float emax = ninf;
@@ -325,13 +308,9 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
                         sqrt_rn4(tt, rt);
 #pragma unroll
                         for (int i = 0; i < 4; i++) e4[i] = apc[i] - rt[i];
-                        const bool own = own_lane && (!FUSED || (lr >= 1 && lr <= kE4H - 2));
-                        if (own) {
-                            emax = max3_nonan(max3_nonan(e4[0], e4[1], e4[2]), e4[3], emax);
-                            *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
-                        }
+                        emax = max3_nonan(max3_nonan(e4[0], e4[1], e4[2]), e4[3], emax);
+                        *reinterpret_cast<float4 *>(eig + ((size_t)f * h + y) * w + x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
                     }
-                    if (FUSED) *reinterpret_cast<float4 *>(&ET[lr][4 * lane + 4]) = make_float4(e4[0], e4[1], e4[2], e4[3]);
                 }
 #pragma unroll
                 for (int i = 0; i < 12; i++) {
@@ -340,9 +319,6 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
                 }
             }
         }
-    } else if (FUSED) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) *reinterpret_cast<float4 *>(&ET[grp * 8 + k][4 * lane + 4]) = make_float4(ninf, ninf, ninf, ninf);
     }
     const uint32_t kmax = emax == ninf ? 0u : f2ord(emax);   // 0 is the identity of the ordered-key max
     if (frame_max) {
@@ -356,70 +332,17 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
         __syncthreads();
         if (tid == 0) atomicMax(&frame_max[f], s_max);   // fire and forget
     }
-    if (!FUSED) return;
-    __syncthreads();
-
-    // ---- 3x3 maxima of the owned pixels (lanes 1..62, tile rows 1..30), prefiltered by the running maximum
-    // running maximum = what other tiles had published when this one started, or this tile's own
-    const uint32_t run_max = seen_max > s_max ? seen_max : s_max;
-    const float thr_p = (float)((double)ord2f(run_max) * quality);
-    uint32_t cmask = 0;   // bit (8 rows x 4 pixels) set where this lane found a candidate
-    if (own_lane && x >= 0 && x < w) {
-        // rolling rows: the centre values (columns x .. x+3) and the horizontal 3-maxima around them; the
-        // 3x3 maximum (centre included) is then one more max3 down the three rows.  No NaNs in ET.
-        float ctr[3][4], hm[3][4];
-#pragma unroll
-        for (int k = 0; k < 10; k++) {
-            const int lr = grp * 8 + k - 1;   // tile row being loaded (0 .. 31 where it exists)
-            if (lr >= 0 && lr < kE4H) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(&ET[lr][4 * lane + 4]);
-                const float lf = ET[lr][4 * lane + 3], rg = ET[lr][4 * lane + 8];
-                ctr[k % 3][0] = c4.x; ctr[k % 3][1] = c4.y; ctr[k % 3][2] = c4.z; ctr[k % 3][3] = c4.w;
-                hm[k % 3][0] = max3_nonan(lf, c4.x, c4.y);
-                hm[k % 3][1] = max3_nonan(c4.x, c4.y, c4.z);
-                hm[k % 3][2] = max3_nonan(c4.y, c4.z, c4.w);
-                hm[k % 3][3] = max3_nonan(c4.z, c4.w, rg);
-            }
-            if (k >= 2) {
-                const int tr = lr - 1;   // row under test
-                const int y = y0 + tr;
-                if (tr >= 1 && tr <= kE4H - 2 && y >= 0 && y < h) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float v = ctr[(k - 1) % 3][i];
-                        const float m = max3_nonan(hm[(k - 2) % 3][i], hm[(k - 1) % 3][i], hm[k % 3][i]);
-                        const int xx = x + i;
-                        const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v > thr_p && !(m > v);
-                        if (cand) cmask |= 1u << (4 * (k - 2) + i);
-                    }
-                }
-            }
-        }
-    }
-    const int nk = __popc(cmask);
-    uint32_t my_off = 0;
-    if (nk) my_off = atomicAdd(&s_cnt, (uint32_t)nk);
-    __syncthreads();
-    if (tid == 0 && s_cnt) s_base = atomicAdd(&counts[f], s_cnt);
-    __syncthreads();
-    size_t pos = (size_t)s_base + my_off;
-    while (cmask) {
-        const int b = __ffs(cmask) - 1;
-        cmask &= cmask - 1;
-        const int lr = grp * 8 + (b >> 2), i = b & 3;
-        const float v = ET[lr][4 * lane + 4 + i];
-        if (pos < key_cap)
-            keys[(size_t)f * key_cap + pos] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)((y0 + lr) * w + x + i);
-        pos++;
-    }
 }
 
 // ------------------------------------------------------------------------------------------
 // Streaming form of the fused response + 3x3-maxima kernel (width % 4 == 0)
 // ------------------------------------------------------------------------------------------
-// One wave owns a column strip (64 lanes x 4 pixels) and walks down a segment of rows.  Everything that the tile form recomputed at tile seams rolls in registers
-// instead: the two previous rows of horizontal Sobel parts, the two previous rows of horizontal product
-// sums, the two previous rows of responses and of their horizontal 3-maxima.  Gray rows come straight from
+// One wave owns a column strip (64 lanes x 4 pixels) and walks down a segment of rows.  Everything that the
+// tile form recomputes at tile seams rolls in registers instead: the two previous rows of horizontal Sobel
+// parts, the two previous rows of horizontal product sums, the two previous rows of responses and of their
+// horizontal 3-maxima.  The corner threshold needs the frame's maximum, which is not known yet, so candidates
+// are prefiltered with a running maximum (always <= the final one, hence a superset) and
+// corner_select_kernel applies the exact threshold.  Gray rows come straight from
 // global memory (three coalesced dwords per lane and row, issued three rows ahead), responses of the
 // neighbouring lanes come through DPP wave shifts, so the kernel uses no LDS except the candidate queue
 // and has no barriers.  Arithmetic and its order are those of min_eigen_v4_kernel (see there).
@@ -687,12 +610,6 @@ __global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__
     stream_flush(a, qn, lane);
 }
 
-// frames whose maximum response is negative cannot use the fused candidates: forget them
-__global__ void negative_max_reset_kernel(const uint32_t *__restrict__ frame_max, uint32_t *__restrict__ counts, int frames) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < frames && ord2f(frame_max[f]) < 0.f) counts[f] = 0;
-}
-
 // ------------------------------------------------------------------------------------------
 // threshold + 3x3 local maximum -> candidate keys (response << 32 | pixel offset)
 // ------------------------------------------------------------------------------------------
@@ -743,80 +660,6 @@ __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
                 cand = (m == v);   // val == dilate(val) on the thresholded image
             }
             if (cand) mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + x);
-        }
-    }
-    uint32_t my_off = 0;
-    if (nk) my_off = atomicAdd(&s_cnt, (uint32_t)nk);
-    __syncthreads();
-    if (tid == 0 && s_cnt) s_base = atomicAdd(&counts[f], s_cnt);
-    __syncthreads();
-    for (int i = 0; i < nk; i++) {
-        const size_t pos = (size_t)s_base + my_off + i;
-        if (pos < key_cap) keys[(size_t)f * key_cap + pos] = mykeys[i];
-    }
-}
-
-// Vectorised form (width % 4 == 0): 256x16 tile, one lane = 4 adjacent pixels x 4 rows, response
-// rows staged in LDS with float4 loads.
-constexpr int kC4W = 256, kC4H = 16, kC4C = kC4W + 8;
-
-__global__ __launch_bounds__(256) void corner_candidates_v4_kernel(
-    const float *__restrict__ eig, int w, int h, const uint32_t *__restrict__ frame_max, double quality,
-    unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
-    size_t key_cap, int only_negative_max) {
-    __shared__ __align__(16) float E[kC4H + 2][kC4C];   // columns x0-4 .. x0+259
-    __shared__ uint32_t s_cnt, s_base;
-    const int f = blockIdx.z, tid = threadIdx.x;
-    if (only_negative_max && !(ord2f(frame_max[f]) < 0.f)) return;
-    const int x0 = blockIdx.x * kC4W, y0 = blockIdx.y * kC4H;
-    const float *src = eig + (size_t)f * w * h;
-    const float thr = (float)((double)ord2f(frame_max[f]) * quality);
-    const float ninf = -__builtin_inff();
-    if (tid == 0) s_cnt = 0;
-    for (int i = tid; i < (kC4H + 2) * (kC4C / 4); i += 256) {
-        const int r = i / (kC4C / 4), c = i - r * (kC4C / 4);
-        const int yy = y0 - 1 + r, xs = x0 - 4 + 4 * c;
-        float4 v = make_float4(ninf, ninf, ninf, ninf);
-        if (yy >= 0 && yy < h && xs >= 0 && xs + 3 < w) {
-            v = *reinterpret_cast<const float4 *>(src + (size_t)yy * w + xs);
-            v.x = v.x > thr ? v.x : 0.f;   // THRESH_TOZERO; outside the image stays -inf (dilate ignores it)
-            v.y = v.y > thr ? v.y : 0.f;
-            v.z = v.z > thr ? v.z : 0.f;
-            v.w = v.w > thr ? v.w : 0.f;
-        }
-        *reinterpret_cast<float4 *>(&E[r][4 * c]) = v;
-    }
-    __syncthreads();
-    const int lane = tid & 63, grp = tid >> 6;
-    const int x = x0 + 4 * lane;
-    unsigned long long mykeys[16];
-    int nk = 0;
-    if (x < w) {
-        float win[3][6];   // rolling rows: columns x-1 .. x+4
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int r = grp * 4 + k;   // E row; image row y0 - 1 + r
-            float *dst = win[k % 3];
-            const float4 c4 = *reinterpret_cast<const float4 *>(&E[r][4 * lane + 4]);
-            dst[0] = E[r][4 * lane + 3];
-            dst[1] = c4.x; dst[2] = c4.y; dst[3] = c4.z; dst[4] = c4.w;
-            dst[5] = E[r][4 * lane + 8];
-            if (k >= 2) {
-                const int y = y0 + grp * 4 + (k - 2);
-                if (y < h) {
-                    const float *up = win[(k - 2) % 3], *mid = win[(k - 1) % 3], *dn = win[k % 3];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float v = mid[i + 1];
-                        // no NaNs here, so fmaxf (v_max3_f32) is the plain maximum of the 8 neighbours
-                        const float m = fmaxf(fmaxf(fmaxf(up[i], up[i + 1]), fmaxf(up[i + 2], mid[i])),
-                                              fmaxf(fmaxf(mid[i + 2], dn[i]), fmaxf(dn[i + 1], dn[i + 2])));
-                        const int xx = x + i;
-                        const bool cand = xx >= 1 && xx < w - 1 && y >= 1 && y < h - 1 && v != 0.f && !(m > v);
-                        if (cand) mykeys[nk++] = ((unsigned long long)f2ord(v) << 32) | (uint32_t)(y * w + xx);
-                    }
-                }
-            }
         }
     }
     uint32_t my_off = 0;
@@ -1565,67 +1408,11 @@ __global__ __launch_bounds__(kBT) void gaussian7_kernel(const uint8_t *__restric
 // is two v_dot4_u32_u8 per pixel on byte windows cut with v_alignbyte, its results stay in a
 // rolling 7-row register window, and the column pass runs straight from those registers, so the
 // kernel reads each gray byte once from HBM and writes each output byte once as a dword store.
-constexpr int kG4W = 256, kG4H = 32, kG4C = kG4W / 4 + 2;
-
-__global__ __launch_bounds__(256) void gaussian7_v4_kernel(const uint8_t *__restrict__ gray, int w, int h,
-                                                           uint8_t *__restrict__ out) {
-    __shared__ uint32_t G[kG4H + 6][kG4C];   // bytes x0-4 .. x0+259 of rows y0-3 .. y0+34
-    const int f = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * kG4W, y0 = blockIdx.y * kG4H;
-    const uint8_t *src = gray + (size_t)f * w * h;
-    for (int i = tid; i < (kG4H + 6) * kG4C; i += 256) {
-        const int r = i / kG4C, c = i - r * kG4C;
-        const int xs = x0 - 4 + 4 * c;
-        const uint8_t *row = src + (size_t)reflect101(y0 - 3 + r, h) * w;
-        uint32_t v;
-        if (xs >= 0 && xs + 3 < w) {
-            v = *reinterpret_cast<const uint32_t *>(row + xs);
-        } else {
-            v = (uint32_t)row[reflect101(xs, w)] | ((uint32_t)row[reflect101(xs + 1, w)] << 8) |
-                ((uint32_t)row[reflect101(xs + 2, w)] << 16) | ((uint32_t)row[reflect101(xs + 3, w)] << 24);
-        }
-        G[r][c] = v;
-    }
-    __syncthreads();
-    const int lane = tid & 63, grp = tid >> 6;
-    const int x = x0 + 4 * lane;
-    if (x >= w) return;
-    constexpr uint32_t W0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // taps 0..3
-    constexpr uint32_t W1 = 48u | (34u << 8) | (18u << 16);                 // taps 4..6
-    uint32_t rp[7][4];
-#pragma unroll
-    for (int k = 0; k < 14; k++) {
-        const int r = grp * 8 + k;
-        const uint32_t d0 = G[r][lane], d1 = G[r][lane + 1], d2 = G[r][lane + 2];
-        uint32_t *dst = rp[k % 7];
-        dst[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), W0,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), W1, 0u, false), false);
-        dst[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), W0,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), W1, 0u, false), false);
-        dst[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), W0,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), W1, 0u, false), false);
-        dst[3] = __builtin_amdgcn_udot4(d1, W0, __builtin_amdgcn_udot4(d2, W1, 0u, false), false);
-        if (k >= 6) {
-            const int y = y0 + grp * 8 + (k - 6);
-            if (y < h) {
-                uint32_t packed = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t sum = 18u * (rp[(k - 6) % 7][i] + rp[k % 7][i]) + 34u * (rp[(k - 5) % 7][i] + rp[(k - 1) % 7][i]) +
-                                         48u * (rp[(k - 4) % 7][i] + rp[(k - 2) % 7][i]) + 56u * rp[(k - 3) % 7][i];
-                    packed |= ((sum + (1u << 15)) >> 16) << (8 * i);
-                }
-                *reinterpret_cast<uint32_t *>(out + ((size_t)f * h + y) * w + x) = packed;
-            }
-        }
-    }
-}
-
 // Streaming form (width % 4 == 0, height >= 4): one wave per 256-pixel column strip and row segment, the last
 // seven horizontally filtered rows rolling in registers, gray rows loaded straight from global memory three
 // rows ahead (no LDS, no barriers, no tile seams: the tile form filters 14 rows to produce 8).
 // Step t of a segment owning rows [ys, ye): filter gray row ys - 3 + t horizontally; from t = 6 on, output
-// row ys - 6 + t.  Same Q8 taps, Q16 accumulate and rounding as gaussian7_v4_kernel.
+// row ys - 6 + t.  Same Q8 taps, Q16 accumulate and rounding as gaussian7_kernel.
 struct BlurState {
     uint32_t rp[7][4];    // horizontally filtered rows (Q8, < 2^16)
     uint32_t raw[3][3];   // prefetched gray dwords x-4, x, x+4
@@ -1948,7 +1735,7 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VsProfScope ps(ctx, "min_eigen_kernel");
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && ((reinterpret_cast<uintptr_t>(eig) & 15) == 0)) {
         dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), frames);
-        min_eigen_v4_kernel<false><<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits, 0.0, nullptr, nullptr, 0);
+        min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
     } else {
         dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
         min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
@@ -1993,12 +1780,9 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
             dim3 grid(vs_div_up(w, kSW), vs_div_up(segs, 4), frames);
             min_eigen_stream_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, keys, counts, key_cap, seg_rows);
         }
-        {   // frames with a negative maximum (not seen in practice) are redone the two-pass way
-            VsProfScope ps(ctx, "corner_candidates_kernel");
-            negative_max_reset_kernel<<<vs_div_up(frames, 256), 256, 0, ctx->stream>>>(fmax, counts, frames);
-            dim3 grid(vs_div_up(w, kC4W), vs_div_up(h, kC4H), frames);
-            corner_candidates_v4_kernel<<<grid, 256, 0, ctx->stream>>>(eig, w, h, fmax, quality, keys, counts, key_cap, 1);
-        }
+        // A frame whose maximum response is negative has no corners (its threshold max * quality lies above every
+        // response, THRESH_TOZERO clears the image and zeros are not corners); corner_select_kernel's exact
+        // threshold drops every key of such a frame, so it needs no special handling here.
     } else {
         if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, fmax))) return rc;
         VsProfScope ps(ctx, "corner_candidates_kernel");
