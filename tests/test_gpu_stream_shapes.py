@@ -1,0 +1,87 @@
+"""Shape edge cases of the streaming kernels (corner response + candidates, 7x7 blur) and of the staged
+descriptor kernel, against the oracle, bit for bit.
+
+The streaming kernels split a frame into 256-pixel column strips and row segments; the cases below put
+frame borders on, next to and between strip / segment seams, and include the smallest frames the
+vectorised path accepts.  The descriptor cases cover a rotation whose sample offsets need the widest
+staged patch and a pattern whose offsets exceed it (direct sampling)."""
+import numpy as np
+import pytest
+import torch
+
+from vslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+# (w, h): w % 4 == 0 takes the streaming path
+SHAPES = [(4, 4), (8, 5), (12, 135), (252, 40), (256, 91), (260, 136), (264, 181), (512, 33), (516, 271), (1028, 64)]
+
+
+def textured(w, h, seed, n=2):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    # blocks give real corners and plateaus on top of the noise
+    for f in range(n):
+        for _ in range(max(1, w * h // 600)):
+            x, y = rng.integers(0, w), rng.integers(0, h)
+            g[f, y:y + rng.integers(2, 9), x:x + rng.integers(2, 9)] = rng.integers(0, 256)
+    return g
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+def test_blur_and_corners_on_seams(ctx, oracle, w, h):
+    gray = textured(w, h, 1000 + w + h)
+    t = torch.from_numpy(gray).cuda()
+    blur = ctx.gaussian7(t).cpu().numpy()
+    maxc = 300
+    xy, n = ctx.good_features(t, maxc)
+    ctx.synchronize()
+    xy, n = xy.cpu().numpy(), n.cpu().numpy()
+    for f in range(gray.shape[0]):
+        assert np.array_equal(blur[f], oracle.gaussian7(gray[f])), (w, h, f)
+        ref = oracle.good_features(gray[f], maxc)
+        assert n[f] == len(ref), (w, h, f, n[f], len(ref))
+        assert np.array_equal(xy[f, :n[f]], ref), (w, h, f)
+
+
+def test_corners_on_strip_seam_columns(ctx, oracle):
+    """Isolated bright dots placed exactly on the first / last column of a strip (x = 255, 256, 511, 512) and
+    next to them: those candidates are emitted unverified by the detector and completed by the selection."""
+    w, h = 772, 96
+    rng = np.random.default_rng(7)
+    gray = rng.integers(100, 110, (2, h, w), dtype=np.uint8)
+    for f in range(2):
+        for y in range(6, h - 6, 9):
+            for x in (254, 255, 256, 257, 510, 511, 512, 513, 767, 768, 769):
+                if rng.random() < 0.7:
+                    gray[f, y + (x % 3), x] = rng.integers(180, 256)
+    t = torch.from_numpy(gray).cuda()
+    for maxc in (50, 2000):
+        xy, n = ctx.good_features(t, maxc, min_distance=1.0)
+        xy, n = xy.cpu().numpy(), n.cpu().numpy()
+        for f in range(2):
+            ref = oracle.good_features(gray[f], maxc, min_dist=1.0)
+            assert n[f] == len(ref), (maxc, f, n[f], len(ref))
+            assert np.array_equal(xy[f, :n[f]], ref), (maxc, f)
+
+
+@pytest.mark.parametrize("angle_deg,scale", [(45.0, 1.15), (-133.0, 1.0), (0.0, 1.0), (0.0, 1.9), (10.0, 1.7)])
+def test_describe_other_rotations_and_wide_patterns(ctx, oracle, angle_deg, scale):
+    """45 degrees stretches a +-15 pattern to +-21 (the widest staged patch); patterns scaled to +-25 exceed the
+    staged patch and are sampled from the image directly (still inside the 31-pixel keypoint border)."""
+    w, h = 320, 240
+    gray = textured(w, h, 99)
+    blur = ctx.gaussian7(torch.from_numpy(gray).cuda())
+    pat = np.clip(np.rint(synth.brief_pattern().astype(np.float32) * scale), -29, 29).astype(np.int8)
+    ca, sa = synth.keypoint_rotation(angle_deg)
+    rng = np.random.default_rng(3)
+    K = 700
+    pts = np.rint(np.stack([rng.uniform(0, w - 1, (2, K)), rng.uniform(0, h - 1, (2, K))], -1)).astype(np.float32)
+    n = np.array([K, 77], np.int32)
+    xy_out, desc, n_out = ctx.orb_describe(blur, torch.from_numpy(pts).cuda(), torch.from_numpy(n).cuda(), ca, sa,
+                                           torch.from_numpy(pat).cuda())
+    xy_out, desc, n_out, blur = xy_out.cpu().numpy(), desc.cpu().numpy(), n_out.cpu().numpy(), blur.cpu().numpy()
+    for f in range(2):
+        rd, keep = oracle.orb_describe(blur[f], pts[f, :n[f]], ca, sa, pat)
+        assert n_out[f] == len(keep), f
+        assert np.array_equal(desc[f, :len(keep)], rd), f

@@ -206,6 +206,20 @@ __device__ __forceinline__ uint32_t cvrng_next(uint64_t &state) {   // cv::RNG (
 // sum of squares of the CURRENT row i (set so at start-up and after each rotation of that row), so the
 // norms are recomputed from the rows where needed instead of being stored: same bits, and the LDS
 // footprint per lane drops by 64 B, which is what bounds this kernel's occupancy.
+// fabs(p) <= eps * sqrt(a * b) with eps = 2 * FLT_EPSILON = 2^-22, decided without the square root where that is
+// safe.  With y = |p| * 2^22 (exact) and x = fl(a * b) the test is y <= RN(sqrt(x)); rounding is monotone, so it
+// equals y * y <= x except when x lies within an ulp or so of y * y.  h = fl(y * y) decides every case in which h
+// and x differ by more than 2^-50 relative; if any lane of the wave is closer than that (or x is 0) the wave
+// evaluates the original expression.
+__device__ __forceinline__ bool jacobi_converged(double p, double a, double b) {
+    const double y = fabs(p) * 4194304.0;
+    const double x = a * b;
+    const double h = y * y;
+    const bool near = !(fabs(h - x) > x * 0x1p-50);   // also true for NaN / zero
+    if (__any(near)) return fabs(p) <= (double)(FLT_EPSILON * 2) * sqrt(x);
+    return h < x;
+}
+
 template <int M, int N, int N1, bool HASV>
 __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, float *extra_row) {
     static_assert(N1 == N || N1 == N + 1, "FULL_UV asks for at most one row beyond the rank here");
@@ -235,7 +249,7 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
                     a = __builtin_fma(di, di, a);   // W[i]
                     b = __builtin_fma(dj, dj, b);   // W[j]
                 }
-                if (fabs(p) <= (double)eps * sqrt(a * b)) continue;
+                if (jacobi_converged(p, a, b)) continue;
 
                 p *= 2;
                 const double beta = a - b;
