@@ -26,7 +26,6 @@ WORKLOADS = {
     "C5": (1920, 1080, 4000, 8192, 512),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # lanes x clock: 78.6 T lane-ops/s (1 op per lane per cycle)
 
 
 def algorithmic_bytes(kernel, w, h, K, H, M):
@@ -36,7 +35,6 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
     table = {
         "bgr2gray_kernel": 2 * (3 * px + px),
         "min_eigen_kernel": 2 * (px + 4 * px),
-        "corner_candidates_kernel": 2 * (4 * px + px),
         "corner_select_kernel": 2 * (K * 8),
         "gaussian7_kernel": 2 * (px + px),
         "keypoint_border_kernel": 2 * (K * 8 * 2),
@@ -52,11 +50,13 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
     return table.get(kernel, 0)
 
 
-# VALU issue slots per unit of work, counted in the gfx950 ISA of the inner loops;
-# f64-rate instructions count as two slots.
-VALU_SLOTS = {
-    "ransac_score_kernel": ("(hypothesis, match) evaluations", 62.0),
-    "match_knn2_kernel": ("(query, train) descriptor pairs", 21.0),
+# VALU issue time per unit of work: the instruction mix of the kernel's inner loop (gfx950 ISA)
+# priced with the per-instruction issue costs tools/valu_rate.hip measures on this GPU (cycles per wave
+# instruction per SIMD at the 2.4 GHz reference clock).  peak = 256 CUs x 4 SIMDs x 2.4 GHz issue cycles/s.
+VALU_PEAK_GCYC = 256 * 4 * 2.4
+VALU_CYCLES = {
+    "ransac_score_kernel": ("(hypothesis, match) evaluations per wave", 172.0),
+    "match_knn2_kernel": ("(query, train) descriptor pairs per wave", 74.0),
 }
 
 
@@ -64,12 +64,13 @@ def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/, C3 batch of 256 pairs);
     bench.py cannot collect PMC counters on itself."""
     import csv
+    import re
     path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic_final.csv")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         for r in csv.DictReader(f):
-            if r["kernel"].replace("_v4", "") == kernel:
+            if re.sub(r"_(v4|stream|lds)_kernel$", "_kernel", r["kernel"]) == kernel:
                 return (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
     return None
 
@@ -274,15 +275,25 @@ def main():
         result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                               "avg_launch_ms": top["ms_per_launch"]}
-        if top["kernel"] in VALU_SLOTS:
-            what, slots = VALU_SLOTS[top["kernel"]]
-            work = (H * m_prelim if top["kernel"] == "ransac_score_kernel" else float(n_kp.mean()) ** 2) * P
-            tops = work * slots / (top["ms_per_launch"] * 1e-3) / 1e12
-            result["roofline"]["valu"] = {"achieved": tops, "peak": VALU_PEAK_GOPS / 1e3, "unit": "T lane-slots/s",
-                                          "frac": tops / (VALU_PEAK_GOPS / 1e3), "work": what, "slots_per_unit": slots}
+        if top["kernel"] in VALU_CYCLES:
+            what, cyc = VALU_CYCLES[top["kernel"]]
+            work = (H * m_prelim if top["kernel"] == "ransac_score_kernel" else float(n_kp.mean()) ** 2) * P / 64.0
+            gcyc = work * cyc / (top["ms_per_launch"] * 1e-3) / 1e9
+            result["roofline"]["valu"] = {"achieved": gcyc, "peak": VALU_PEAK_GCYC, "unit": "G SIMD issue cycles/s",
+                                          "frac": gcyc / VALU_PEAK_GCYC, "work": what, "cycles_per_unit": cyc}
             result["roofline"]["note"] = ("this kernel is VALU-issue bound by construction (SURVEY.md 8d): its compulsory "
                                           "bytes are a rounding error next to its arithmetic, so the HBM fraction is "
-                                          "small by design; `valu` is the ceiling that binds")
+                                          "small by design; `valu` prices its instruction mix with the issue costs "
+                                          "tools/valu_rate.hip measures (a fraction near or above 1 means the kernel "
+                                          "issues as fast as that microbenchmark does)")
+        # the largest HBM-class (stencil) kernel, for the bandwidth view of the step
+        stencil = [k for k in kernels if k["kernel"] in ("min_eigen_kernel", "gaussian7_kernel", "bgr2gray_kernel")]
+        if stencil:
+            st = stencil[0]
+            result["roofline_stencil"] = {"kernel": st["kernel"], "bound": "hbm", "achieved": st["alg_GBps"],
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["alg_GBps"] / HBM_PEAK_GBS,
+                                          "traffic": pmc_traffic(st["kernel"]) if (args.workload == "C3" and P == WORKLOADS["C3"][4]) else None,
+                                          "avg_launch_ms": st["ms_per_launch"]}
         result["kernels"] = kernels
         result["profile_pass_ms_per_step"] = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels)
 
