@@ -528,13 +528,19 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
 __global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
                                                                float *__restrict__ eig, uint32_t *__restrict__ frame_max,
                                                                double quality, unsigned long long *__restrict__ keys,
-                                                               uint32_t *__restrict__ counts, size_t key_cap, int seg_rows) {
+                                                               uint32_t *__restrict__ counts, size_t key_cap, int seg_rows,
+                                                               int frames, int strips, int per_frame) {
     __shared__ unsigned long long queue[4][kSQ];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int f = blockIdx.z;
+    // all strips and segments of a frame run on one XCD: the cache lines two neighbouring strips (or segments)
+    // both touch are then fetched from HBM once, into that XCD's L2
+    int f, blk;
+    vs_xcd_item_block(blockIdx.x, per_frame, f, blk);
+    if (f >= frames) return;
+    const int strip = blk % strips, segblk = blk / strips;
     StreamArgs a;
-    a.ys = (blockIdx.y * 4 + wave) * seg_rows;
+    a.ys = (segblk * 4 + wave) * seg_rows;
     if (a.ys >= h) return;   // whole wave; the kernel has no barriers
     a.ye = a.ys + seg_rows < h ? a.ys + seg_rows : h;
     a.steps = a.ye - a.ys + 6;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__
     a.keys = keys + (size_t)f * key_cap;
     a.count = counts + f;
     a.key_cap = key_cap;
-    const int x0 = blockIdx.x * kSW;
+    const int x0 = strip * kSW;
     a.x = x0 + 4 * lane;
     a.own_lane = a.x < w;
     a.edge = x0 == 0 || x0 + kSW + 4 > w;
@@ -1415,7 +1421,7 @@ __global__ __launch_bounds__(kBT) void gaussian7_kernel(const uint8_t *__restric
 // row ys - 6 + t.  Same Q8 taps, Q16 accumulate and rounding as gaussian7_kernel.
 struct BlurState {
     uint32_t rp[7][4];    // horizontally filtered rows (Q8, < 2^16)
-    uint32_t raw[3][3];   // prefetched gray dwords x-4, x, x+4
+    uint32_t raw[7][3];   // prefetched gray dwords x-4, x, x+4 of the next seven rows
 };
 struct BlurArgs {
     const uint8_t *src;
@@ -1425,18 +1431,18 @@ struct BlurArgs {
     bool edge, left_fix, right_fix, own_lane;
 };
 
-template <int K, int P>   // K = t % 7 (ring slot), P = t % 3 (prefetch slot)
+template <int K>   // K = t % 7: ring slot of both the filtered row and the prefetched gray row
 __device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int t) {
     constexpr uint32_t W0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // taps 0..3
     constexpr uint32_t W1 = 48u | (34u << 8) | (18u << 16);                 // taps 4..6
-    uint32_t d0 = st.raw[P][0];
-    const uint32_t d1 = st.raw[P][1];
-    uint32_t d2 = st.raw[P][2];
-    if (t + 3 < a.steps) {
-        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + t + 3, a.h) * a.w;
-        st.raw[P][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
-        st.raw[P][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
-        st.raw[P][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+    uint32_t d0 = st.raw[K][0];
+    const uint32_t d1 = st.raw[K][1];
+    uint32_t d2 = st.raw[K][2];
+    if (t + 7 < a.steps) {   // the row seven steps ahead goes into the slot just consumed
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + t + 7, a.h) * a.w;
+        st.raw[K][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
+        st.raw[K][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
+        st.raw[K][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
     }
     if (a.edge) {   // BORDER_REFLECT_101: columns -3..-1 are 3..1, columns w..w+2 are w-2..w-4
         if (a.left_fix) d0 = __builtin_amdgcn_perm(d1, d1, 0x01020300u);
@@ -1462,12 +1468,16 @@ __device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int 
 }
 
 __global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
-                                                               uint8_t *__restrict__ out, int seg_rows) {
+                                                               uint8_t *__restrict__ out, int seg_rows, int frames,
+                                                               int strips, int per_frame) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int f = blockIdx.z;
+    int f, blk;   // a frame's strips and segments share an XCD (see min_eigen_stream_kernel)
+    vs_xcd_item_block(blockIdx.x, per_frame, f, blk);
+    if (f >= frames) return;
+    const int strip = blk % strips, segblk = blk / strips;
     BlurArgs a;
-    a.ys = (blockIdx.y * 4 + wave) * seg_rows;
+    a.ys = (segblk * 4 + wave) * seg_rows;
     if (a.ys >= h) return;   // whole wave; no barriers in this kernel
     const int ye = a.ys + seg_rows < h ? a.ys + seg_rows : h;
     a.steps = ye - a.ys + 6;
@@ -1475,7 +1485,7 @@ __global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__
     a.h = h;
     a.src = gray + (size_t)f * w * h;
     a.dst = out + (size_t)f * w * h;
-    const int x0 = blockIdx.x * 256;
+    const int x0 = strip * 256;
     a.x = x0 + 4 * lane;
     a.own_lane = a.x < w;
     a.edge = x0 == 0 || x0 + 256 + 4 > w;
@@ -1487,18 +1497,15 @@ __global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__
     a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
     BlurState st;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 7; k++) {   // steps >= 7 always (a segment has at least one row)
         const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
         st.raw[k][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
         st.raw[k][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
         st.raw[k][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
     }
-    // 21 = lcm(7, 3) steps per trip keeps every ring index a compile-time constant
-    for (int t0 = 0; t0 < a.steps; t0 += 21) {
-#define VS_BLUR_STEP(J) if (t0 + (J) < a.steps) blur_step<(J) % 7, (J) % 3>(st, a, t0 + (J));
+    for (int t0 = 0; t0 < a.steps; t0 += 7) {   // seven steps per trip keep every ring index a compile-time constant
+#define VS_BLUR_STEP(J) if (t0 + (J) < a.steps) blur_step<(J)>(st, a, t0 + (J));
         VS_BLUR_STEP(0) VS_BLUR_STEP(1) VS_BLUR_STEP(2) VS_BLUR_STEP(3) VS_BLUR_STEP(4) VS_BLUR_STEP(5) VS_BLUR_STEP(6)
-        VS_BLUR_STEP(7) VS_BLUR_STEP(8) VS_BLUR_STEP(9) VS_BLUR_STEP(10) VS_BLUR_STEP(11) VS_BLUR_STEP(12) VS_BLUR_STEP(13)
-        VS_BLUR_STEP(14) VS_BLUR_STEP(15) VS_BLUR_STEP(16) VS_BLUR_STEP(17) VS_BLUR_STEP(18) VS_BLUR_STEP(19) VS_BLUR_STEP(20)
 #undef VS_BLUR_STEP
     }
 }
@@ -1777,8 +1784,9 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
             VsProfScope ps(ctx, "min_eigen_kernel");
             const int segs = h >= 135 ? (h + 45) / 90 : 1;   // about 90 rows per wave
             const int seg_rows = vs_div_up(h, segs);
-            dim3 grid(vs_div_up(w, kSW), vs_div_up(segs, 4), frames);
-            min_eigen_stream_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, fmax, quality, keys, counts, key_cap, seg_rows);
+            const int strips = vs_div_up(w, kSW), per_frame = strips * vs_div_up(segs, 4);
+            min_eigen_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
+                gray, w, h, eig, fmax, quality, keys, counts, key_cap, seg_rows, frames, strips, per_frame);
         }
         // A frame whose maximum response is negative has no corners (its threshold max * quality lies above every
         // response, THRESH_TOZERO clears the image and zeros are not corners); corner_select_kernel's exact
@@ -1824,8 +1832,9 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
         const int segs = h >= 135 ? (h + 45) / 90 : 1;   // about 90 rows per wave
         const int seg_rows = vs_div_up(h, segs);
-        dim3 grid(vs_div_up(w, 256), vs_div_up(segs, 4), frames);
-        gaussian7_stream_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, out, seg_rows);
+        const int strips = vs_div_up(w, 256), per_frame = strips * vs_div_up(segs, 4);
+        gaussian7_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(gray, w, h, out, seg_rows, frames,
+                                                                                          strips, per_frame);
     } else {
         dim3 grid(vs_div_up(w, kBTW), vs_div_up(h, kBTH), frames);
         gaussian7_kernel<<<grid, kBT, 0, ctx->stream>>>(gray, w, h, out);
