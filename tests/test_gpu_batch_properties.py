@@ -1,0 +1,72 @@
+"""Size-independent properties of the whole path at the headline frame size (1280x720, 2000 keypoints,
+4096 hypotheses), where the oracle is too slow to check more than one pair directly
+(tests/test_gpu_extract.py::test_frontend_headline_size_one_pair does that one):
+
+* batch independence: a pair's outputs do not depend on which other pairs share the launch or on its slot —
+  the batch [A, B, A, A, B, ...] gives identical records for every copy of A (and of B), and they equal the
+  records of a launch holding A (or B) alone.  This is what guards the stages that exchange data between
+  workgroups of a frame (running response maximum, candidate queues, strip-edge candidates) against
+  timing-dependent results;
+* repeatability: two launches on the same inputs give identical bytes;
+* sharding independence: the result of a pair is the same whether it is computed as part of the full batch
+  or of the slice a rank would own (bench.py's N > 1 path shards exactly like this).
+"""
+import numpy as np
+import pytest
+import torch
+
+from vslam_amd import shard, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, K, HYP, THR = 1280, 720, 2000, 4096, 10.0
+
+
+def run(ctx, bgr, seeds):
+    P = bgr.shape[0] // 2
+    pat = torch.from_numpy(synth.brief_pattern()).cuda()
+    ca, sa = synth.keypoint_rotation()
+    out = ctx.frontend_pairs(torch.from_numpy(bgr).cuda(), P, K, ca, sa, pat,
+                             torch.from_numpy(seeds.view(np.int32)).cuda(), HYP, THR)
+    ctx.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def record(out, p, P):
+    """Everything the path produces for pair p (frames p and P + p), trimmed to the valid counts."""
+    n1, n2 = int(out["n"][p]), int(out["n"][P + p])
+    k = int(out["best"][p, 3])
+    return (n1, n2, out["xy"][p, :n1].tobytes(), out["xy"][P + p, :n2].tobytes(), out["desc"][p, :n1].tobytes(),
+            out["desc"][P + p, :n2].tobytes(), out["nodes"][p, :n1].tobytes(), out["nodes"][P + p, :n2].tobytes(),
+            out["best"][p].tobytes(), out["matches"][p, :k].tobytes(), out["F"][p].tobytes())
+
+
+def test_pairs_do_not_see_their_batch(ctx):
+    base = synth.frames_numpy(0x5EED0002, 2, W, H)          # pairs A = (0, 2), B = (1, 3)
+    last, cur = base[:2], base[2:]
+    order = [0, 1, 0, 0, 1, 0, 1, 1, 0, 1, 1, 0]            # 12 pairs, 24 frames
+    bgr = np.concatenate([last[order], cur[order]])
+    seed_of = np.array([0xA5A50001, 0xA5A50002], np.uint32)
+    seeds = seed_of[order]
+    P = len(order)
+    out = run(ctx, bgr, seeds)
+    again = run(ctx, bgr, seeds)
+    alone = [run(ctx, np.concatenate([last[i:i + 1], cur[i:i + 1]]), seed_of[i:i + 1]) for i in range(2)]
+    ref = [record(alone[i], 0, 1) for i in range(2)]
+    assert ref[0] != ref[1]
+    for p, which in enumerate(order):
+        assert int(out["best"][p, 3]) >= 8 and int(out["n"][p]) > K // 2, p      # a real, non-degenerate result
+        assert record(out, p, P) == ref[which], (p, which)
+        assert record(again, p, P) == ref[which], (p, which)
+
+
+def test_a_rank_slice_equals_the_full_batch(ctx):
+    P, world = 6, 3
+    bgr = synth.frames_numpy(0x5EED0003, P, W, H)
+    seeds = shard.pair_seeds(0x5EED0003, 0, P)
+    full = run(ctx, bgr, seeds)
+    for rank in range(world):
+        lo, hi = shard.shard_range(P, rank, world)
+        part = run(ctx, np.concatenate([bgr[lo:hi], bgr[P + lo:P + hi]]), shard.pair_seeds(0x5EED0003, lo, hi))
+        for p in range(lo, hi):
+            assert record(part, p - lo, hi - lo) == record(full, p, P), (rank, p)
