@@ -56,6 +56,18 @@ int vslam_dev_free(vslam_ctx *ctx, void *d_ptr);
 int vslam_copy_h2d(vslam_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int vslam_copy_d2h(vslam_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 
+/* Frame ingest (what replaces cv::VideoCapture's per-frame host Mat, src/vslam.cpp:54-60).
+ * Page-locked host buffers and uploads that run on the context's copy stream beside the kernels:
+ *   vslam_host_alloc / vslam_host_free   page-locked host memory (hipHostMalloc)
+ *   vslam_upload_async                   enqueue host -> device on the copy stream (returns at once)
+ *   vslam_upload_fence                   later work on the compute stream waits for every upload enqueued so far
+ *   vslam_upload_wait                    the calling thread waits for them (before a host buffer is refilled)  */
+int vslam_host_alloc(vslam_ctx *ctx, size_t bytes, void **h_out);
+int vslam_host_free(vslam_ctx *ctx, void *h_ptr);
+int vslam_upload_async(vslam_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int vslam_upload_fence(vslam_ctx *ctx);
+int vslam_upload_wait(vslam_ctx *ctx);
+
 /* per-kernel timing with HIP events on the context's stream (bench.py's roofline leg) */
 int vslam_prof_enable(vslam_ctx *ctx, int on);
 int vslam_prof_reset(vslam_ctx *ctx);
@@ -248,6 +260,17 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
                          const uint32_t *d_seeds, int hyp, float threshold,
                          float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
                          int32_t *d_matches, int32_t *d_best, float *d_F);
+
+/* The same path for a run of consecutive video frames, the shape of the reference's main loop
+ * (src/vslam.cpp:60-77: every new frame is matched against the previous one): extract each of the `frames`
+ * frames ONCE, then pair i = (frame i, frame i + 1) for i in [0, frames - 1).
+ * Per-frame outputs as in vslam_extract_features ([frames] slots); d_seeds, d_matches, d_best, d_F have
+ * frames - 1 slots.  frames >= 2.                                                              */
+int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
+                            int row_stride, const vslam_extract_params *params, int kp_stride,
+                            const uint32_t *d_seeds, int hyp, float threshold, float *d_xy,
+                            uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches,
+                            int32_t *d_best, float *d_F);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,114 @@
+"""Consecutive-frame entry point and the C++ capture loop against the oracle.
+
+* vslam_frontend_sequence: every frame extracted once, pair i = (frame i, frame i + 1) — per-frame features and
+  per-pair results equal the oracle's, and equal what vslam_frontend_pairs gives for the same pairs.
+* vslam::run_sequence (through its C entry point): raw BGR24 file -> record file; the records equal the oracle's
+  pair results and do not depend on the batch size (which moves the frame that consecutive batches share).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vslam_amd import build, records, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, MAXC, HYP, THR = 320, 240, 300, 64, 10.0
+
+
+def video(n_frames, seed):
+    """A short clip: the 'last' and 'current' halves of synthetic pairs interleaved, so neighbours match."""
+    fr = synth.frames_numpy(seed, (n_frames + 1) // 2, W, H)
+    half = fr.shape[0] // 2
+    clip = np.empty((2 * half, H, W, 3), np.uint8)
+    clip[0::2], clip[1::2] = fr[:half], fr[half:]
+    return np.ascontiguousarray(clip[:n_frames])
+
+
+def oracle_pairs(oracle, clip, seed, pat, ca, sa):
+    feats = [oracle.extract_features(f, MAXC, ca, sa, pat) for f in clip]
+    out = []
+    for i in range(len(clip) - 1):
+        a, b = feats[i], feats[i + 1]
+        out.append(oracle.match_features(a["xy"], a["desc"], b["xy"], b["desc"], int(np.uint32(seed) ^ np.uint32(i)), HYP, THR))
+    return feats, out
+
+
+def test_sequence_equals_oracle_and_pairs(ctx, oracle):
+    clip = video(5, 77)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    seed = 0xC0FFEE
+    seeds = (np.arange(len(clip) - 1, dtype=np.uint32) ^ np.uint32(seed))
+    dpat = torch.from_numpy(pat).cuda()
+    out = ctx.frontend_sequence(torch.from_numpy(clip).cuda(), MAXC, ca, sa, dpat, torch.from_numpy(seeds.view(np.int32)).cuda(), HYP, THR)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    feats, ref = oracle_pairs(oracle, clip, seed, pat, ca, sa)
+    for f, r in enumerate(feats):
+        n = len(r["xy"])
+        assert out["n"][f] == n and np.array_equal(out["xy"][f, :n], r["xy"]) and np.array_equal(out["desc"][f, :n], r["desc"]), f
+        assert np.array_equal(out["nodes"][f, :n], r["nodes"]), f
+    # the same pairs through the pair entry point
+    P = len(clip) - 1
+    both = np.concatenate([clip[:-1], clip[1:]])
+    pairs = ctx.frontend_pairs(torch.from_numpy(both).cuda(), P, MAXC, ca, sa, dpat, torch.from_numpy(seeds.view(np.int32)).cuda(), HYP, THR)
+    ctx.synchronize()
+    pairs = {k: v.cpu().numpy() for k, v in pairs.items()}
+    for i, r in enumerate(ref):
+        k = len(r["matches"])
+        assert out["best"][i, 3] == k, i
+        assert np.array_equal(out["matches"][i, :k], r["matches"]), i
+        if r["rc"] == 0:
+            assert np.array_equal(out["F"][i].view(np.uint32), r["F"].view(np.uint32)), i
+        assert np.array_equal(out["best"][i], pairs["best"][i]) and np.array_equal(out["matches"][i, :k], pairs["matches"][i, :k]), i
+        assert out["F"][i].tobytes() == pairs["F"][i].tobytes(), i
+
+
+def run_sequence(video_path, record_path, batch, seed, max_frames=0):
+    lib = ctypes.CDLL(build.build_host())
+    frames, pairs, secs = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+    err = ctypes.create_string_buffer(512)
+    rc = lib.vslam_host_run_sequence(str(video_path).encode(), str(record_path).encode(), W, H, batch, MAXC, HYP,
+                                     ctypes.c_float(THR), ctypes.c_uint32(seed), ctypes.c_uint64(max_frames),
+                                     ctypes.byref(frames), ctypes.byref(pairs), ctypes.byref(secs), err, 512)
+    assert rc == 0, err.value.decode()
+    return frames.value, pairs.value
+
+
+def test_capture_loop_records(oracle, tmp_path, monkeypatch):
+    n_frames, seed = 7, 0xABCD
+    clip = video(n_frames, 91)
+    vid = tmp_path / "clip.bgr"
+    vid.write_bytes(clip.tobytes() + b"\x00" * 100)          # a trailing partial frame is ignored
+    pat = synth.brief_pattern()
+    patfile = tmp_path / "pattern.i8"
+    patfile.write_bytes(pat.tobytes())
+    monkeypatch.setenv("VSLAM_BRIEF_PATTERN", str(patfile))   # the C++ layer reads its pattern from here
+    ca, sa = synth.keypoint_rotation()
+    _, ref = oracle_pairs(oracle, clip, seed, pat, ca, sa)
+    blobs = []
+    for batch in (2, 3, 4, 64):
+        out = tmp_path / f"rec_{batch}.bin"
+        frames, pairs = run_sequence(vid, out, batch, seed)
+        assert (frames, pairs) == (n_frames, n_frames - 1), batch
+        blobs.append(out.read_bytes())
+    assert all(b == blobs[0] for b in blobs), "records must not depend on the batch size"
+    head, recs = records.read_records(tmp_path / "rec_3.bin")
+    assert head == dict(width=W, height=H, max_corners=MAXC, hypotheses=HYP, threshold=THR, seed=seed)
+    assert [r["first_frame"] for r in recs] == list(range(n_frames - 1))
+    for r, o in zip(recs, ref):
+        assert np.array_equal(r["matches"], o["matches"]), r["first_frame"]
+        if o["rc"] == 0:
+            assert r["F"].tobytes() == o["F"].tobytes(), r["first_frame"]
+            assert r["inliers"] == len(o["matches"])
+    # max_frames stops early; fewer than two frames gives an empty record file
+    frames, pairs = run_sequence(vid, tmp_path / "short.bin", 3, seed, max_frames=4)
+    assert (frames, pairs) == (4, 3)
+    assert (tmp_path / "short.bin").read_bytes() == blobs[0][:len((tmp_path / "short.bin").read_bytes())]
+    (tmp_path / "one.bgr").write_bytes(clip[0].tobytes())
+    frames, pairs = run_sequence(tmp_path / "one.bgr", tmp_path / "none.bin", 3, seed)
+    assert pairs == 0 and len((tmp_path / "none.bin").read_bytes()) == 40

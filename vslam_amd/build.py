@@ -38,18 +38,19 @@ def build(force=False, verbose=False):
 
 
 HOST_LIB = os.path.join(HERE, "libvslam_host.so")
-HOST_SRC = os.path.join(HERE, "host", "adapters.cpp")
+HOST_SRCS = [os.path.join(HERE, "host", f) for f in ("adapters.cpp", "ingest.cpp")]
+HOST_HDRS = [os.path.join(HERE, "host", "host_internal.h")]
 INCLUDE = os.path.join(HERE, "..", "include")
 
 
 def build_host(force=False, verbose=False):
     """The C++ drop-in layer (include/vslam/*.h): plain g++, links against libvslam_amd.so."""
     build(force=False)
-    deps = [HOST_SRC, LIB] + [os.path.join(INCLUDE, "vslam", f) for f in os.listdir(os.path.join(INCLUDE, "vslam"))]
+    deps = HOST_SRCS + HOST_HDRS + [LIB] + [os.path.join(INCLUDE, "vslam", f) for f in os.listdir(os.path.join(INCLUDE, "vslam"))]
     if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
         return HOST_LIB
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, HOST_SRC,
-           "-L" + HERE, "-lvslam_amd", "-Wl,-rpath,$ORIGIN"]
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-o", HOST_LIB] + HOST_SRCS + [
+        "-L" + HERE, "-lvslam_amd", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

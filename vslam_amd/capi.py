@@ -24,7 +24,8 @@ SYMBOLS = [
     "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_extract_features_grid", "vslam_bgr2gray", "vslam_min_eigen",
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points", "vslam_reprojection_filter",
     "vslam_match_features",
-    "vslam_frontend_pairs",
+    "vslam_frontend_pairs", "vslam_frontend_sequence",
+    "vslam_host_alloc", "vslam_host_free", "vslam_upload_async", "vslam_upload_fence", "vslam_upload_wait",
 ]
 
 
@@ -373,6 +374,28 @@ class Context:
         p = self._params(max_corners, cos_a, sin_a, pattern)
         self._check(self.lib.vslam_frontend_pairs(
             self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K),
+            _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out["nodes"]),
+            _ptr(out["n"]), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"])))
+        return out
+
+    def frontend_sequence(self, bgr, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, kp_stride=None, out=None):
+        """Consecutive frames: every frame extracted once, pair i = (frame i, frame i + 1); seeds has F - 1 entries."""
+        torch = self.torch
+        F, H, W, _ = bgr.shape
+        assert F >= 2 and seeds.shape[0] == F - 1
+        K = kp_stride or max_corners
+        dev = bgr.device
+        if out is None:
+            out = dict(xy=torch.zeros((F, K, 2), dtype=torch.float32, device=dev),
+                       desc=torch.zeros((F, K, 32), dtype=torch.uint8, device=dev),
+                       nodes=torch.full((F, K), -1, dtype=torch.int32, device=dev),
+                       n=torch.zeros((F,), dtype=torch.int32, device=dev),
+                       matches=torch.zeros((F - 1, K, 2), dtype=torch.int32, device=dev),
+                       best=torch.zeros((F - 1, 4), dtype=torch.int32, device=dev),
+                       F=torch.zeros((F - 1, 9), dtype=torch.float32, device=dev))
+        p = self._params(max_corners, cos_a, sin_a, pattern)
+        self._check(self.lib.vslam_frontend_sequence(
+            self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K),
             _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out["nodes"]),
             _ptr(out["n"]), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"])))
         return out

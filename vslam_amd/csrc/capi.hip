@@ -130,6 +130,11 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return VSLAM_ERR_HIP;
+    }
     if (const char *e = getenv("VSLAM_OVERLAP_BLUR")) ctx->overlap_blur = e[0] - '0';
     *out = ctx;
     return VSLAM_OK;
@@ -150,6 +155,11 @@ int vslam_ctx_destroy(vslam_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
     }
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -210,6 +220,34 @@ int vslam_copy_d2h(vslam_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
         VS_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return VSLAM_OK;
+}
+
+int vslam_host_alloc(vslam_ctx *ctx, size_t bytes, void **h_out) {
+    if (!ctx || !h_out) return VSLAM_ERR_INVALID;
+    VS_HIP(ctx, hipHostMalloc(h_out, bytes ? bytes : 1, hipHostMallocDefault));
+    return VSLAM_OK;
+}
+int vslam_host_free(vslam_ctx *ctx, void *h_ptr) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    if (h_ptr) VS_HIP(ctx, hipHostFree(h_ptr));
+    return VSLAM_OK;
+}
+int vslam_upload_async(vslam_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, d_dst && h_src, VSLAM_ERR_INVALID);
+    if (bytes) VS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    return VSLAM_OK;
+}
+int vslam_upload_fence(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->copy_stream));
+    VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
+    return VSLAM_OK;
+}
+int vslam_upload_wait(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return VSLAM_OK;
 }
 
@@ -504,6 +542,35 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     rc = vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * half, d_desc + VSLAM_DESC_BYTES * half,
                               d_n + pairs, pairs, kp_stride, d_seeds, hyp, threshold, d_matches, d_best,
                               d_F, nullptr);
+    if (overlap) VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return rc;
+}
+
+// consecutive frames: extract once, pair i = (frame i, frame i + 1)
+int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
+                            int row_stride, const vslam_extract_params *params, int kp_stride,
+                            const uint32_t *d_seeds, int hyp, float threshold, float *d_xy,
+                            uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches,
+                            int32_t *d_best, float *d_F) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, frames >= 2, VSLAM_ERR_INVALID);
+    const bool overlap = d_nodes && !ctx->prof;   // k-d trees beside the matching stages, as in vslam_frontend_pairs
+    int rc = vslam_extract_features(ctx, d_bgr, frames, width, height, row_stride, params, kp_stride, d_xy, d_desc,
+                                    overlap ? nullptr : d_nodes, d_n, nullptr);
+    if (rc) return rc;
+    if (overlap) {
+        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->aux_stream;
+        rc = vs_launch_kdtree_build(ctx, d_xy, d_n, frames, kp_stride, d_nodes);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        VS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    }
+    const size_t one = (size_t)kp_stride;
+    rc = vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * one, d_desc + VSLAM_DESC_BYTES * one, d_n + 1,
+                              frames - 1, kp_stride, d_seeds, hyp, threshold, d_matches, d_best, d_F, nullptr);
     if (overlap) VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return rc;
 }

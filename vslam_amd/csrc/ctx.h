@@ -30,6 +30,9 @@ struct vslam_ctx {
     // match/RANSAC) run beside the main stream inside vslam_frontend_pairs
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // uploads (frame ingest) run on their own stream; ev_upload marks the last one enqueued
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_upload = nullptr;
     int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, 1 fork after bgr2gray, 2 fork after min_eigen
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     std::string err;

@@ -15,6 +15,7 @@
 
 #include "../../include/vslam/Frame.h"
 #include "../../include/vslam_amd.h"
+#include "host_internal.h"
 
 namespace {
 
@@ -171,6 +172,22 @@ Settings &settings() {
     static Settings s;
     return s;
 }
+
+namespace detail {
+vslam_ctx *context() { return ctx(); }
+void check(int rc, const char *what) { ::check(rc, what); }
+const std::vector<s8> &brief_pattern() { return pattern(); }
+void fill_extract_params(vslam_extract_params &p, int max_corners, const int8_t *d_pattern) {
+    auto &st = vslam::settings();
+    p.max_corners = max_corners;
+    p.quality = st.quality;
+    p.min_distance = st.min_distance;
+    const float a = st.keypoint_angle_deg * (float)(3.14159265358979323846 / 180.f);   // angle *= CV_PI/180
+    p.cos_a = (float)std::cos((double)a);
+    p.sin_a = (float)std::sin((double)a);
+    p.d_pattern = d_pattern;
+}
+}  // namespace detail
 
 void forget_kdtree(const void *root) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -1,0 +1,334 @@
+// Frame ingest + result records on top of the C ABI (include/vslam/Ingest.h).
+//
+// run_sequence keeps three things busy at once: a reader thread fills one page-locked buffer from the file
+// while the copy stream uploads the other and the compute stream works on the batch before it.
+// Batch k holds frames [k * (B - 1), k * (B - 1) + B): consecutive batches share one frame, so every
+// consecutive pair is computed exactly once and no feature has to survive a batch (re-extracting the shared
+// frame costs 1 / B of the extraction).
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vslam/Ingest.h"
+#include "host_internal.h"
+
+namespace vslam {
+namespace {
+
+void put(std::FILE *f, const void *p, size_t n) {
+    if (std::fwrite(p, 1, n, f) != n) throw std::runtime_error("vslam records: write failed");
+}
+bool get(std::FILE *f, void *p, size_t n, bool eof_ok) {
+    const size_t r = std::fread(p, 1, n, f);
+    if (r == n) return true;
+    if (r == 0 && eof_ok) return false;
+    throw std::runtime_error("vslam records: truncated file");
+}
+const char kMagic[8] = {'V', 'S', 'L', 'A', 'M', 'R', 'E', 'C'};
+
+struct Pinned {   // page-locked host buffer
+    uint8_t *p = nullptr;
+    explicit Pinned(size_t bytes) { detail::check(vslam_host_alloc(detail::context(), bytes, reinterpret_cast<void **>(&p)), "host_alloc"); }
+    ~Pinned() { (void)vslam_host_free(detail::context(), p); }
+    Pinned(const Pinned &) = delete;
+    Pinned &operator=(const Pinned &) = delete;
+};
+template <typename T>
+struct Dev {
+    T *p = nullptr;
+    explicit Dev(size_t count) { detail::check(vslam_dev_alloc(detail::context(), sizeof(T) * (count ? count : 1), reinterpret_cast<void **>(&p)), "dev_alloc"); }
+    ~Dev() { (void)vslam_dev_free(detail::context(), p); }
+    Dev(const Dev &) = delete;
+    Dev &operator=(const Dev &) = delete;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ records
+RecordWriter::RecordWriter(const std::string &path, const RecordHeader &h) {
+    std::FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("vslam records: cannot create " + path);
+    file_ = f;
+    const uint32_t words[5] = {h.version, h.width, h.height, h.max_corners, h.hypotheses};
+    const uint32_t tail[2] = {h.seed, 0u};
+    put(f, kMagic, 8);
+    put(f, words, sizeof words);
+    put(f, &h.threshold, 4);
+    put(f, tail, sizeof tail);
+}
+RecordWriter::~RecordWriter() {
+    if (file_) std::fclose(static_cast<std::FILE *>(file_));
+}
+void RecordWriter::close() {
+    if (file_ && std::fclose(static_cast<std::FILE *>(file_)) != 0) {
+        file_ = nullptr;
+        throw std::runtime_error("vslam records: close failed");
+    }
+    file_ = nullptr;
+}
+void RecordWriter::append(const PairRecord &r) {
+    std::FILE *f = static_cast<std::FILE *>(file_);
+    if (!f) throw std::runtime_error("vslam records: writer is closed");
+    const uint32_t n = (uint32_t)r.matches.size();
+    put(f, &r.first_frame, 8);
+    put(f, &r.winner, 4);
+    put(f, &r.inliers, 4);
+    put(f, &r.score, 4);
+    put(f, r.F, 36);
+    put(f, &n, 4);
+    std::vector<int32_t> flat(2 * (size_t)n);
+    for (uint32_t i = 0; i < n; i++) {
+        flat[2 * i] = r.matches[i].first;
+        flat[2 * i + 1] = r.matches[i].second;
+    }
+    if (n) put(f, flat.data(), 8 * (size_t)n);
+}
+
+RecordReader::RecordReader(const std::string &path) {
+    std::FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("vslam records: cannot open " + path);
+    file_ = f;
+    char magic[8];
+    uint32_t words[5], tail[2];
+    get(f, magic, 8, false);
+    if (std::memcmp(magic, kMagic, 8) != 0) throw std::runtime_error("vslam records: not a record file: " + path);
+    get(f, words, sizeof words, false);
+    get(f, &header_.threshold, 4, false);
+    get(f, tail, sizeof tail, false);
+    header_.version = words[0];
+    header_.width = words[1];
+    header_.height = words[2];
+    header_.max_corners = words[3];
+    header_.hypotheses = words[4];
+    header_.seed = tail[0];
+    if (header_.version != 1) throw std::runtime_error("vslam records: unknown version");
+}
+RecordReader::~RecordReader() {
+    if (file_) std::fclose(static_cast<std::FILE *>(file_));
+}
+bool RecordReader::next(PairRecord &r) {
+    std::FILE *f = static_cast<std::FILE *>(file_);
+    if (!get(f, &r.first_frame, 8, true)) return false;
+    uint32_t n = 0;
+    get(f, &r.winner, 4, false);
+    get(f, &r.inliers, 4, false);
+    get(f, &r.score, 4, false);
+    get(f, r.F, 36, false);
+    get(f, &n, 4, false);
+    std::vector<int32_t> flat(2 * (size_t)n);
+    if (n) get(f, flat.data(), 8 * (size_t)n, false);
+    r.matches.resize(n);
+    for (uint32_t i = 0; i < n; i++) r.matches[i] = {flat[2 * i], flat[2 * i + 1]};
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ the capture loop
+SequenceStats run_sequence(const std::string &video_path, const std::string &record_path, const SequenceOptions &o) {
+    if (o.width <= 0 || o.height <= 0 || o.batch_frames < 2 || o.max_corners <= 0 || o.hypotheses <= 0)
+        throw std::invalid_argument("run_sequence: bad options");
+    std::FILE *in = std::fopen(video_path.c_str(), "rb");
+    if (!in) throw std::runtime_error("run_sequence: cannot open " + video_path);
+    struct Closer {
+        std::FILE *f;
+        ~Closer() { std::fclose(f); }
+    } closer{in};
+
+    vslam_ctx *ctx = detail::context();
+    const int B = o.batch_frames, K = o.max_corners;
+    const size_t frame_bytes = (size_t)o.width * o.height * 3;
+    Pinned hbuf0(frame_bytes * B), hbuf1(frame_bytes * B);
+    uint8_t *hbuf[2] = {hbuf0.p, hbuf1.p};
+    Dev<uint8_t> dbuf0(frame_bytes * B), dbuf1(frame_bytes * B);
+    uint8_t *dbuf[2] = {dbuf0.p, dbuf1.p};
+    Dev<float> d_xy(2 * (size_t)B * K), d_F(9 * (size_t)B);
+    Dev<uint8_t> d_desc(32 * (size_t)B * K);
+    Dev<int32_t> d_nodes((size_t)B * K), d_n(B), d_matches(2 * (size_t)B * K), d_best(4 * (size_t)B);
+    Dev<uint32_t> d_seeds(B);
+    Dev<int8_t> d_pat(1024);
+    detail::check(vslam_copy_h2d(ctx, d_pat.p, detail::brief_pattern().data(), 1024), "pattern upload");
+    vslam_extract_params params;
+    detail::fill_extract_params(params, K, d_pat.p);
+
+    RecordHeader head;
+    head.width = (uint32_t)o.width;
+    head.height = (uint32_t)o.height;
+    head.max_corners = (uint32_t)K;
+    head.hypotheses = (uint32_t)o.hypotheses;
+    head.threshold = o.threshold;
+    head.seed = o.seed;
+    RecordWriter writer(record_path, head);
+
+    // ---- reader thread: batch k -> hbuf[k & 1]; state[b]: 0 free, 1 filled (count[b] frames), 2 end of stream
+    std::mutex mu;
+    std::condition_variable cv;
+    int state[2] = {0, 0}, count[2] = {0, 0};
+    bool stop = false;
+    std::string reader_error;
+    std::thread reader([&] {
+        try {
+            uint64_t read_total = 0;
+            for (uint64_t k = 0;; k++) {
+                const int b = (int)(k & 1);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return state[b] == 0 || stop; });
+                    if (stop) return;
+                }
+                int have = 0;
+                if (k > 0) {   // the frame this batch shares with the previous one
+                    std::memcpy(hbuf[b], hbuf[b ^ 1] + frame_bytes * (size_t)(B - 1), frame_bytes);
+                    have = 1;
+                }
+                while (have < B && (o.max_frames == 0 || read_total < o.max_frames)) {
+                    const size_t r = std::fread(hbuf[b] + frame_bytes * (size_t)have, 1, frame_bytes, in);
+                    if (r != frame_bytes) break;   // end of file (a trailing partial frame is dropped)
+                    have++;
+                    read_total++;
+                }
+                const bool last = have < B;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    count[b] = have;
+                    state[b] = (last && have < 2) ? 2 : 1;   // fewer than two frames: nothing left to pair
+                    if (last && have >= 2) count[b] = -have;  // negative: final batch
+                }
+                cv.notify_all();
+                if (last) return;
+            }
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            reader_error = e.what();
+            state[0] = state[1] = 2;
+            cv.notify_all();
+        }
+    });
+    struct Joiner {
+        std::thread &t;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &stop;
+        ~Joiner() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+    } joiner{reader, mu, cv, stop};
+
+    auto wait_filled = [&](int b, int &frames, bool &final_batch) -> bool {   // false: stream ended before this batch
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return state[b] != 0; });
+        if (!reader_error.empty()) throw std::runtime_error("run_sequence: reader: " + reader_error);
+        if (state[b] == 2) return false;
+        final_batch = count[b] < 0;
+        frames = final_batch ? -count[b] : count[b];
+        return true;
+    };
+    auto release = [&](int b) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            state[b] = 0;
+        }
+        cv.notify_all();
+    };
+
+    SequenceStats stats;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int32_t> h_best(4 * (size_t)B), h_matches(2 * (size_t)B * K);
+    std::vector<float> h_F(9 * (size_t)B);
+    std::vector<uint32_t> h_seeds(B);
+
+    int frames = 0, next_frames = 0;
+    bool final_batch = false, next_final = false;
+    bool have = wait_filled(0, frames, final_batch);
+    if (have) {
+        detail::check(vslam_upload_async(ctx, dbuf[0], hbuf[0], frame_bytes * (size_t)frames), "upload");
+        detail::check(vslam_upload_fence(ctx), "upload fence");
+    }
+    for (uint64_t k = 0; have; k++) {
+        const int b = (int)(k & 1);
+        const uint64_t first = k * (uint64_t)(B - 1);   // global index of this batch's first frame = of its first pair
+        const int pairs = frames - 1;
+        for (int i = 0; i < pairs; i++) h_seeds[i] = o.seed ^ (uint32_t)(first + (uint64_t)i);
+        detail::check(vslam_copy_h2d(ctx, d_seeds.p, h_seeds.data(), sizeof(uint32_t) * (size_t)pairs), "seed upload");
+        detail::check(vslam_frontend_sequence(ctx, dbuf[b], frames, o.width, o.height, 3 * o.width, &params, K, d_seeds.p,
+                                              o.hypotheses, o.threshold, d_xy.p, d_desc.p, d_nodes.p, d_n.p, d_matches.p,
+                                              d_best.p, d_F.p),
+                      "frontend_sequence");
+        // the next batch goes up while this one is computed
+        bool have_next = false;
+        if (!final_batch) {
+            have_next = wait_filled(b ^ 1, next_frames, next_final);
+            if (have_next) detail::check(vslam_upload_async(ctx, dbuf[b ^ 1], hbuf[b ^ 1], frame_bytes * (size_t)next_frames), "upload");
+        }
+        detail::check(vslam_copy_d2h(ctx, h_best.data(), d_best.p, sizeof(int32_t) * 4 * (size_t)pairs), "download");
+        detail::check(vslam_copy_d2h(ctx, h_F.data(), d_F.p, sizeof(float) * 9 * (size_t)pairs), "download");
+        detail::check(vslam_copy_d2h(ctx, h_matches.data(), d_matches.p, sizeof(int32_t) * 2 * (size_t)pairs * K), "download");
+        for (int i = 0; i < pairs; i++) {
+            PairRecord r;
+            r.first_frame = first + (uint64_t)i;
+            r.winner = h_best[4 * i + 0];
+            r.inliers = h_best[4 * i + 1];
+            std::memcpy(&r.score, &h_best[4 * i + 2], 4);
+            std::memcpy(r.F, &h_F[9 * (size_t)i], 36);
+            const int n = h_best[4 * i + 3];
+            r.matches.resize((size_t)n);
+            for (int j = 0; j < n; j++) r.matches[(size_t)j] = {h_matches[2 * ((size_t)i * K + j)], h_matches[2 * ((size_t)i * K + j) + 1]};
+            writer.append(r);
+        }
+        stats.pairs += (uint64_t)pairs;
+        stats.frames = first + (uint64_t)frames;
+        stats.batches++;
+        if (have_next) {
+            detail::check(vslam_upload_wait(ctx), "upload wait");   // hbuf[b ^ 1] is on the device
+            detail::check(vslam_upload_fence(ctx), "upload fence");
+        }
+        // hbuf[b] was uploaded before this batch ran and the next batch's shared frame comes from hbuf[b ^ 1]:
+        // the reader may refill it
+        release(b);
+        have = have_next;
+        frames = next_frames;
+        final_batch = next_final;
+    }
+    writer.close();
+    stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return stats;
+}
+
+}  // namespace vslam
+
+extern "C" int vslam_host_run_sequence(const char *video_path, const char *record_path, int width, int height,
+                                       int batch_frames, int max_corners, int hypotheses, float threshold,
+                                       uint32_t seed, uint64_t max_frames, uint64_t *frames_out, uint64_t *pairs_out,
+                                       double *seconds_out, char *err, int err_cap) {
+    try {
+        vslam::SequenceOptions o;
+        o.width = width;
+        o.height = height;
+        o.batch_frames = batch_frames;
+        o.max_corners = max_corners;
+        o.hypotheses = hypotheses;
+        o.threshold = threshold;
+        o.seed = seed;
+        o.max_frames = max_frames;
+        const vslam::SequenceStats s = vslam::run_sequence(video_path ? video_path : "", record_path ? record_path : "", o);
+        if (frames_out) *frames_out = s.frames;
+        if (pairs_out) *pairs_out = s.pairs;
+        if (seconds_out) *seconds_out = s.seconds;
+        return 0;
+    } catch (const std::exception &e) {
+        if (err && err_cap > 0) {
+            std::strncpy(err, e.what(), (size_t)err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return -1;
+    }
+}
