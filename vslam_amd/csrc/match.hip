@@ -6,7 +6,7 @@
 // Mapping: one 256-thread workgroup owns 512 query rows of one frame pair (2 per lane, kept in
 // 16 VGPRs); train rows stream through LDS in 8 KiB tiles (coalesced 16-B global loads) and are
 // read back as wave-uniform ds_read_b128 broadcasts.  Per (query, train) pair the work is
-// 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating) + one key pack + a 3-op running min-2,
+// 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (accumulating) + one key pack + a 2-op running min-2 (min, med3),
 // i.e. the kernel is integer-VALU bound (about 450 int ops per HBM byte), not HBM bound.
 // The two best candidates per query are tracked as packed keys (distance << 16 | trainIdx):
 // an unsigned min over keys is exactly "smaller distance, then lower train index", which is
@@ -27,6 +27,12 @@ constexpr int kTile = 256;   // train rows per LDS tile (8 KiB)
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
     uint32_t r;
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+// second-smallest tracking: with k1 <= k2, the new k2 is the median of (k1, k2, key)
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ uint32_t ham256(const uint4 &qa, const uint4 &qb, const uint4 &ta,
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
 #pragma unroll
                 for (int s = 0; s < kQueriesPerLane; s++) {
                     const uint32_t key = (ham256(qa[s], qb[s], ta[u], tb[u]) << 16) | (uint32_t)(t0 + j + u);
-                    k2[s] = min(k2[s], max(k1[s], key));
+                    k2[s] = med3_u32(k1[s], k2[s], key);
                     k1[s] = min(k1[s], key);
                 }
         }
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
 #pragma unroll
             for (int s = 0; s < kQueriesPerLane; s++) {
                 const uint32_t key = (ham256(qa[s], qb[s], ta, tb) << 16) | (uint32_t)(t0 + j);
-                k2[s] = min(k2[s], max(k1[s], key));
+                k2[s] = med3_u32(k1[s], k2[s], key);
                 k1[s] = min(k1[s], key);
             }
         }
