@@ -1101,7 +1101,7 @@ __device__ __forceinline__ int nms_visit_lds(const volatile uint32_t *offs, cons
 //    best-ranked candidates (N a little above maxCorners), sorted in LDS; if they yield fewer than
 //    maxCorners survivors N is doubled (decisions already made stay valid).
 //  slow path (N would exceed the LDS sort buffer): suppression over every candidate, then select.
-__global__ __launch_bounds__(kST) void corner_select_kernel(
+__global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) void corner_select_kernel(
     const float *__restrict__ eig, int w, int h, uint8_t *__restrict__ state,
     unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
     int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
