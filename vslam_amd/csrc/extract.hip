@@ -1601,12 +1601,14 @@ __global__ __launch_bounds__(kKT) void rbrief_kernel(const uint8_t *__restrict__
 // scattered byte loads per lane, each 64 separate addresses for the texture addresser).  Here
 //  * the pattern is rotated once per launch (rbrief_rotate_kernel) instead of once per workgroup,
 //  * a workgroup walks through 64 keypoints, 8 at a time; the 32 lanes of a keypoint copy its patch rows
-//    (2R+1 rows of 48 bytes, R = the largest rotated offset; dword loads, one or two cache lines per row) into
+//    (2R+1 rows of up to 36 bytes, R = the largest rotated offset; dword loads, one or two cache lines per row) into
 //    LDS and take the 16 samples per lane from there,
 //  * the patch loads of the next 8 keypoints are in flight while the current 8 are sampled (two LDS buffers).
 // Sample offsets are kept transposed ([sample][byte]) so the 32 lanes of a keypoint read 32 consecutive words.
-constexpr int kRPitch = 48;     // bytes per staged patch row (12 dwords: 2 * 22 + 1 columns plus alignment slack)
-constexpr int kRMax = 22;       // largest |offset| of a 31x31 pattern under any rotation (15 * sqrt(2))
+constexpr int kRPitch = 36;     // bytes per staged patch row (9 dwords: 2 * 16 + 1 columns plus alignment slack)
+constexpr int kRMax = 16;       // largest |offset| staged: covers the 31x31 pattern at the angles cv::KeyPoint's default
+                                // (-1 degree) and small rotations give; wider rotated patterns are sampled directly.
+                                // Keeping the patch small is what lets 7 workgroups share a CU's LDS.
 constexpr int kRRows = 2 * kRMax + 1;
 constexpr int kRGroups = 8;     // groups of 8 keypoints per workgroup
 constexpr int kRLoads = (kRRows * (kRPitch / 4) + 31) / 32;   // patch dwords per lane, worst case
@@ -1660,7 +1662,7 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
         cxs[g] = (int)rintf(p.x);
         cys[g] = (int)rintf(p.y);
     }
-    // dwords per staged row: columns (cx - R) & ~3 .. cx + R, at most 2R + 4 bytes; rows keep the 48-byte pitch
+    // dwords per staged row: columns (cx - R) & ~3 .. cx + R, at most 2R + 4 bytes; rows keep the fixed pitch
     const int nd = staged ? (2 * R + 3) / 4 + 1 : 1;
     const int total = (2 * R + 1) * nd;
     const int r0 = l32 / nd, c0 = l32 - r0 * nd, dq = 32 / nd, dr = 32 - dq * nd;   // dword l32 + 32k = row r, column c
