@@ -48,24 +48,15 @@ __device__ __forceinline__ uint32_t ham256(const uint4 &qa, const uint4 &qb, con
     return d;
 }
 
-__global__ __launch_bounds__(kThreads) void match_knn2_kernel(
-    const uint8_t *__restrict__ desc1, const int32_t *__restrict__ n1,
-    const uint8_t *__restrict__ desc2, const int32_t *__restrict__ n2, int kp_stride,
-    int32_t *__restrict__ sel, int32_t *__restrict__ knn) {
-    const int b = blockIdx.y;
-    const int nq = n1[b], nt = n2[b];
-    const int qbase = blockIdx.x * (kThreads * kQueriesPerLane);
-    if (qbase >= nq) return;   // uniform for the whole workgroup
-
-    __shared__ uint4 tile[kTile * 2];
-
-    const uint4 *q4 = reinterpret_cast<const uint4 *>(desc1 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
-    const uint4 *t4 = reinterpret_cast<const uint4 *>(desc2 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
-
-    uint4 qa[kQueriesPerLane], qb[kQueriesPerLane];
-    uint32_t k1[kQueriesPerLane], k2[kQueriesPerLane];
+// NQ = query rows per lane in this workgroup (2, or 1 when the second slot would hold no valid query: the last
+// workgroup of a pair then issues half the instructions instead of computing clamped duplicates)
+template <int NQ>
+__device__ __forceinline__ void match_knn2_body(const uint4 *__restrict__ q4, const uint4 *__restrict__ t4, int nq, int nt,
+                                                int qbase, uint4 *tile, int32_t *__restrict__ sel_b, int4 *__restrict__ knn_b) {
+    uint4 qa[NQ], qb[NQ];
+    uint32_t k1[NQ], k2[NQ];
 #pragma unroll
-    for (int s = 0; s < kQueriesPerLane; s++) {
+    for (int s = 0; s < NQ; s++) {
         const int q = qbase + s * kThreads + threadIdx.x;
         const int qc = q < nq ? q : nq - 1;   // clamp: lanes past the end recompute a valid row
         qa[s] = q4[2 * qc];
@@ -80,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
         for (int i = threadIdx.x; i < rows * 2; i += kThreads) tile[i] = t4[2 * t0 + i];
         __syncthreads();
         int j = 0;
-        for (; j + 4 <= rows; j += 4) {   // four train rows per trip: eight independent distance chains in flight
+        for (; j + 4 <= rows; j += 4) {   // four train rows per trip: 4 * NQ independent distance chains in flight
             uint4 ta[4], tb[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -90,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
 #pragma unroll
             for (int u = 0; u < 4; u++)
 #pragma unroll
-                for (int s = 0; s < kQueriesPerLane; s++) {
+                for (int s = 0; s < NQ; s++) {
                     const uint32_t key = (ham256(qa[s], qb[s], ta[u], tb[u]) << 16) | (uint32_t)(t0 + j + u);
                     k2[s] = med3_u32(k1[s], k2[s], key);
                     k1[s] = min(k1[s], key);
@@ -99,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
         for (; j < rows; j++) {
             const uint4 ta = tile[2 * j], tb = tile[2 * j + 1];
 #pragma unroll
-            for (int s = 0; s < kQueriesPerLane; s++) {
+            for (int s = 0; s < NQ; s++) {
                 const uint32_t key = (ham256(qa[s], qb[s], ta, tb) << 16) | (uint32_t)(t0 + j);
                 k2[s] = med3_u32(k1[s], k2[s], key);
                 k1[s] = min(k1[s], key);
@@ -108,22 +99,44 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
     }
 
 #pragma unroll
-    for (int s = 0; s < kQueriesPerLane; s++) {
+    for (int s = 0; s < NQ; s++) {
         const int q = qbase + s * kThreads + threadIdx.x;
         if (q >= nq) continue;
         const int d0 = (int)(k1[s] >> 16), i0 = (int)(k1[s] & 0xFFFFu);
         const int d1 = (int)(k2[s] >> 16), i1 = (int)(k2[s] & 0xFFFFu);
         const bool pass = (nt >= 2) && (10 * d0 < 7 * d1);
-        sel[(size_t)b * kp_stride + q] = pass ? i0 : -1;
-        if (knn) {
+        sel_b[q] = pass ? i0 : -1;
+        if (knn_b) {
             int4 o;
             o.x = nt >= 1 ? i0 : -1;
             o.y = nt >= 1 ? d0 : 0x7FFFFFFF;
             o.z = nt >= 2 ? i1 : -1;
             o.w = nt >= 2 ? d1 : 0x7FFFFFFF;
-            reinterpret_cast<int4 *>(knn)[(size_t)b * kp_stride + q] = o;
+            knn_b[q] = o;
         }
     }
+}
+
+__global__ __launch_bounds__(kThreads) void match_knn2_kernel(
+    const uint8_t *__restrict__ desc1, const int32_t *__restrict__ n1,
+    const uint8_t *__restrict__ desc2, const int32_t *__restrict__ n2, int kp_stride,
+    int32_t *__restrict__ sel, int32_t *__restrict__ knn) {
+    const int b = blockIdx.y;
+    const int nq = n1[b], nt = n2[b];
+    const int qbase = blockIdx.x * (kThreads * kQueriesPerLane);
+    if (qbase >= nq) return;   // uniform for the whole workgroup
+
+    __shared__ uint4 tile[kTile * 2];
+
+    const uint4 *q4 = reinterpret_cast<const uint4 *>(desc1 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(desc2 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
+    int32_t *sel_b = sel + (size_t)b * kp_stride;
+    int4 *knn_b = knn ? reinterpret_cast<int4 *>(knn) + (size_t)b * kp_stride : nullptr;
+    static_assert(kQueriesPerLane == 2, "the two instantiations below cover 1 and 2 rows per lane");
+    if (qbase + kThreads >= nq)
+        match_knn2_body<1>(q4, t4, nq, nt, qbase, tile, sel_b, knn_b);
+    else
+        match_knn2_body<2>(q4, t4, nq, nt, qbase, tile, sel_b, knn_b);
 }
 
 // Ordered compaction of the ratio-test survivors into (queryIdx, trainIdx) pairs, query order
