@@ -66,3 +66,48 @@ def test_truncation_is_reported(tmp_path):
     (tmp_path / "bad.bin").write_bytes(b"NOTAVSLM" + data[8:])
     with pytest.raises(ValueError):
         records.read_records(tmp_path / "bad.bin")
+
+
+def test_cpp_reader_and_writer_agree_with_python(tmp_path):
+    """The C++ RecordWriter / RecordReader (libvslam_host.so) and vslam_amd.records read each other's files."""
+    import os
+    import subprocess
+    from vslam_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build.build_host()
+    exe = str(tmp_path / "records_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "native", "records_check.cpp"),
+                    "-I" + os.path.join(root, "include"), "-L" + os.path.join(root, "vslam_amd"), "-lvslam_host", "-lvslam_amd",
+                    "-Wl,-rpath," + os.path.join(root, "vslam_amd")], check=True)
+    # C++ writes, Python reads
+    f1 = str(tmp_path / "cpp.bin")
+    subprocess.run([exe, "write", f1], check=True, timeout=60)
+    head, recs = records.read_records(f1)
+    assert head == dict(width=640, height=480, max_corners=500, hypotheses=512, threshold=10.0, seed=0xC0FFEE)
+    assert [r["first_frame"] for r in recs] == [1000, 1001, 1002]
+    for i, r in enumerate(recs):
+        assert (r["winner"], r["inliers"], float(r["score"])) == (i - 1, 10 * i, 0.5 * i)
+        assert np.array_equal(r["F"], (np.arange(9) + 9 * i).astype(np.float32) * 0.125)
+        assert np.array_equal(r["matches"], np.array([[k, 2 * k + i] for k in range(10 * i)], np.int32).reshape(-1, 2))
+    # Python writes, C++ reads
+    header, mine = sample()
+    f2 = str(tmp_path / "py.bin")
+    records.write_records(f2, header, mine)
+    out = subprocess.run([exe, "read", f2], check=True, timeout=60, capture_output=True, text=True).stdout.split("\n")
+    assert out[0].split()[:6] == ["H", "1", "1280", "720", "2000", "4096"] and int(out[0].split()[7]) == 0x5EED0001
+    assert float.fromhex(out[0].split()[6]) == 10.0
+    for line, r in zip(out[1:], mine):
+        t = line.split()
+        assert t[0] == "R" and int(t[1]) == r["first_frame"] and int(t[2]) == r["winner"] and int(t[3]) == r["inliers"]
+        assert int(t[4], 16) == int(np.float32(r["score"]).view(np.uint32)) and int(t[5]) == len(r["matches"])
+        assert [int(x, 16) for x in t[6:15]] == [int(v) for v in r["F"].view(np.uint32)]
+        acc = 0
+        for a, b in r["matches"]:
+            acc = acc * 31 + int(a) * 7 + int(b)
+            acc = (acc + 2 ** 63) % 2 ** 64 - 2 ** 63       # the C++ side accumulates in a wrapping int64
+        assert int(t[15]) == acc
+    assert len([l for l in out if l.startswith("R")]) == len(mine)
+    # a truncated file makes the C++ reader fail loudly
+    cut = str(tmp_path / "cut.bin")
+    open(cut, "wb").write(open(f2, "rb").read()[:-3])
+    assert subprocess.run([exe, "read", cut], capture_output=True).returncode == 1
