@@ -848,20 +848,18 @@ __device__ void bitonic_sort_desc_regs(unsigned long long *buf) {
     __syncthreads();
 }
 
-// buf[0 .. cap) sorted descending, cap a power of two; every thread of the workgroup calls it
-__device__ void bitonic_sort_desc(unsigned long long *buf, int cap) {
+// buf[0 .. cap) sorted descending, cap a power of two; every thread of the workgroup calls it.
+// EPT = cap / kST is a template parameter of the selection kernel (0: cap < kST) so that each instantiation only
+// carries the registers of the network it uses.
+template <int EPT>
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long *buf, int cap) {
     __syncthreads();
-    switch (cap / kST) {
-        case 1: bitonic_sort_desc_regs<1>(buf); break;
-        case 2: bitonic_sort_desc_regs<2>(buf); break;
-        case 4: bitonic_sort_desc_regs<4>(buf); break;
-        case 8: bitonic_sort_desc_regs<8>(buf); break;
-        case 16: bitonic_sort_desc_regs<16>(buf); break;
-        default: bitonic_sort_desc_lds(buf, cap); break;   // cap < kST
-    }
+    if (EPT == 0) bitonic_sort_desc_lds(buf, cap);
+    else bitonic_sort_desc_regs<(EPT > 0 ? EPT : 1)>(buf);
 }
 
 // Gather the keys >= T into LDS (unordered) and sort them descending; returns how many.
+template <int EPT>
 __device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsigned long long T,
                                   unsigned long long *sortbuf, int sort_cap, SelectShared &sh) {
     const int tid = threadIdx.x;
@@ -877,7 +875,7 @@ __device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsig
         }
     }
     __syncthreads();
-    bitonic_sort_desc(sortbuf, sort_cap);
+    bitonic_sort_desc<EPT>(sortbuf, sort_cap);
     return sh.fill < (uint32_t)sort_cap ? sh.fill : (uint32_t)sort_cap;
 }
 
@@ -889,6 +887,7 @@ __device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsig
 // which is then sorted: its first N entries are the N best-ranked candidates.  Returns false when the
 // gathered set would not fit the buffer (heavy ties); the caller then uses the generic radix select.
 // n_kept receives the number of keys above the threshold, N_io is clamped to it.
+template <int EPT>
 __device__ bool rank_window_2pass(unsigned long long *K, uint32_t n, unsigned long long tkey, uint32_t t32,
                                   uint32_t m32, uint32_t &N_io, unsigned long long *sortbuf, int sort_cap,
                                   SelectShared &sh, uint32_t &n_kept, const float *__restrict__ E, int w) {
@@ -993,7 +992,7 @@ __device__ bool rank_window_2pass(unsigned long long *K, uint32_t n, unsigned lo
                 sortbuf[atomicAdd(&sh.fill, 1u)] = key[u];
     }
     __syncthreads();
-    bitonic_sort_desc(sortbuf, sort_cap);
+    bitonic_sort_desc<EPT>(sortbuf, sort_cap);
     return true;
 }
 
@@ -1101,6 +1100,7 @@ __device__ __forceinline__ int nms_visit_lds(const volatile uint32_t *offs, cons
 //    best-ranked candidates (N a little above maxCorners), sorted in LDS; if they yield fewer than
 //    maxCorners survivors N is doubled (decisions already made stay valid).
 //  slow path (N would exceed the LDS sort buffer): suppression over every candidate, then select.
+template <int EPT>
 __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) void corner_select_kernel(
     const float *__restrict__ eig, int w, int h, uint8_t *__restrict__ state,
     unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
@@ -1173,13 +1173,13 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (R == 0) N = want_max;
         while (true) {
             uint32_t got = N, n_kept = 0;
-            if (!rank_window_2pass(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept, E, w)) {
+            if (!rank_window_2pass<EPT>(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept, E, w)) {
                 if (!compacted) compact_keys();
                 n_kept = n;
                 got = N < n ? N : n;
                 if (got > (uint32_t)sort_cap) got = (uint32_t)sort_cap;
                 const unsigned long long T = radix_select_nth(K, n, got, sh);
-                got = gather_sorted(K, n, T, sortbuf, sort_cap, sh);
+                got = gather_sorted<EPT>(K, n, T, sortbuf, sort_cap, sh);
             }
             if (R > 0) {
                 // window -> offs[] (entries are read, then a barrier, then written: offs[i] overlays sortbuf[i / 2])
@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t want = n_acc < want_max ? n_acc : want_max;
     if (want > (uint32_t)sort_cap) want = (uint32_t)sort_cap;
     const unsigned long long T = radix_select_nth(K, n_acc, want, sh);
-    gather_sorted(K, n_acc, T, sortbuf, sort_cap, sh);
+    gather_sorted<EPT>(K, n_acc, T, sortbuf, sort_cap, sh);
     for (uint32_t i = tid; i < want; i += kST) {
         const uint32_t off = (uint32_t)sortbuf[i];
         const int y = off / w, x = off - y * w;
@@ -1812,16 +1812,29 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         // second region of the same size: per window entry the ranks of up to four candidates that can suppress it
         const int use_lists = 2 * lds <= 128 * 1024;
         if (use_lists) lds *= 2;
-        if (!ctx->attr_done["corner_select"]) {
-            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corner_select_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            ctx->attr_done["corner_select"] = true;
-        }
         const float md = (float)min_distance;
         const float md2 = (float)(min_distance * min_distance);   // `minDistance *= minDistance` in double, compared as float
         VsProfScope ps(ctx, "corner_select_kernel");
-        corner_select_kernel<<<frames, kST, lds, ctx->stream>>>(eig, w, h, state, keys, counts, key_cap, max_corners, md,
-                                                                md2, sort_cap, xy, n, kp_stride, overflow, fmax, quality, use_lists);
+#define VS_SELECT_LAUNCH(EPT)                                                                                              \
+    do {                                                                                                                   \
+        if (!ctx->attr_done["corner_select" #EPT]) {                                                                       \
+            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corner_select_kernel<EPT>),                     \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                     \
+            ctx->attr_done["corner_select" #EPT] = true;                                                                   \
+        }                                                                                                                  \
+        corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(eig, w, h, state, keys, counts, key_cap, max_corners, \
+                                                                     md, md2, sort_cap, xy, n, kp_stride, overflow, fmax,  \
+                                                                     quality, use_lists);                                  \
+    } while (0)
+        switch (sort_cap / kST) {
+            case 1: VS_SELECT_LAUNCH(1); break;
+            case 2: VS_SELECT_LAUNCH(2); break;
+            case 4: VS_SELECT_LAUNCH(4); break;
+            case 8: VS_SELECT_LAUNCH(8); break;
+            case 16: VS_SELECT_LAUNCH(16); break;
+            default: VS_SELECT_LAUNCH(0); break;   // sort_cap < kST
+        }
+#undef VS_SELECT_LAUNCH
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
