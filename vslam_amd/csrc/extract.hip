@@ -1654,14 +1654,10 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
     const int slot = tid >> 5, l32 = tid & 31;
     const uint8_t *img = blurred + (size_t)f * w * h;
     const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)f * kp_stride;
-    int cxs[kRGroups], cys[kRGroups];   // this slot's keypoint of every group (a group's 32 lanes read the same one)
-#pragma unroll
-    for (int g = 0; g < kRGroups; g++) {
+    auto keypoint = [&](int g) -> float2 {   // this slot's keypoint of group g (its 32 lanes read the same one)
         const int kp = kp0 + g * (kKT / 32) + slot;
-        const float2 p = kp < n ? P[kp] : make_float2(31.f, 31.f);
-        cxs[g] = (int)rintf(p.x);
-        cys[g] = (int)rintf(p.y);
-    }
+        return (g < kRGroups && kp < n) ? P[kp] : make_float2(-1.f, -1.f);   // x < 0: no keypoint
+    };
     // dwords per staged row: columns (cx - R) & ~3 .. cx + R, at most 2R + 4 bytes; rows keep the fixed pitch
     const int nd = staged ? (2 * R + 3) / 4 + 1 : 1;
     const int total = (2 * R + 1) * nd;
@@ -1682,11 +1678,13 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
             }
         }
     };
-    prefetch(cxs[0], cys[0], kp0 + slot < n);
-#pragma unroll
+    // keypoints are read two groups ahead and patches one group ahead, so no load waits on another inside the loop
+    float2 p0 = keypoint(0), p1 = keypoint(1);
+    int cx = (int)rintf(p0.x), cy = (int)rintf(p0.y);
+    bool live = p0.x >= 0.f;
+    prefetch(cx, cy, live);
+#pragma unroll 1   // one copy of the body: the fully unrolled form needs twice the registers and halves the occupancy
     for (int g = 0; g < kRGroups; g++) {
-        const int kp = kp0 + g * (kKT / 32) + slot;
-        const bool live = kp < n;
         if (staged && live) {
             int r = r0, c = c0;
 #pragma unroll
@@ -1701,9 +1699,12 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
             }
         }
         __syncthreads();   // also orders the first s_off reads after their writes
-        if (g + 1 < kRGroups) prefetch(cxs[g + 1], cys[g + 1], kp + (kKT / 32) < n);
+        const float2 p2 = keypoint(g + 2);
+        const int cx_n = (int)rintf(p1.x), cy_n = (int)rintf(p1.y);
+        const bool live_n = p1.x >= 0.f;
+        prefetch(cx_n, cy_n, live_n);
         if (live) {
-            const int cx = cxs[g], cy = cys[g];
+            const int kp = kp0 + g * (kKT / 32) + slot;
             const uint8_t *pb = staged ? reinterpret_cast<const uint8_t *>(s_patch[g & 1][slot]) + R * kRPitch + (cx - ((cx - R) & ~3))
                                        : img + (size_t)cy * w + cx;
             uint32_t val = 0;
@@ -1715,6 +1716,10 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
             }
             desc[((size_t)f * kp_stride + kp) * VSLAM_DESC_BYTES + l32] = (uint8_t)val;
         }
+        cx = cx_n;
+        cy = cy_n;
+        live = live_n;
+        p1 = p2;
     }
 }
 
