@@ -2,18 +2,21 @@
 //
 // Replaces extract_features(Frame&), /root/reference/src/Frame.cpp:53-80:
 //   cv::cvtColor(BGR2GRAY) :56            -> bgr2gray_kernel
-//   cv::goodFeaturesToTrack(...) :61      -> min_eigen_kernel (Sobel + products + 3x3 box + min
-//                                            eigenvalue, LDS tiled, per-frame max),
-//                                            corner_candidates_kernel (threshold + 3x3 local max),
-//                                            corner_select_kernel (greedy min-distance as a
-//                                            fixpoint, top-N by rank, sorted output)
-//   cv::ORB::compute(gray, kps, desc) :68 -> gaussian7_kernel, keypoint_border_kernel,
-//                                            rbrief_kernel
+//   cv::goodFeaturesToTrack(...) :61      -> min_eigen_stream_kernel (Sobel + products + 3x3 box + min eigenvalue +
+//                                            3x3 local maxima, per-frame max; one wave per column strip, rolling
+//                                            registers), corner_select_kernel (exact threshold, greedy
+//                                            min-distance as a fixpoint on the best-ranked window, sorted output).
+//                                            Widths that are not a multiple of 4, and vslam_min_eigen, use the tiled
+//                                            min_eigen_kernel / min_eigen_v4_kernel + corner_candidates_kernel.
+//   cv::ORB::compute(gray, kps, desc) :68 -> gaussian7_stream_kernel (gaussian7_kernel for other widths),
+//                                            keypoint_border_kernel, rbrief_rotate_kernel + rbrief_lds_kernel
+//                                            (rbrief_kernel for other widths)
 // The arithmetic follows the oracle (oracle/vso_extract.cpp) operation for operation; float
 // steps are written so that no contraction or reassociation can occur (-ffp-contract=off).
 //
-// All of these are streaming stencils over 8-bit / 32-bit images: HBM-bound by design, so each
-// kernel reads its input tile once into LDS with coalesced loads and writes each output once.
+// The image kernels read every input byte once and write every output once; what bounds them in practice is
+// VALU issue for the corner response (exact f64 box sums, correctly rounded sqrt) and HBM for the rest
+// (DESIGN.md section 5).
 #include "ctx.h"
 #include <cstdlib>
 
