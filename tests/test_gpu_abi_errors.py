@@ -45,3 +45,31 @@ def test_undefined_reference_inputs_are_defined_here(ctx):
     ctx.synchronize()
     assert int(out["prelim_m"][0]) < 8
     assert out["best"][0].tolist() == [-1, 0, 0, 0] and torch.equal(out["F"], F0)     # `fundamental` left untouched
+
+
+def test_sequence_and_upload_arguments(ctx):
+    """vslam_frontend_sequence needs at least two frames; the upload helpers reject null pointers; page-locked
+    buffers round-trip through the copy stream."""
+    lib, h = ctx.lib, ctx.handle
+    z = C.c_void_p(0)
+    bgr = torch.zeros((1, 64, 64, 3), dtype=torch.uint8, device="cuda")
+    pat = torch.from_numpy(synth.brief_pattern()).cuda()
+    ca, sa = synth.keypoint_rotation()
+    p = ctx._params(50, ca, sa, pat)
+    assert lib.vslam_frontend_sequence(h, C.c_void_p(bgr.data_ptr()), 1, 64, 64, 192, C.byref(p), 50, z, 8, C.c_float(10.0),
+                                       z, z, z, z, z, z, z) == -1
+    assert lib.vslam_upload_async(h, z, z, C.c_size_t(16)) == -1
+    assert lib.vslam_host_alloc(h, C.c_size_t(16), z) == -1
+    # a real round trip: pinned -> device (copy stream) -> fence -> read back on the compute stream
+    hp = C.c_void_p()
+    assert lib.vslam_host_alloc(h, C.c_size_t(4096), C.byref(hp)) == 0
+    src = (C.c_uint8 * 4096).from_address(hp.value)
+    for i in range(4096):
+        src[i] = (i * 7) & 0xFF
+    dst = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    assert lib.vslam_upload_async(h, C.c_void_p(dst.data_ptr()), hp, C.c_size_t(4096)) == 0
+    assert lib.vslam_upload_fence(h) == 0
+    assert lib.vslam_upload_wait(h) == 0
+    ctx.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), (np.arange(4096) * 7 & 0xFF).astype(np.uint8))
+    assert lib.vslam_host_free(h, hp) == 0
