@@ -172,7 +172,7 @@ def main():
     lo, hi = shard.shard_range(world * P, rank, world)          # this rank's slice of the global batch
     seeds = torch.from_numpy(shard.pair_seeds(seed, lo, hi).view(np.int32)).to(dev)
     out = None
-    gathered = torch.empty((world * P, shard.REC_HEAD + 2 * K), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * P, shard.record_words(K)), dtype=torch.int32, device=dev) if world > 1 else None
 
     if lanes > 1:   # lane l owns pairs [l*PL, (l+1)*PL): its "last" and "current" frames made contiguous
         lane_bgr = [torch.cat([bgr[l * PL:(l + 1) * PL], bgr[P + l * PL:P + (l + 1) * PL]]).contiguous() for l in range(lanes)]

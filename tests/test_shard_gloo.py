@@ -40,7 +40,7 @@ def _worker(rank, world, port, total_pairs, K, q):
     best_all = torch.randint(-1, 2000, (total_pairs, 4), generator=g, dtype=torch.int32)
     m_all = torch.randint(0, 2000, (total_pairs, K, 2), generator=g, dtype=torch.int32)
     rec = shard.pack_records(F_all[lo:hi], best_all[lo:hi], m_all[lo:hi])
-    assert rec.shape == (P, shard.REC_HEAD + 2 * K)
+    assert rec.shape == (P, shard.record_words(K))
     out = shard.gather_records(rec, world)
     F, best, m = shard.unpack_records(out, K)
     ok = torch.equal(F.view(torch.int32), F_all.view(torch.int32)) and torch.equal(best, best_all) and torch.equal(m, m_all)

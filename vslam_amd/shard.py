@@ -17,18 +17,29 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def record_words(K):
+    """int32 words per pair record: F (9) + best (4) + one word per match slot."""
+    return REC_HEAD + K
+
+
 def pack_records(F, best, matches):
-    """(P,9) f32, (P,4) i32, (P,K,2) i32 -> (P, 13 + 2K) i32 words (bit-preserving)."""
+    """(P,9) f32, (P,4) i32, (P,K,2) i32 -> (P, 13 + K) i32 words.  F and best are bit-preserving; a match
+    (query index, train index) becomes one word q | t << 16 — keypoint indices are below VSLAM_MAX_KP = 16384 —
+    which halves what the gather moves over xGMI."""
     import torch
-    P = F.shape[0]
-    return torch.cat([F.contiguous().view(torch.int32), best, matches.reshape(P, -1)], dim=1).contiguous()
+    P, K = matches.shape[0], matches.shape[1]
+    assert K <= 32767
+    m = matches.reshape(P, K, 2)
+    packed = m[:, :, 0] | (m[:, :, 1] << 16)
+    return torch.cat([F.contiguous().view(torch.int32), best, packed], dim=1).contiguous()
 
 
 def unpack_records(rec, K):
     import torch
     F = rec[:, :9].contiguous().view(torch.float32)
     best = rec[:, 9:13]
-    matches = rec[:, 13:13 + 2 * K].reshape(rec.shape[0], K, 2)
+    packed = rec[:, 13:13 + K]
+    matches = torch.stack([packed & 0xFFFF, (packed >> 16) & 0xFFFF], dim=2)
     return F, best, matches
 
 
