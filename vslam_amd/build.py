@@ -11,8 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvslam_amd.so")
-SOURCES = ["capi.hip", "match.hip", "ransac.hip", "kdtree.hip", "extract.hip", "orb_grid.hip", "pose.hip", "assoc.hip"]
-HEADERS = ["ctx.h", "introselect.h", os.path.join("..", "..", "include", "vslam_amd.h")]
+SOURCES = ["capi.hip", "match.hip", "ransac.hip", "kdtree.hip", "gray.hip", "response.hip", "select.hip", "blur.hip",
+           "brief.hip", "orb_grid.hip", "pose.hip", "assoc.hip"]
+HEADERS = ["ctx.h", "introselect.h", "image_common.h", os.path.join("..", "..", "include", "vslam_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 
 
