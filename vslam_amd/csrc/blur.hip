@@ -148,9 +148,10 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VS_REQUIRE(ctx, frames > 0 && w >= 4 && h >= 4, VSLAM_ERR_INVALID);
     VsProfScope ps(ctx, "gaussian7_kernel");
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
-        const int segs = h >= 135 ? (h + 45) / 90 : 1;   // about 90 rows per wave
+        const int strips = vs_div_up(w, 256);
+        const int segs = vs_stream_segments(h, frames, strips);
         const int seg_rows = vs_div_up(h, segs);
-        const int strips = vs_div_up(w, 256), per_frame = strips * vs_div_up(segs, 4);
+        const int per_frame = strips * vs_div_up(segs, 4);
         gaussian7_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(gray, w, h, out, seg_rows, frames,
                                                                                           strips, per_frame);
     } else {

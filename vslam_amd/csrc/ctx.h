@@ -99,6 +99,21 @@ __device__ __forceinline__ void vs_xcd_item_block(int linear, int per_item, int 
 #endif
 static inline int vs_xcd_grid(int items, int per_item) { return vs_div_up(items, 8) * 8 * per_item; }
 
+// Row segments per column strip for the streaming image kernels: about 90 rows per wave (6 warm-up rows each,
+// 7 %), more and shorter segments (down to 24 rows) when the batch alone would leave the 1024 SIMDs with fewer
+// than four waves each.
+static inline int vs_stream_segments(int h, int frames, int strips) {
+    int segs = h >= 135 ? (h + 45) / 90 : 1;
+    const long long waves = (long long)frames * strips * segs;
+    if (waves < 4096) {
+        const long long want = (4096 + (long long)frames * strips - 1) / ((long long)frames * strips);
+        const int most = h / 24 > 1 ? h / 24 : 1;
+        segs = (int)(want < most ? want : most);
+        if (segs < 1) segs = 1;
+    }
+    return segs;
+}
+
 // ---- stage launchers implemented in the .hip files (all async on ctx->stream) ----
 int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const uint8_t *d2,
                     const int32_t *n2, int batch, int kp_stride, int32_t *pairs, int32_t *m,

@@ -601,9 +601,10 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
     if (fused) {
         VS_HIP(ctx, hipMemsetAsync(fmax, 0, sizeof(uint32_t) * (size_t)frames, ctx->stream));
         VsProfScope ps(ctx, "min_eigen_kernel");
-        const int segs = h >= 135 ? (h + 45) / 90 : 1;   // about 90 rows per wave
+        const int strips = vs_div_up(w, kSW);
+        const int segs = vs_stream_segments(h, frames, strips);
         const int seg_rows = vs_div_up(h, segs);
-        const int strips = vs_div_up(w, kSW), per_frame = strips * vs_div_up(segs, 4);
+        const int per_frame = strips * vs_div_up(segs, 4);
         min_eigen_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
             gray, w, h, eig, fmax, quality, keys, counts, key_cap, seg_rows, frames, strips, per_frame);
         // A frame whose maximum response is negative has no corners (its threshold max * quality lies above every
