@@ -18,6 +18,7 @@ namespace {
 // each round settles at least the highest-ranked undecided candidate.  The first maxCorners
 // accepted in rank order are then the reference's output, in its order.
 constexpr int kST = 1024;
+constexpr int kDiscMax = 15 * 15;   // (2R+1)^2 positions for R <= 7
 
 struct SelectShared {
     uint32_t wave_cnt[kST / 64];
@@ -383,6 +384,56 @@ __device__ __forceinline__ int nms_collect(const uint32_t *offs, const uint32_t 
     return cnt;
 }
 
+// The same through a list of the offsets inside the distance that the host builds and passes as a kernel argument
+// (disc.e[k] = dy << 16 | (dx & 0xFFFF); scalar loads, no float test per position), four positions per trip so that
+// the four table probes are in flight together; the up to four ranks are packed into one 64-bit value (rank k in
+// bits 16k .. 16k+15, unused ones 0xFFFF).
+struct DiscTable {
+    int n;                 // 0: no table (R == 0 or R > 7); padded to a multiple of 4 with entries that repeat e[0]
+    int e[kDiscMax + 3];
+};
+
+__device__ __forceinline__ int nms_collect_disc(const uint32_t *offs, const uint32_t *slot32, uint32_t smask, int hshift,
+                                                int w, int h, uint32_t i, const DiscTable &disc,
+                                                unsigned long long &packed) {
+    const uint32_t off = offs[i] & kOffMask;
+    const int y = off / w, x = off - y * w;
+    int cnt = 0;
+    packed = ~0ull;
+    for (int e0 = 0; e0 < disc.n; e0 += 4) {
+        uint32_t q[4], hs[4], r[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pk = disc.e[e0 + u];
+            const int dy = pk >> 16, dx = (int)(int16_t)(pk & 0xFFFF);
+            const int yy = y + dy, xx = x + dx;
+            in[u] = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && e0 + u < disc.n;
+            q[u] = (uint32_t)(yy * w + xx);
+            hs[u] = slot_hash(q[u], hshift);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = (slot32[hs[u] >> 1] >> ((hs[u] & 1u) * 16)) & 0xFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!in[u]) continue;
+            uint32_t rr = r[u], hh = hs[u];
+            while (rr != 0xFFFFu) {   // empty on the first probe for almost every position
+                if ((offs[rr] & kOffMask) == q[u]) {
+                    if (rr < i) {
+                        if (cnt < 4) packed = (packed & ~(0xFFFFull << (16 * cnt))) | ((unsigned long long)rr << (16 * cnt));
+                        cnt++;
+                    }
+                    break;
+                }
+                hh = (hh + 1u) & smask;
+                rr = (slot32[hh >> 1] >> ((hh & 1u) * 16)) & 0xFFFFu;
+            }
+        }
+    }
+    return cnt;
+}
+
 // One visit of window entry i through the table: 1 accepted, 2 rejected, 0 still blocked by an undecided
 // better-ranked neighbour.  Statuses are read as they are at this moment (other waves publish theirs
 // without a barrier); they only ever go from undecided to decided, so a stale read costs a later visit.
@@ -432,7 +483,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
     int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
     int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow,
-    const uint32_t *__restrict__ frame_max, double quality, int use_lists) {
+    const uint32_t *__restrict__ frame_max, double quality, int use_lists, const DiscTable disc) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(smem_raw);
     __shared__ SelectShared sh;
@@ -534,13 +585,22 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 {
                     int k = 0;
                     for (uint32_t i = tid; i < got; i += kST, k++) {
-                        uint32_t list[4];
-                        const int cnt = nms_collect(offs, slot32, smask, hshift, w, h, i, R, min_dist_sq, list);
+                        int cnt;
+                        uint2 ranks;
+                        if (disc.n) {
+                            unsigned long long packed;
+                            cnt = nms_collect_disc(offs, slot32, smask, hshift, w, h, i, disc, packed);
+                            ranks = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
+                        } else {
+                            uint32_t list[4];
+                            cnt = nms_collect(offs, slot32, smask, hshift, w, h, i, R, min_dist_sq, list);
+                            ranks = make_uint2(list[0] | (list[1] << 16), list[2] | (list[3] << 16));
+                        }
                         if (cnt == 0) {
                             offs[i] |= 1u << 30;
                             pend &= ~(1u << k);
                         } else if (nbr && cnt <= 4) {
-                            nbr[i] = make_uint2(list[0] | (list[1] << 16), list[2] | (list[3] << 16));
+                            nbr[i] = ranks;
                         } else {
                             full |= 1u << k;
                         }
@@ -743,6 +803,17 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         if (use_lists) lds *= 2;
         const float md = (float)min_distance;
         const float md2 = (float)(min_distance * min_distance);   // `minDistance *= minDistance` in double, compared as float
+        DiscTable disc;   // the offsets with dx^2 + dy^2 < minDistance^2 (float arithmetic as in the kernels), dy-major
+        disc.n = 0;
+        const int R = md >= 1.f ? (int)ceilf(md) : 0;
+        if (R > 0 && R <= 7) {
+            for (int dy = -R; dy <= R; dy++)
+                for (int dx = -R; dx <= R; dx++) {
+                    const float fx = (float)dx, fy = (float)dy;
+                    if ((dx != 0 || dy != 0) && fx * fx + fy * fy < md2) disc.e[disc.n++] = (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xFFFFu));
+                }
+        }
+        for (int k = disc.n; k < disc.n + 3 && k < kDiscMax + 3; k++) disc.e[k] = disc.n ? disc.e[0] : 0;
         VsProfScope ps(ctx, "corner_select_kernel");
 #define VS_SELECT_LAUNCH(EPT)                                                                                              \
     do {                                                                                                                   \
@@ -753,7 +824,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         }                                                                                                                  \
         corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(eig, w, h, state, keys, counts, key_cap, max_corners, \
                                                                      md, md2, sort_cap, xy, n, kp_stride, overflow, fmax,  \
-                                                                     quality, use_lists);                                  \
+                                                                     quality, use_lists, disc);                            \
     } while (0)
         switch (sort_cap / kST) {
             case 1: VS_SELECT_LAUNCH(1); break;
