@@ -1,4 +1,4 @@
-"""A fixed slice of the randomised extraction parity run (tests/fuzz_extract.py)."""
+"""Fixed slices of the randomised parity runs (tests/fuzz_extract.py, tests/fuzz_ransac.py)."""
 import pytest
 
 import fuzz_extract
@@ -8,3 +8,8 @@ pytestmark = pytest.mark.gpu
 
 def test_extraction_stages_on_random_shapes(ctx, oracle):
     assert fuzz_extract.run(ctx, oracle, seed=20261004, cases=150) == 150
+
+
+def test_ransac_kernels_on_random_and_degenerate_inputs(ctx, oracle):
+    import fuzz_ransac
+    assert fuzz_ransac.run(ctx, oracle, seed=20261005, cases=400) == 400
