@@ -34,7 +34,8 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
     px = w * h
     table = {
         "bgr2gray_kernel": 2 * (3 * px + px),
-        "min_eigen_kernel": 2 * (px + 4 * px),
+        "min_eigen_kernel": 2 * (px + 80 * K),        # gray in; out: candidate keys, about 10 per kept keypoint, 8 B each
+                                                      # (the response image itself is not written on this path)
         "corner_select_kernel": 2 * (K * 8),
         "gaussian7_kernel": 2 * (px + px),
         "keypoint_border_kernel": 2 * (K * 8 * 2),
@@ -286,10 +287,10 @@ def main():
                                           "small by design; `valu` prices its instruction mix with the issue costs "
                                           "tools/valu_rate.hip measures (a fraction near or above 1 means the kernel "
                                           "issues as fast as that microbenchmark does)")
-        # the largest HBM-class (stencil) kernel, for the bandwidth view of the step
+        # the HBM-class (stencil) kernel that moves the most bytes, for the bandwidth view of the step
         stencil = [k for k in kernels if k["kernel"] in ("min_eigen_kernel", "gaussian7_kernel", "bgr2gray_kernel")]
         if stencil:
-            st = stencil[0]
+            st = max(stencil, key=lambda k: k["alg_bytes_per_launch"])
             result["roofline_stencil"] = {"kernel": st["kernel"], "bound": "hbm", "achieved": st["alg_GBps"],
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["alg_GBps"] / HBM_PEAK_GBS,
                                           "traffic": pmc_traffic(st["kernel"]) if (args.workload == "C3" and P == WORKLOADS["C3"][4]) else None,

@@ -143,8 +143,9 @@ int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, in
                        uint8_t *gray);
 int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, float *eig,
                         uint32_t *frame_max_bits);
+int vs_response_strips(int w);   // column strips of the streaming response kernel (edge buffer layout)
 int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, double quality,
-                                  float *eig, uint32_t *fmax, unsigned long long *keys, uint32_t *counts,
+                                  float *eig, float *edge, uint32_t *fmax, unsigned long long *keys, uint32_t *counts,
                                   size_t key_cap);
 int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h,
                             int max_corners, double quality, double min_distance, int kp_stride,

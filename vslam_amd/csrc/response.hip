@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
 // corner_select_kernel applies the exact threshold.  Gray rows come straight from
 // global memory (three coalesced dwords per lane and row, issued three rows ahead), responses of the
 // neighbouring lanes come through DPP wave shifts, so the kernel uses no LDS except the candidate queue
-// and has no barriers.  Arithmetic and its order are those of min_eigen_v4_kernel (see there).
+// and has no barriers.  It writes no response image: candidate keys, the frame maximum and each strip's two
+// edge columns of responses are everything later stages read.  Arithmetic and its order are those of min_eigen_v4_kernel (see there).
 //
 // Step t of a segment owning rows [ys, ye):   gray row g = ys - 3 + t   (Sobel parts of row g)
 //   t >= 2: products and their horizontal sums on row p = g - 1
@@ -278,7 +279,7 @@ struct StreamState {
 
 struct StreamArgs {
     const uint8_t *src;          // frame base
-    float *eig;                  // frame base
+    float *edge_l, *edge_r;      // this strip's first / last column of responses, indexed by row
     unsigned long long *queue;   // this wave's LDS queue
     unsigned long long *keys;    // frame base
     uint32_t *count;             // this frame's candidate counter
@@ -381,7 +382,10 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
         for (int i = 0; i < 4; i++) e4[i] = apc[i] - rt[i];
         if (y >= a.ys && y < a.ye && a.own_lane) {
             st.emax = max3_nonan(max3_nonan(e4[0], e4[1], e4[2]), e4[3], st.emax);
-            *reinterpret_cast<float4 *>(a.eig + (size_t)y * a.w + a.x) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            // the response image itself is not kept: all that is read back later are the strip's edge columns
+            // (corner_select_kernel completes the 3x3 test of the neighbouring strips' edge candidates with them)
+            if (lane == 0) a.edge_l[y] = e4[0];
+            if (lane == 63) a.edge_r[y] = e4[3];
         }
         // rows y < 0 or y >= h, and the pixels of lanes outside the image, are never a neighbour of a testable
         // pixel (tests cover rows 1 .. h-2 and columns 1 .. w-2), so their values need no special marking
@@ -418,7 +422,7 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
 }
 
 __global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
-                                                               float *__restrict__ eig, uint32_t *__restrict__ frame_max,
+                                                               float *__restrict__ edge, uint32_t *__restrict__ frame_max,
                                                                double quality, unsigned long long *__restrict__ keys,
                                                                uint32_t *__restrict__ counts, size_t key_cap, int seg_rows,
                                                                int frames, int strips, int per_frame) {
@@ -439,7 +443,8 @@ __global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__
     a.w = w;
     a.h = h;
     a.src = gray + (size_t)f * w * h;
-    a.eig = eig + (size_t)f * w * h;
+    a.edge_l = edge + (((size_t)f * strips + strip) * 2 + 0) * h;   // [frames][strips][2][h]
+    a.edge_r = a.edge_l + h;
     a.queue = queue[wave];
     a.keys = keys + (size_t)f * key_cap;
     a.count = counts + f;
@@ -592,9 +597,12 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
 
 
 // Responses + candidate keys for vs_launch_good_features: keys[f][0 .. counts[f]) = (ordered response << 32 | pixel
-// offset [| kKeyCheck*]), frame_max[f] = ordered maximum response.  counts must be zero on entry.
+// offset [| kKeyCheck*]), frame_max[f] = ordered maximum response.  counts must be zero on entry.  The streaming
+// form fills edge[f][strip][2][h] (vs_response_strips(w) strips) and leaves eig untouched; the tiled form fills eig.
+int vs_response_strips(int w) { return vs_div_up(w, kSW); }
+
 int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, double quality,
-                                  float *eig, uint32_t *fmax, unsigned long long *keys, uint32_t *counts,
+                                  float *eig, float *edge, uint32_t *fmax, unsigned long long *keys, uint32_t *counts,
                                   size_t key_cap) {
     int rc;
     const bool fused = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
@@ -606,7 +614,7 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
         const int seg_rows = vs_div_up(h, segs);
         const int per_frame = strips * vs_div_up(segs, 4);
         min_eigen_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
-            gray, w, h, eig, fmax, quality, keys, counts, key_cap, seg_rows, frames, strips, per_frame);
+            gray, w, h, edge, fmax, quality, keys, counts, key_cap, seg_rows, frames, strips, per_frame);
         // A frame whose maximum response is negative has no corners (its threshold max * quality lies above every
         // response, THRESH_TOZERO clears the image and zeros are not corners); corner_select_kernel's exact
         // threshold drops every key of such a frame, so it needs no special handling here.

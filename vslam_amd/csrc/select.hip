@@ -217,7 +217,7 @@ __device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsig
 template <int EPT>
 __device__ bool rank_window_2pass(unsigned long long *K, uint32_t n, unsigned long long tkey, uint32_t t32,
                                   uint32_t m32, uint32_t &N_io, unsigned long long *sortbuf, int sort_cap,
-                                  SelectShared &sh, uint32_t &n_kept, const float *__restrict__ E, int w) {
+                                  SelectShared &sh, uint32_t &n_kept, const float *__restrict__ edge, int w, int h) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *hist = reinterpret_cast<uint32_t *>(sortbuf);
     const int bins = 2 * sort_cap < 4096 ? 2 * sort_cap : 4096;
@@ -243,14 +243,15 @@ __device__ bool rank_window_2pass(unsigned long long *K, uint32_t n, unsigned lo
                 // strip could not see, then store the key without the flag (or 0: never a candidate)
                 const uint32_t off = lo & kOffMask;
                 const float v = ord2f((uint32_t)(key[u] >> 32));
+                const int y = (int)(off / (uint32_t)w), strip = ((int)off - y * w) >> 8;   // strips are 256 wide
                 bool ok = true;
-                if (lo & kKeyCheckLeft) {
-                    const float *e = E + (size_t)off - w - 1;
-                    ok = ok && !(e[0] > v) && !(e[w] > v) && !(e[2 * (size_t)w] > v);
+                if (lo & kKeyCheckLeft) {    // the last column of the strip to the left, rows y-1 .. y+1
+                    const float *e = edge + (((size_t)(strip - 1)) * 2 + 1) * h + (y - 1);
+                    ok = ok && !(e[0] > v) && !(e[1] > v) && !(e[2] > v);
                 }
-                if (lo & kKeyCheckRight) {
-                    const float *e = E + (size_t)off - w + 1;
-                    ok = ok && !(e[0] > v) && !(e[w] > v) && !(e[2 * (size_t)w] > v);
+                if (lo & kKeyCheckRight) {   // the first column of the strip to the right
+                    const float *e = edge + (((size_t)(strip + 1)) * 2 + 0) * h + (y - 1);
+                    ok = ok && !(e[0] > v) && !(e[1] > v) && !(e[2] > v);
                 }
                 key[u] = ok ? ((key[u] & 0xFFFFFFFF00000000ull) | off) : 0ull;
                 K[i0 + u * kST + tid] = key[u];
@@ -479,7 +480,7 @@ __device__ __forceinline__ int nms_visit_lds(const volatile uint32_t *offs, cons
 //  slow path (N would exceed the LDS sort buffer): suppression over every candidate, then select.
 template <int EPT>
 __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) void corner_select_kernel(
-    const float *__restrict__ eig, int w, int h, uint8_t *__restrict__ state,
+    float *__restrict__ eig, const float *__restrict__ edge, int strips, int w, int h, uint8_t *__restrict__ state,
     unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
     int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
     int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow,
@@ -490,7 +491,8 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
     const int f = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const float *E = eig + (size_t)f * w * h;
+    float *E = eig + (size_t)f * w * h;   // slow path only: responses of the candidates, scattered from their keys
+    const float *EDGE = edge + (size_t)f * strips * 2 * h;
     uint8_t *S = state + (size_t)f * w * h;
     unsigned long long *K = keys + (size_t)f * key_cap;
     float2 *O = reinterpret_cast<float2 *>(out_xy) + (size_t)f * kp_stride;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (R == 0) N = want_max;
         while (true) {
             uint32_t got = N, n_kept = 0;
-            if (!rank_window_2pass<EPT>(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept, E, w)) {
+            if (!rank_window_2pass<EPT>(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept, EDGE, w, h)) {
                 if (!compacted) compact_keys();
                 n_kept = n;
                 got = N < n ? N : n;
@@ -702,7 +704,11 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (R > 0) {
         for (uint32_t i = tid; i < (uint32_t)(w * h); i += kST) S[i] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += kST) S[(uint32_t)K[i]] = 1;
+        for (uint32_t i = tid; i < n; i += kST) {   // nms_visit reads the response of candidates only
+            const unsigned long long key = K[i];
+            S[(uint32_t)key] = 1;
+            E[(uint32_t)key] = ord2f((uint32_t)(key >> 32));
+        }
     }
     if (R > 0) {
         while (true) {
@@ -776,7 +782,10 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     unsigned long long *keys = nullptr;
     int32_t *overflow = nullptr;
     int rc;
+    float *edge = nullptr;
+    const int strips = vs_response_strips(w);
     if ((rc = vs_arena_get(ctx, "gf.eig", sizeof(float) * px * frames, (void **)&eig))) return rc;
+    if ((rc = vs_arena_get(ctx, "gf.edge", sizeof(float) * 2 * (size_t)strips * h * frames, (void **)&edge))) return rc;
     if ((rc = vs_arena_get(ctx, "gf.fmax", sizeof(uint32_t) * (size_t)frames, (void **)&fmax))) return rc;
     if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), (void **)&counts))) return rc;
     if ((rc = vs_arena_get(ctx, "gf.state", px * frames, (void **)&state))) return rc;
@@ -787,7 +796,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     overflow = reinterpret_cast<int32_t *>(counts + frames);
 
     VS_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), ctx->stream));
-    if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, fmax, keys, counts, key_cap))) return rc;
+    if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, edge, fmax, keys, counts, key_cap))) return rc;
     if (ctx->fork_after_eigen) {   // the caller runs an independent stage on the auxiliary stream beside the selection
         VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
@@ -822,8 +831,9 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                     \
             ctx->attr_done["corner_select" #EPT] = true;                                                                   \
         }                                                                                                                  \
-        corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(eig, w, h, state, keys, counts, key_cap, max_corners, \
-                                                                     md, md2, sort_cap, xy, n, kp_stride, overflow, fmax,  \
+        corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(eig, edge, strips, w, h, state, keys, counts, key_cap, \
+                                                                     max_corners, md, md2, sort_cap, xy, n, kp_stride,     \
+                                                                     overflow, fmax,                                       \
                                                                      quality, use_lists, disc);                            \
     } while (0)
         switch (sort_cap / kST) {
