@@ -179,6 +179,7 @@ def main():
     seeds = torch.from_numpy(shard.pair_seeds(seed, lo, hi).view(np.int32)).to(dev)
     out = None
     gathered = torch.empty((world * P, shard.record_words(K)), dtype=torch.int32, device=dev) if multi else None
+    rec_buf = torch.empty((P, shard.record_words(K)), dtype=torch.int32, device=dev) if multi else None
 
     if lanes > 1:   # lane l owns pairs [l*PL, (l+1)*PL): its "last" and "current" frames made contiguous
         lane_bgr = [torch.cat([bgr[l * PL:(l + 1) * PL], bgr[P + l * PL:P + (l + 1) * PL]]).contiguous() for l in range(lanes)]
@@ -198,7 +199,7 @@ def main():
         out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
         if multi:
             # the only exchange on the path: fixed-size per-pair result records to every rank
-            rec = shard.pack_records(out["F"], out["best"], out["matches"])
+            rec = ctx.pack_records(out["F"], out["best"], out["matches"], out=rec_buf)
             if dist.get_backend() == "nccl":
                 dist.all_gather_into_tensor(gathered, rec)   # = shard.gather_records for world > 1
             else:

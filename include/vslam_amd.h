@@ -261,6 +261,12 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
                          float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
                          int32_t *d_matches, int32_t *d_best, float *d_F);
 
+/* Fixed-size per-pair result records for the one exchange of the multi-GPU path: per pair
+ * 13 + kp_stride int32 words = F (9 words, bit-preserving), d_best's 4 words, then one word per match slot,
+ * query index | train index << 16 (keypoint indices are below VSLAM_MAX_KP).  d_records: [pairs][13 + kp_stride]. */
+int vslam_pack_records(vslam_ctx *ctx, const float *d_F, const int32_t *d_best, const int32_t *d_matches,
+                       int pairs, int kp_stride, int32_t *d_records);
+
 /* The same path for a run of consecutive video frames, the shape of the reference's main loop
  * (src/vslam.cpp:60-77: every new frame is matched against the previous one): extract each of the `frames`
  * frames ONCE, then pair i = (frame i, frame i + 1) for i in [0, frames - 1).

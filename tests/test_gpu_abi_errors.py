@@ -73,3 +73,19 @@ def test_sequence_and_upload_arguments(ctx):
     ctx.synchronize()
     assert np.array_equal(dst.cpu().numpy(), (np.arange(4096) * 7 & 0xFF).astype(np.uint8))
     assert lib.vslam_host_free(h, hp) == 0
+
+
+def test_pack_records_kernel_equals_the_python_packing(ctx):
+    """vslam_pack_records writes the record layout shard.pack_records / unpack_records define."""
+    from vslam_amd import shard
+    P, K = 5, 333
+    g = torch.Generator().manual_seed(3)
+    F = torch.randn((P, 9), generator=g).cuda()
+    F[1, 2] = float("nan")
+    best = torch.randint(-1, 5000, (P, 4), generator=g, dtype=torch.int32).cuda()
+    m = torch.randint(0, 16384, (P, K, 2), generator=g, dtype=torch.int32).cuda()
+    rec = ctx.pack_records(F, best, m)
+    ctx.synchronize()
+    assert torch.equal(rec, shard.pack_records(F, best, m))
+    F2, b2, m2 = shard.unpack_records(rec, K)
+    assert torch.equal(F2.view(torch.int32), F.view(torch.int32)) and torch.equal(b2, best) and torch.equal(m2, m)

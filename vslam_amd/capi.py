@@ -24,7 +24,7 @@ SYMBOLS = [
     "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_extract_features", "vslam_extract_features_grid", "vslam_bgr2gray", "vslam_min_eigen",
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points", "vslam_reprojection_filter",
     "vslam_match_features",
-    "vslam_frontend_pairs", "vslam_frontend_sequence",
+    "vslam_frontend_pairs", "vslam_frontend_sequence", "vslam_pack_records",
     "vslam_host_alloc", "vslam_host_free", "vslam_upload_async", "vslam_upload_fence", "vslam_upload_wait",
 ]
 
@@ -376,6 +376,15 @@ class Context:
             self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K),
             _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out["nodes"]),
             _ptr(out["n"]), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"])))
+        return out
+
+    def pack_records(self, F, best, matches, out=None):
+        """(P,9) f32, (P,4) i32, (P,K,2) i32 -> (P, 13 + K) i32 records (same layout as shard.pack_records)."""
+        torch = self.torch
+        P, K = matches.shape[0], matches.shape[1]
+        if out is None:
+            out = torch.empty((P, 13 + K), dtype=torch.int32, device=F.device)
+        self._check(self.lib.vslam_pack_records(self.handle, _ptr(F), _ptr(best), _ptr(matches), C.c_int(P), C.c_int(K), _ptr(out)))
         return out
 
     def frontend_sequence(self, bgr, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, kp_stride=None, out=None):

@@ -546,6 +546,36 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     return rc;
 }
 
+// result records for the gather of the sharded path
+__global__ __launch_bounds__(256) void pack_records_kernel(const float *__restrict__ F, const int32_t *__restrict__ best,
+                                                           const int32_t *__restrict__ matches, int kp_stride,
+                                                           int32_t *__restrict__ rec) {
+    const int p = blockIdx.y;
+    const int words = 13 + kp_stride;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    int32_t v;
+    if (i < 9) v = __float_as_int(F[(size_t)p * 9 + i]);
+    else if (i < 13) v = best[(size_t)p * 4 + (i - 9)];
+    else {
+        const int2 m = reinterpret_cast<const int2 *>(matches)[(size_t)p * kp_stride + (i - 13)];
+        v = m.x | (m.y << 16);
+    }
+    rec[(size_t)p * words + i] = v;
+}
+
+int vslam_pack_records(vslam_ctx *ctx, const float *d_F, const int32_t *d_best, const int32_t *d_matches,
+                       int pairs, int kp_stride, int32_t *d_records) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, d_F && d_best && d_matches && d_records, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, pairs > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
+    dim3 grid(vs_div_up(13 + kp_stride, 256), pairs);
+    pack_records_kernel<<<grid, 256, 0, ctx->stream>>>(d_F, d_best, d_matches, kp_stride, d_records);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
 // consecutive frames: extract once, pair i = (frame i, frame i + 1)
 int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
                             int row_stride, const vslam_extract_params *params, int kp_stride,
