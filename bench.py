@@ -180,6 +180,12 @@ def main():
     out = None
     gathered = torch.empty((world * P, shard.record_words(K)), dtype=torch.int32, device=dev) if multi else None
     rec_buf = torch.empty((P, shard.record_words(K)), dtype=torch.int32, device=dev) if multi else None
+    if multi and dist.get_backend() == "nccl":
+        # set-up, not a step: the RCCL communicator is created by the first collective (seconds); keep that out of the
+        # steps even when the caller asks for no warm-up
+        rec_buf.zero_()
+        dist.all_gather_into_tensor(gathered, rec_buf)
+        torch.cuda.synchronize(dev)
 
     if lanes > 1:   # lane l owns pairs [l*PL, (l+1)*PL): its "last" and "current" frames made contiguous
         lane_bgr = [torch.cat([bgr[l * PL:(l + 1) * PL], bgr[P + l * PL:P + (l + 1) * PL]]).contiguous() for l in range(lanes)]
