@@ -9,6 +9,11 @@ own shard (weak scaling, configs[3]) and the per-pair result records are gathere
 Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of the step,
 timed with HIP events on the stream the kernels run on; `cpu_baseline` is the oracle (a CPU port
 of the reference path, single thread) timed on a bounded sample of the same workload.
+
+`python bench.py --gpus N` with N > 1 and no launcher in the environment starts the N ranks itself:
+the parent (which never imports torch or touches a GPU) runs `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a CHILD process, relays rank 0's line and exits with the child's
+code.  Under a launcher (RANK / WORLD_SIZE set, as the driver does for N > 1) it is a rank.
 """
 import argparse
 import json
@@ -46,19 +51,63 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
         "ransac_sets_kernel": H * 32,
         "ransac_solve_kernel": H * 32 + M * 24 + H * 36,
         "ransac_score_kernel": H * 36 + M * 24 + H * 8,
+        "ransac_count_kernel": H * 36 + M * 24 + H * 4,
+        "ransac_ties_kernel": H * 4 + H * 4,
+        "ransac_tiesum_kernel": M * 24 + 36 + 4,          # per tied hypothesis; at least one per pair
         "ransac_select_kernel": H * 8 + M * 24 + M + M * 8 + 36,
     }
     return table.get(kernel, 0)
 
 
-# VALU issue time per unit of work: the instruction mix of the kernel's inner loop (gfx950 ISA)
-# priced with the per-instruction issue costs tools/valu_rate.hip measures on this GPU (cycles per wave
-# instruction per SIMD at the 2.4 GHz reference clock).  peak = 256 CUs x 4 SIMDs x 2.4 GHz issue cycles/s.
-VALU_PEAK_GCYC = 256 * 4 * 2.4
-VALU_CYCLES = {
-    "ransac_score_kernel": ("(hypothesis, match) evaluations per wave", 172.0),
-    "match_knn2_kernel": ("(query, train) descriptor pairs per wave", 74.0),
+# Arithmetic ceilings for the kernels that are VALU-bound by construction: match and RANSAC.
+#  * flops: SURVEY.md 8(d)'s algorithmic operation count per unit of work against the FP32 vector peak
+#    (MI355X_MICROARCH.md: 157.3 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 x 2.4 GHz);
+#  * VALU issue: vector instructions the kernel actually issued (SQ_INSTS_VALU, rocprofv3 PMC pass of this
+#    command, committed under profiles/ -- an instruction count per wave is a property of the code and the
+#    workload, not of the run) x 2 cycles per wave instruction (a 64-lane wave on a SIMD-32) against
+#    SIMDs x clock.  Both fractions are <= 1 by construction.
+FP32_PEAK_TFLOPS = 157.3
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
+ALG_OPS = {
+    # kernel: (what one unit is, algorithmic ops per unit, kind)
+    "ransac_count_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop"),
+    "ransac_score_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop"),
+    "match_knn2_kernel": ("(query, train) descriptor pairs", 16.0, "int op (8 x 32-bit xor + 8 x popcount)"),
 }
+SQ_PROFILE = os.path.join(ROOT, "profiles", "r02_sq_counters.csv")
+
+
+def sq_counters(kernel):
+    """(waves per launch, VALU instructions per wave) from the committed rocprofv3 SQ counter summary."""
+    import csv
+    import re
+    if not os.path.exists(SQ_PROFILE):
+        return None
+    with open(SQ_PROFILE) as f:
+        for r in csv.DictReader(f):
+            if re.sub(r"_(v4|stream|lds)_kernel$", "_kernel", r["kernel"]) == kernel:
+                return float(r["waves_per_launch"]), float(r["valu_insts_per_wave"])
+    return None
+
+
+def arithmetic_view(kernel, units, ms_per_launch, full_batch):
+    """flops / issue fractions of one launch of `kernel` that processed `units` units of work."""
+    if kernel not in ALG_OPS or ms_per_launch <= 0:
+        return None
+    what, ops, kind = ALG_OPS[kernel]
+    t = ms_per_launch * 1e-3
+    tops = units * ops / t / 1e12
+    view = {"unit_of_work": what, "units_per_launch": units, "ops_per_unit": ops, "op_kind": kind,
+            "achieved": tops, "peak": FP32_PEAK_TFLOPS, "unit": "Tops/s vs the FP32 vector peak (TFLOP/s)",
+            "frac": tops / FP32_PEAK_TFLOPS}
+    sq = sq_counters(kernel) if full_batch else None
+    if sq:
+        waves, insts = sq
+        ginst = waves * insts / t / 1e9
+        view["valu_issue"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU wave-instructions/s",
+                              "frac": ginst / VALU_PEAK_GINST, "waves_per_launch": waves, "valu_insts_per_wave": insts,
+                              "source": os.path.relpath(SQ_PROFILE, ROOT)}
+    return view
 
 
 def pmc_traffic(kernel):
@@ -66,7 +115,7 @@ def pmc_traffic(kernel):
     bench.py cannot collect PMC counters on itself."""
     import csv
     import re
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic_final.csv")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.csv")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -116,6 +165,70 @@ def cpu_baseline(wl, sample_pairs, seed):
             "sample": f"{sample_pairs} pairs of {wl} ({w}x{h}, {K} kp, {H} hyp), oracle single thread, {dt:.1f} s"}
 
 
+def self_launch(n_gpus, argv):
+    """--gpus N > 1 without a launcher: start the ranks as a CHILD process tree (never exec: this parent has
+    not imported torch or touched the GPU, and it stays alive to relay the result).  Rank 0's JSON line is the
+    only thing the ranks write to stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        # the contract is ONE JSON line on stdout; anything else a library printed there (gloo's connection notes)
+        # goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    return proc.returncode
+
+
+def dry_run(args, rank, world):
+    """VSLAM_BENCH_DRY=1: the launcher, process group, record gather and max-over-ranks timing with made-up
+    records and NO kernels (no GPU needed) -- what tests/test_bench_launch.py runs on a CPU-only box.  The line it
+    prints carries no measurement (value null, metric says so)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vslam_amd import shard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    _, _, K, _, P = WORKLOADS[args.workload]
+    P = args.pairs or 4
+    lo, hi = shard.shard_range(world * P, rank, world)
+    g = torch.Generator().manual_seed(99)
+    F_all = torch.randn((world * P, 9), generator=g)
+    best_all = torch.randint(-1, K, (world * P, 4), generator=g, dtype=torch.int32)
+    m_all = torch.randint(0, K, (world * P, K, 2), generator=g, dtype=torch.int32)
+    seeds = shard.pair_seeds(0x5EED0000, lo, hi)
+    assert seeds.shape[0] == P and int(seeds[0]) == (0x5EED0000 ^ lo)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = shard.pack_records(F_all[lo:hi], best_all[lo:hi], m_all[lo:hi])
+        out = shard.gather_records(rec, world, n_items=world * P)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    F, best, m = shard.unpack_records(out, K)
+    ok = torch.equal(F.view(torch.int32), F_all.view(torch.int32)) and torch.equal(best, best_all) and torch.equal(m, m_all)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN: launcher + record gather only, no kernels, not a measurement", "value": None,
+                          "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "gather_ok": bool(flag.item()), "data": "synthetic",
+                          "config": {"workload": "dry", "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}, gloo all_gather of result records"}}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if flag.item() else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +246,12 @@ def main():
                     help="also run two 1 GiB streaming copies (4 B and 16 B per lane) so FETCH_SIZE/WRITE_SIZE can be calibrated")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (child processes; see self_launch)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if os.environ.get("VSLAM_BENCH_DRY"):
+        sys.exit(dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -145,7 +264,8 @@ def main():
     # with a single rank, which is how that path is exercised with RCCL on a one-GPU box
     multi = world > 1 or bool(os.environ.get("VSLAM_BENCH_FORCE_DIST"))
     if args.gpus > 1 or multi:
-        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # VSLAM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks
@@ -159,6 +279,7 @@ def main():
             dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
+    backend_label = {"nccl": "RCCL"}.get(dist.get_backend(), dist.get_backend()) if multi else "none"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -209,7 +330,7 @@ def main():
             if dist.get_backend() == "nccl":
                 dist.all_gather_into_tensor(gathered, rec)   # = shard.gather_records for world > 1
             else:
-                gathered.copy_(shard.gather_records(rec.cpu(), world))
+                gathered.copy_(shard.gather_records(rec.cpu(), world, n_items=world * P))
 
     if args.pmc_calibrate and rank == 0:
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
@@ -260,7 +381,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f32/f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w}x{h}, {K} keypoints, {H} hypotheses, batch {P} pairs per GPU",
-                       "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}" + (", RCCL all_gather of result records" if world > 1 else "")},
+                       "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}" + (f", {backend_label} all_gather of result records" if multi else "")},
             "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
         }
 
@@ -288,17 +409,27 @@ def main():
         result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                               "avg_launch_ms": top["ms_per_launch"]}
-        if top["kernel"] in VALU_CYCLES:
-            what, cyc = VALU_CYCLES[top["kernel"]]
-            work = (H * m_prelim if top["kernel"] == "ransac_score_kernel" else float(n_kp.mean()) ** 2) * P / 64.0
-            gcyc = work * cyc / (top["ms_per_launch"] * 1e-3) / 1e9
-            result["roofline"]["valu"] = {"achieved": gcyc, "peak": VALU_PEAK_GCYC, "unit": "G SIMD issue cycles/s",
-                                          "frac": gcyc / VALU_PEAK_GCYC, "work": what, "cycles_per_unit": cyc}
-            result["roofline"]["note"] = ("this kernel is VALU-issue bound by construction (SURVEY.md 8d): its compulsory "
-                                          "bytes are a rounding error next to its arithmetic, so the HBM fraction is "
-                                          "small by design; `valu` prices its instruction mix with the issue costs "
-                                          "tools/valu_rate.hip measures (a fraction near or above 1 means the kernel "
-                                          "issues as fast as that microbenchmark does)")
+        full_batch = args.workload == "C3" and P == WORKLOADS["C3"][4]   # the shape the committed counter passes ran
+
+        def units_of(kname):   # units of work one launch processes (M = inlier matches, a lower bound of the evaluated ones)
+            return (H * m_prelim if kname.startswith("ransac") else float(n_kp.mean()) ** 2) * P
+
+        by_name = {k["kernel"]: k for k in kernels}
+        av = arithmetic_view(top["kernel"], units_of(top["kernel"]), top["ms_per_launch"], full_batch)
+        if av:
+            result["roofline"]["arithmetic"] = av
+            result["roofline"]["note"] = ("VALU-bound by construction (SURVEY.md 8d): the compulsory bytes of this kernel are a "
+                                          "rounding error next to its arithmetic, so the HBM fraction is small by design; "
+                                          "`arithmetic` gives its algorithmic op rate against the FP32 vector peak and its issued "
+                                          "VALU instructions against the chip's issue rate")
+        if "match_knn2_kernel" in by_name:   # north_star names the match kernel: always report it
+            mk = by_name["match_knn2_kernel"]
+            result["roofline_match"] = {"kernel": "match_knn2_kernel", "bound": "hbm", "achieved": mk["alg_GBps"], "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": mk["alg_GBps"] / HBM_PEAK_GBS,
+                                        "traffic": pmc_traffic("match_knn2_kernel") if full_batch else None,
+                                        "avg_launch_ms": mk["ms_per_launch"],
+                                        "arithmetic": arithmetic_view("match_knn2_kernel", units_of("match_knn2_kernel"),
+                                                                      mk["ms_per_launch"], full_batch)}
         # the HBM-class (stencil) kernel that moves the most bytes, for the bandwidth view of the step
         stencil = [k for k in kernels if k["kernel"] in ("min_eigen_kernel", "gaussian7_kernel", "bgr2gray_kernel")]
         if stencil:

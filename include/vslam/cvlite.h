@@ -7,10 +7,12 @@
 #include <opencv2/core.hpp>
 #define VSLAM_HAVE_OPENCV 1
 #else
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <type_traits>
 #include <vector>
 
 #define CV_8U 0
@@ -27,11 +29,19 @@ struct Point_ {
     T x, y;
     Point_() : x(0), y(0) {}
     Point_(T x_, T y_) : x(x_), y(y_) {}
+    // OpenCV converts through saturate_cast: float -> int rounds to nearest-even (cvRound), it does not truncate
     template <typename U>
-    Point_(const Point_<U> &o) : x(static_cast<T>(o.x)), y(static_cast<T>(o.y)) {}
+    Point_(const Point_<U> &o) : x(convert_(o.x)), y(convert_(o.y)) {}
     T dot(const Point_ &o) const { return x * o.x + y * o.y; }
     bool operator==(const Point_ &o) const { return x == o.x && y == o.y; }
     bool operator!=(const Point_ &o) const { return !(*this == o); }
+
+   private:
+    template <typename U>
+    static T convert_(U v) {
+        if (std::is_integral<T>::value && std::is_floating_point<U>::value) return static_cast<T>(std::lrint(v));
+        return static_cast<T>(v);
+    }
 };
 template <typename T>
 inline Point_<T> operator-(const Point_<T> &a, const Point_<T> &b) { return Point_<T>(a.x - b.x, a.y - b.y); }

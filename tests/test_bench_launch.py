@@ -1,0 +1,36 @@
+"""bench.py --gpus N, started the way the driver starts --gpus 1 (plain `python bench.py ...`, no launcher):
+the parent must spawn the ranks itself as child processes, relay rank 0's single JSON line and exit with the
+children's code.  Runs here without a GPU in the dry mode (gloo, made-up records, no kernels): what is under
+test is the launcher, the process group, the record gather and the one-line contract, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n, extra_env=None):
+    env = dict(os.environ, VSLAM_BENCH_DRY="1", VSLAM_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "0"],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_gpus2_self_launches_child_ranks_and_prints_one_line():
+    r = _run(2)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gather_ok"] is True and d["value"] is None
+    assert "gloo" in d["config"]["parallelism"]
+
+
+def test_world_size_mismatch_is_an_error_not_an_assert():
+    # a launcher that started 1 rank while --gpus says 2
+    r = _run(2, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999",
+                 "VSLAM_BENCH_DRY": ""})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

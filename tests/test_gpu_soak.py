@@ -1,5 +1,6 @@
 """A wider net for rare events: a few dozen frame pairs at the headline shape (1280x720, 2000 keypoints,
-4096 hypotheses) and at a mid-size shape, every output compared with the oracle bit for bit.  The oracle runs
+4096 hypotheses), at a mid-size shape and at the largest configured shape (1920x1080, 4000 keypoints, 8192
+hypotheses), every output compared with the oracle bit for bit.  The oracle runs
 in a process pool (about 0.1 s per pair and core), so the whole test stays within seconds.
 
 What this is for: the code paths that only fire on unusual values — the slow branch of the correctly rounded
@@ -36,7 +37,8 @@ def _oracle_pair(args):
     return p, a, b, m
 
 
-@pytest.mark.parametrize("w,h,K,H,P,seed", [(1280, 720, 2000, 4096, 24, 0x50AC0001), (640, 480, 1000, 1024, 24, 0x50AC0002)])
+@pytest.mark.parametrize("w,h,K,H,P,seed", [(1280, 720, 2000, 4096, 24, 0x50AC0001), (640, 480, 1000, 1024, 24, 0x50AC0002),
+                                             (1920, 1080, 4000, 8192, 6, 0x50AC0005)])   # C3, C2 and C5's shape (BASELINE.json configs[4])
 def test_many_pairs_bit_exact(ctx, w, h, K, H, P, seed):
     bgr = synth.frames_numpy(seed, P, w, h)
     pat = synth.brief_pattern()

@@ -41,7 +41,7 @@ def _worker(rank, world, port, total_pairs, K, q):
     m_all = torch.randint(0, 2000, (total_pairs, K, 2), generator=g, dtype=torch.int32)
     rec = shard.pack_records(F_all[lo:hi], best_all[lo:hi], m_all[lo:hi])
     assert rec.shape == (P, shard.record_words(K))
-    out = shard.gather_records(rec, world)
+    out = shard.gather_records(rec, world, n_items=total_pairs)
     F, best, m = shard.unpack_records(out, K)
     ok = torch.equal(F.view(torch.int32), F_all.view(torch.int32)) and torch.equal(best, best_all) and torch.equal(m, m_all)
     # max-over-ranks timing reduction as bench.py does it
@@ -53,18 +53,22 @@ def _worker(rank, world, port, total_pairs, K, q):
     dist.destroy_process_group()
 
 
-def test_world2_gather_reassembles_global_result():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world,total_pairs", [(2, 64), (2, 65), (3, 64)])   # even slices, and uneven ones (padded gather)
+def test_gather_reassembles_global_result(world, total_pairs):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 64, 50, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_pairs, 50, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == {0: True, 1: True}
+    assert res == {r: True for r in range(world)}

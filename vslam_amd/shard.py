@@ -43,16 +43,38 @@ def unpack_records(rec, K):
     return F, best, matches
 
 
-def gather_records(rec, world, out=None):
-    """all_gather of equally-sized per-rank record blocks -> (world * P, words)."""
+def slice_sizes(n_items, world):
+    """Rows each rank owns under shard_range."""
+    return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
+
+
+def gather_records(rec, world, n_items=None, out=None):
+    """all_gather of the per-rank record blocks -> (n_items, words), rank order = global pair order.
+
+    all_gather_into_tensor needs equal blocks.  With n_items % world == 0 (every BASELINE.json configuration) the
+    slices are equal and the blocks go out as they are; otherwise each rank pads its block to the largest slice
+    (shard_range gives the first n_items % world ranks one row more) and the padding rows are dropped after the
+    gather.  n_items defaults to world * rows, i.e. the even case."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return rec
-    if out is None:
-        out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out, rec)
-    return out
+    rows, words = rec.shape
+    if n_items is None:
+        n_items = world * rows
+    sizes = slice_sizes(n_items, world)
+    if rows != sizes[dist.get_rank()]:
+        raise ValueError(f"rank {dist.get_rank()} holds {rows} records, shard_range({n_items}, rank, {world}) says {sizes[dist.get_rank()]}")
+    cap = max(sizes)
+    if min(sizes) == cap:
+        if out is None:
+            out = torch.empty((n_items, words), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec)
+        return out
+    padded = rec if rows == cap else torch.cat([rec, rec.new_zeros((cap - rows, words))])
+    full = torch.empty((world * cap, words), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(full, padded.contiguous())
+    return torch.cat([full[r * cap:r * cap + sizes[r]] for r in range(world)])
 
 
 def pair_seeds(base_seed, lo, hi):
