@@ -49,6 +49,16 @@ int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream);
 int vslam_ctx_synchronize(vslam_ctx *ctx);
 const char *vslam_last_error(vslam_ctx *ctx);
 const char *vslam_version(void);
+/* Context options (value 0 / 1).
+ *   VSLAM_OPT_RANSAC_ALL_SUMS  0 (default): vslam_ransac_* compute the exact inlier count of every hypothesis and the
+ *       residual sum only where find_fundamental can consult it — for the hypotheses whose count equals the pair's
+ *       maximum (src/RansacFilter.cpp:59: the sum breaks ties at equal count, nothing else).  d_hyp_sum holds NaN
+ *       for every other hypothesis.  Winner, mask, F and matches are the reference's either way.
+ *       1: the residual sum of EVERY hypothesis is computed as the reference does (:138) — what
+ *       RansacFilter::compute_fundamental_residual and the per-hypothesis parity tests ask for; about 2x the
+ *       scoring time.                                                                              */
+#define VSLAM_OPT_RANSAC_ALL_SUMS 1
+int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */
 int vslam_dev_alloc(vslam_ctx *ctx, size_t bytes, void **d_out);
@@ -105,7 +115,8 @@ int vslam_ransac_sets(vslam_ctx *ctx, const uint32_t *d_seeds, const int32_t *d_
  *          d_mask [batch][kp_stride] u8, d_best [batch][4] int32 = winner, count, bits(sum), n_out,
  *          d_matches [batch][kp_stride][2] int32 compacted inlier matches (n_out of them).
  * Workspaces: d_hypF [batch][hyp][9] f32, d_hyp_count [batch][hyp] int32, d_hyp_sum [batch][hyp] f32
- * (also the per-hypothesis outputs the parity tests read).                                   */
+ * (also the per-hypothesis outputs the parity tests read: every F and every count always; every
+ * sum with VSLAM_OPT_RANSAC_ALL_SUMS, otherwise the sums of the maximum-count hypotheses).   */
 int vslam_ransac_fundamental(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2,
                              const int32_t *d_pairs, const int32_t *d_m, const int32_t *d_sets,
                              int batch, int kp_stride, int hyp, float threshold, float *d_F,

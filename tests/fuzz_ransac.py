@@ -17,6 +17,8 @@ def bits(a):
 
 
 def run(ctx, o, seed, cases=None, seconds=None):
+    """Cases alternate between the two scoring paths (default: sums of the maximum-count hypotheses only;
+    VSLAM_OPT_RANSAC_ALL_SUMS: every sum)."""
     rng = np.random.default_rng(seed)
     t0, done = time.time(), 0
     while (cases is None or done < cases) and (seconds is None or time.time() - t0 < seconds):
@@ -52,6 +54,8 @@ def run(ctx, o, seed, cases=None, seconds=None):
             pairs[b, :, 1] = rng.permutation(K) if rng.random() < 0.3 else pairs[b, :, 1]
         sets = np.stack([o.ransac_sets(int(rng.integers(0, 2 ** 31)), int(m[b]), Hy) for b in range(B)])
         t = lambda a: torch.from_numpy(a).cuda()
+        all_sums = done % 2 == 1
+        ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, all_sums)
         out = ctx.ransac_fundamental(t(xy1), t(xy2), t(pairs), t(m), t(sets), thr)
         ctx.synchronize()
         out = {k: v.cpu().numpy() for k, v in out.items()}
@@ -61,13 +65,19 @@ def run(ctx, o, seed, cases=None, seconds=None):
             tag = (done, b, n, Hy, thr)
             assert np.array_equal(bits(out["hypF"][b]), bits(ref["hypF"])), ("hypF",) + tag
             assert np.array_equal(out["hyp_count"][b], ref["hyp_count"]), ("count",) + tag
-            assert np.array_equal(bits(out["hyp_sum"][b]), bits(ref["hyp_sum"])), ("sum",) + tag
+            tied = ref["hyp_count"] == ref["hyp_count"].max()
+            assert np.array_equal(bits(out["hyp_sum"][b])[tied], bits(ref["hyp_sum"])[tied]), ("tied sums",) + tag
+            if all_sums:
+                assert np.array_equal(bits(out["hyp_sum"][b]), bits(ref["hyp_sum"])), ("sum",) + tag
+            else:
+                assert np.isnan(out["hyp_sum"][b][~tied]).all(), ("untied sums must be NaN",) + tag
             assert out["best"][b, 0] == ref["winner"], ("winner",) + tag
             if ref["winner"] >= 0:
                 assert out["best"][b, 1] == ref["count"], ("best count",) + tag
                 assert np.array_equal(bits(out["F"][b]), bits(ref["F"])), ("F",) + tag
                 assert np.array_equal(out["mask"][b, :n], ref["mask"]), ("mask",) + tag
         done += 1
+    ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
     return done
 
 

@@ -34,13 +34,19 @@ def test_ransac_golden(ctx):
     sets = ctx.ransac_sets(t(G["r_sets_seed"].view(np.int32)), torch.tensor([37], dtype=torch.int32).cuda(), 16)
     assert np.array_equal(sets[0].cpu().numpy(), G["r_sets"])
     pairs = np.zeros((1, 120, 2), np.int32); pairs[0, :100] = G["r_pairs"]
-    out = ctx.ransac_fundamental(t(G["r_p1"][None]), t(G["r_p2"][None]), t(pairs), torch.tensor([100], dtype=torch.int32).cuda(),
-                                 t(G["r_fsets"][None]), 10.0)
-    out = {k: v.cpu().numpy() for k, v in out.items()}
-    assert np.array_equal(bits(out["hypF"][0]), bits(G["r_hypF"]))
-    assert np.array_equal(out["hyp_count"][0], G["r_hyp_count"]) and np.array_equal(bits(out["hyp_sum"][0]), bits(G["r_hyp_sum"]))
-    assert np.array_equal(bits(out["F"][0]), bits(G["r_F"])) and np.array_equal(out["mask"][0, :100], G["r_mask"])
-    assert out["best"][0, :3].tolist() == G["r_best"].tolist()
+    for all_sums in (False, True):   # default scoring path (sums where the accept rule can consult them), then every sum
+        ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, all_sums)
+        out = ctx.ransac_fundamental(t(G["r_p1"][None]), t(G["r_p2"][None]), t(pairs), torch.tensor([100], dtype=torch.int32).cuda(),
+                                     t(G["r_fsets"][None]), 10.0)
+        ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
+        out = {k: v.cpu().numpy() for k, v in out.items()}
+        assert np.array_equal(bits(out["hypF"][0]), bits(G["r_hypF"]))
+        assert np.array_equal(out["hyp_count"][0], G["r_hyp_count"])
+        tied = G["r_hyp_count"] == G["r_hyp_count"].max()
+        assert np.array_equal(bits(out["hyp_sum"][0])[tied], bits(G["r_hyp_sum"])[tied])
+        assert np.array_equal(bits(out["hyp_sum"][0]), bits(G["r_hyp_sum"])) if all_sums else np.isnan(out["hyp_sum"][0][~tied]).all()
+        assert np.array_equal(bits(out["F"][0]), bits(G["r_F"])) and np.array_equal(out["mask"][0, :100], G["r_mask"])
+        assert out["best"][0, :3].tolist() == G["r_best"].tolist()
 
 
 def test_extract_and_pipeline_golden(ctx):

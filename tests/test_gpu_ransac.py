@@ -13,6 +13,27 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+@pytest.fixture(params=["ties", "all"])
+def sums_mode(ctx, request):
+    """Both scoring paths: the default one (exact counts everywhere, exact sums for the maximum-count hypotheses only:
+    ransac_count / ties / tiesum kernels) and VSLAM_OPT_RANSAC_ALL_SUMS (ransac_score_kernel: every sum)."""
+    ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, request.param == "all")
+    yield request.param
+    ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
+
+
+def check_sums(got_sum, ref_count, ref_sum, mode, tag=None):
+    """Sums the reference can consult (count == the pair's maximum) are bit-exact in both modes; the others are
+    bit-exact in 'all' mode and NaN ("not computed") in the default mode."""
+    ref_count = np.asarray(ref_count)
+    tied = ref_count == ref_count.max()
+    assert np.array_equal(bits(got_sum)[tied], bits(ref_sum)[tied]), tag
+    if mode == "all":
+        assert np.array_equal(bits(got_sum), bits(ref_sum)), tag
+    else:
+        assert np.isnan(got_sum[~tied]).all(), tag
+
+
 @pytest.mark.parametrize("H", [64, 333])
 def test_sets_bit_exact(ctx, oracle, H):
     ms = [8, 9, 37, 150, 1100, 4000, 5, 0]
@@ -56,7 +77,7 @@ def _batch(seed0, sizes, K, W, H):
     return xy1, xy2, pairs, m
 
 
-def test_fundamental_bit_exact(ctx, oracle):
+def test_fundamental_bit_exact(ctx, oracle, sums_mode):
     K, Hy, thr = 600, 192, 10.0
     sizes = [300, 8, 9, 600, 150, 5]
     xy1, xy2, pairs, m = _batch(500, sizes, K, 1280, 720)
@@ -77,7 +98,7 @@ def test_fundamental_bit_exact(ctx, oracle):
         bad = np.nonzero((bits(out["hypF"][b]) != bits(ref["hypF"])).any(axis=1))[0]
         assert bad.size == 0, f"item {b}: {bad.size} of {Hy} hypothesis F differ, first {bad[:5]}"
         assert np.array_equal(out["hyp_count"][b], ref["hyp_count"]), b
-        assert np.array_equal(bits(out["hyp_sum"][b]), bits(ref["hyp_sum"])), b
+        check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], sums_mode, b)
         assert out["best"][b, 0] == ref["winner"] and out["best"][b, 1] == ref["count"], b
         assert out["best"][b, 2] == int(bits(np.float32(ref["sum"])).reshape(-1)[0]), b
         assert np.array_equal(bits(out["F"][b]), bits(ref["F"])), b
@@ -87,7 +108,7 @@ def test_fundamental_bit_exact(ctx, oracle):
         assert np.array_equal(out["matches"][b, :len(keep)], keep), b
 
 
-def test_degenerate_geometry_still_bit_exact(ctx, oracle):
+def test_degenerate_geometry_still_bit_exact(ctx, oracle, sums_mode):
     """Collinear / repeated / zero-motion samples drive the Jacobi into its zero-singular-value
     branch (the cv::RNG fill) and the residual into 0/0 and x/0; NaN and Inf must propagate
     identically (NaN <= thr is false, src/RansacFilter.cpp:130)."""
@@ -109,13 +130,13 @@ def test_degenerate_geometry_still_bit_exact(ctx, oracle):
         ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b], sets[b], thr)
         assert np.array_equal(bits(out["hypF"][b]), bits(ref["hypF"])), b
         assert np.array_equal(out["hyp_count"][b], ref["hyp_count"]), b
-        assert np.array_equal(bits(out["hyp_sum"][b]), bits(ref["hyp_sum"])), b
+        check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], sums_mode, b)
         assert out["best"][b, 0] == ref["winner"], b
         if ref["winner"] >= 0:
             assert np.array_equal(out["mask"][b], ref["mask"]), b
 
 
-def test_match_features_pipeline_bit_exact(ctx, oracle):
+def test_match_features_pipeline_bit_exact(ctx, oracle, sums_mode):
     """match -> sets -> RANSAC -> inlier filter through vslam_match_features (src/Frame.cpp:82-105)."""
     B, K, Hy, thr = 4, 500, 256, 10.0
     n1s, n2s = [500, 420, 300, 12], [480, 500, 310, 40]
@@ -146,3 +167,71 @@ def test_match_features_pipeline_bit_exact(ctx, oracle):
         assert out["best"][b, 3] == k, b
         assert np.array_equal(out["matches"][b, :k], ref["matches"]), b
         assert np.array_equal(bits(out["F"][b]), bits(ref["F"])), b
+
+
+def _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr):
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = ctx.ransac_fundamental(t(xy1), t(xy2), t(pairs), t(m), t(sets), thr)
+    ctx.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _compare(out, ref, b, n, mode):
+    assert np.array_equal(out["hyp_count"][b], ref["hyp_count"]), b
+    check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], mode, b)
+    assert out["best"][b, 0] == ref["winner"], b
+    if ref["winner"] >= 0:
+        assert out["best"][b, 1] == ref["count"], b
+        assert out["best"][b, 2] == int(bits(np.float32(ref["sum"])).reshape(-1)[0]), b
+        assert np.array_equal(bits(out["F"][b]), bits(ref["F"])), b
+        assert np.array_equal(out["mask"][b, :n], ref["mask"]), b
+
+
+def test_counts_first_path_at_scale(ctx, oracle, sums_mode):
+    """The shapes the counting kernel is built around: more than one wave of matches per workgroup (1024 / wave), a
+    partial last sub-block, hypothesis counts that are not a multiple of 64, and thresholds that put many
+    evaluations next to the decision boundary."""
+    for K, sizes, Hy, thr in ((2304, [2304, 1500, 1025, 257, 256, 64], 200, 10.0), (2304, [1800, 700], 130, 3.0),
+                              (2304, [1200, 2000], 64, 40.0), (16384, [16384, 9000, 4097], 70, 10.0)):
+        xy1, xy2, pairs, m = _batch(900 + Hy, sizes, K, 1280, 720)
+        sets = np.stack([oracle.ransac_sets(70 + b, n, Hy) for b, n in enumerate(sizes)])
+        out = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
+        for b, n in enumerate(sizes):
+            ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], thr)
+            _compare(out, ref, b, n, sums_mode)
+
+
+def test_many_tied_hypotheses(ctx, oracle, sums_mode):
+    """Identical frames on an integer grid: a large share of the hypotheses reaches the same (maximal) count, so the
+    tie list is long (the lane-per-hypothesis form of ransac_tiesum_kernel) and the winner is decided by the sums."""
+    K, Hy, thr = 400, 512, 10.0
+    rng = np.random.default_rng(17)
+    xy1 = np.zeros((2, K, 2), np.float32); xy2 = np.zeros((2, K, 2), np.float32)
+    xy1[0] = np.rint(rng.uniform(0, 640, (K, 2))); xy2[0] = xy1[0]
+    xy1[1] = np.rint(rng.uniform(0, 64, (K, 2))); xy2[1] = xy1[1] + np.float32(1.0)
+    pairs = np.tile(np.stack([np.arange(K), np.arange(K)], 1)[None], (2, 1, 1)).astype(np.int32)
+    m = np.array([K, 300], np.int32)
+    sets = np.stack([oracle.ransac_sets(31 + b, int(m[b]), Hy) for b in range(2)])
+    out = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
+    tied = []
+    for b in range(2):
+        n = int(m[b])
+        ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], thr)
+        tied.append(int((ref["hyp_count"] == ref["hyp_count"].max()).sum()))
+        _compare(out, ref, b, n, sums_mode)
+    assert max(tied) >= 192, tied      # the long-list form really ran
+
+
+def test_threshold_and_scale_outside_certified_range(ctx, oracle, sums_mode):
+    """Thresholds / coordinates beyond the range the cheap evaluation's bounds are derived for (thr in [2^-20, 2^20],
+    |coordinates| <= 2^20): every evaluation must take the exact sequence and still give the reference's counts."""
+    K, Hy = 300, 96
+    for scale, thr in ((1.0, 1e-7), (1.0, 3e6), (4e6, 10.0), (1e-9, 10.0), (1.0, -1.0), (1.0, float("inf"))):
+        xy1, xy2, pairs, m = _batch(1200, [300, 77], K, 1280, 720)
+        xy1 = (xy1 * np.float32(scale)).astype(np.float32); xy2 = (xy2 * np.float32(scale)).astype(np.float32)
+        sets = np.stack([oracle.ransac_sets(5 + b, int(m[b]), Hy) for b in range(2)])
+        out = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
+        for b in range(2):
+            n = int(m[b])
+            ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], thr)
+            _compare(out, ref, b, n, sums_mode)

@@ -196,6 +196,13 @@ int vslam_ctx_synchronize(vslam_ctx *ctx) {
 
 const char *vslam_last_error(vslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, option == VSLAM_OPT_RANSAC_ALL_SUMS, VSLAM_ERR_INVALID);
+    ctx->ransac_all_sums = value != 0;
+    return VSLAM_OK;
+}
+
 int vslam_dev_alloc(vslam_ctx *ctx, size_t bytes, void **d_out) {
     VS_REQUIRE(ctx, ctx && d_out, VSLAM_ERR_INVALID);
     VS_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));

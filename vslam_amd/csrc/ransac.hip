@@ -679,6 +679,408 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// compute_fundamental_residual, counts first (the default scoring path)
+// ------------------------------------------------------------------------------------------
+// find_fundamental consults a hypothesis' residual SUM only to break ties among hypotheses whose inlier COUNT
+// equals the running maximum (RansacFilter.cpp:59); every other sum is computed by the reference and thrown away.
+// So the scoring is split:
+//   ransac_count_kernel   exact inlier count of every hypothesis, from a cheap evaluation of e with a certified
+//                         error band; the few evaluations that land inside the band are re-done with the exact
+//                         sequence (residual_e) -> the counts are the reference's counts, bit for bit;
+//   ransac_ties_kernel    C* = max count per pair and the list of hypotheses that reach it;
+//   ransac_tiesum_kernel  the exact, index-ordered double sum (cv::sum, :138) for those hypotheses only;
+//   ransac_select_kernel  unchanged: it only ever reads the sums of hypotheses whose count is C*.
+// ransac_score_kernel above (all counts and all sums, exact) stays behind VSLAM_OPT_RANSAC_ALL_SUMS for callers that
+// want every per-hypothesis sum (the per-hypothesis parity tests, RansacFilter::compute_fundamental_residual).
+//
+// The cheap evaluation.  With u = 2^-24 and everything finite, the reference computes (floats, round to nearest)
+//   a_k = (f_3k x1 + f_3k+1 y1) + f_3k+2,  n = (x2 a0 + y2 a1) + a2,  nn = n n,  dd = a0 a0,  q = nn / dd,
+//   t_0 = float(double(f0 x2 + f3 y2) + f6),  t_1 likewise,  e = ((q + a1 a1) + t0 t0) + t1 t1.
+// The count kernel computes a_k, n, nn, dd with the SAME operations (they are cheap and any other order would need
+// a cancellation-dependent bound), and replaces the rest by
+//   q~ = nn * v_rcp_f32(dd)                        relative error <= 3.1 u  (rcp: 1 ulp)
+//   t~_k = fma(f_3+k, y2, fma(f_k, x2, f_6+k))     |t~_k - t_k| <= 3.1 u S_k,  S_k = |f_k x2| + |f_3+k y2| + |f_6+k|
+//   g = fma(t~1, t~1, fma(t~0, t~0, fma(a1, a1, q~)))
+// All terms of e are squares, so every rounding is a relative error on a non-negative sum; with
+// beta = 4.04 u (S_0 + S_1) (S bounded per hypothesis with the pair's largest |x2|, |y2|) and s = sqrt(thr):
+//   g < lo = (s (1 - 2^-20) - 1.01 beta)^2                  =>  e <  thr   (e <= (sqrt(g) + 1.005 beta)^2 (1 + 12 u))
+//   g > hi = (s (1 + 2^-20) + 2.5 beta)^2 (1 + 2^-20)       =>  e >  thr   (e >= ((sqrt(g)(1 - 1.7u) - beta)^2 - 2 beta^2)(1 - 9u))
+// Anything else — g inside [lo, hi], NaN, a denormal / zero dd (where v_rcp_f32 is not a 1-ulp reciprocal), or a
+// hypothesis / pair outside the range the bounds were derived for (|f| <= 2^10, coordinates <= 2^20, thr in
+// [2^-20, 2^20], so nothing overflows before the true value does) — is decided by the exact sequence.  On image
+// data the band is about 0.3 % of thr wide (beta is a few 1e-3: f32 cancellation in t~), i.e. about one evaluation
+// in a thousand, so uncertain evaluations are not handled in place (a wave would leave the fast path for 6 % of its
+// evaluations) but queued per wave in LDS as (hypothesis, match) words and evaluated 64 at a time with full lanes.
+//
+// Mapping: one workgroup = 64 hypotheses x all matches of a pair; a wave owns up to 1024 matches, 16 per lane, held
+// in registers for the 64 hypotheses; the hypothesis' record (F, lo, hi) is a broadcast read from LDS;
+// v_cmp writes lane masks to SGPRs, counting is s_bcnt1 on the scalar unit (north_star: ballot / popcount).
+constexpr int kCntHyps = 64;
+constexpr int kCntMaxWaves = VSLAM_MAX_KP / 1024;
+constexpr int kCntQueue = 1088;   // words per wave: 16 evaluations x 64 lanes of one hypothesis + 63 carried over
+constexpr float kCntTinyDD = 0x1p-120f;
+// A hypothesis as the counting loop reads it from LDS: every element of F twice (so a register pair is the
+// (f, f) operand of a packed instruction with no v_mov), then lo, hi.  kCntRec floats per hypothesis.
+constexpr int kCntRec = 20;
+static_assert(kCntMaxWaves * 64 <= 1024, "one workgroup must be able to hold VSLAM_MAX_KP matches");
+
+struct CntCoords {
+    v2f x1[8], y1[8], x2[8], y2[8];   // [j] = the lane's matches 2j and 2j+1
+};
+
+// exact evaluation of up to 64 queued (hypothesis, match) words, one per lane
+__device__ __forceinline__ void cnt_drain(const volatile uint32_t *q, int from, int count, int lane, const float *s_rec,
+                                          int *s_cnt, const float2 *P1, const float2 *P2, const int2 *PR, float threshold) {
+    if (lane < count) {
+        const uint32_t en = q[from + lane];
+        const int hh = (int)(en >> 16), i = (int)(en & 0xFFFFu);
+        ResidualF R;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.f[k] = s_rec[hh * kCntRec + 2 * k];
+        residual_prepare(R);
+        const int2 pr = PR[i];
+        const float2 a = P1[pr.x], c = P2[pr.y];
+        const float e = residual_e(R, make_float4(a.x, a.y, c.x, c.y), (double)c.x, (double)c.y);
+        if (e <= threshold) atomicAdd(&s_cnt[hh], 1);
+    }
+}
+
+// append the lanes of mask U (evaluation `idx0 + lane` of hypothesis hh) to the wave's queue
+__device__ __forceinline__ void cnt_push(volatile uint32_t *q, int &qn, unsigned long long U, int hh, int idx0, int lane) {
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(U >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)U, 0u));
+    if ((U >> lane) & 1ull) q[qn + rank] = ((uint32_t)hh << 16) | (uint32_t)(idx0 + lane);
+    qn += __popcll(U);
+}
+
+struct CntRec {
+    v2f f[9];
+    float lo, hi;
+};
+
+// two matches per lane under one hypothesis: count of the certain inliers and masks of the undecided lanes
+template <bool PARTIAL>
+__device__ __forceinline__ void cnt_eval_pair(const CntRec &R, const v2f X1, const v2f Y1, const v2f X2, const v2f Y2, int idx0,
+                                              int lane, int m, int &cnt, unsigned long long &ua, unsigned long long &ub,
+                                              float &ddmin) {
+    const v2f a0 = (R.f[0] * X1 + R.f[1] * Y1) + R.f[2];
+    const v2f a1 = (R.f[3] * X1 + R.f[4] * Y1) + R.f[5];
+    const v2f a2 = (R.f[6] * X1 + R.f[7] * Y1) + R.f[8];
+    const v2f n = (X2 * a0 + Y2 * a1) + a2;
+    const v2f nn = n * n, dd = a0 * a0;
+    ddmin = fminf(ddmin, fminf(dd.x, dd.y));
+    v2f r;
+    r.x = __builtin_amdgcn_rcpf(dd.x);
+    r.y = __builtin_amdgcn_rcpf(dd.y);
+    v2f g = __builtin_elementwise_fma(a1, a1, nn * r);
+    const v2f t0 = __builtin_elementwise_fma(R.f[3], Y2, __builtin_elementwise_fma(R.f[0], X2, R.f[6]));
+    const v2f t1 = __builtin_elementwise_fma(R.f[4], Y2, __builtin_elementwise_fma(R.f[1], X2, R.f[7]));
+    g = __builtin_elementwise_fma(t0, t0, g);
+    g = __builtin_elementwise_fma(t1, t1, g);
+    // v_cmp straight into a lane mask (llvm::CmpInst predicates: 4 = ordered <, 2 = ordered >)
+    unsigned long long ia = __builtin_amdgcn_fcmpf(g.x, R.lo, 4), oa = __builtin_amdgcn_fcmpf(g.x, R.hi, 2);
+    unsigned long long ib = __builtin_amdgcn_fcmpf(g.y, R.lo, 4), ob = __builtin_amdgcn_fcmpf(g.y, R.hi, 2);
+    if (PARTIAL) {
+        const unsigned long long va = __builtin_amdgcn_sicmp(idx0 + lane, m, 40);        // 40 = signed <
+        const unsigned long long vb = __builtin_amdgcn_sicmp(idx0 + 64 + lane, m, 40);
+        ia &= va;
+        ib &= vb;
+        ua = va & ~(ia | oa);
+        ub = vb & ~(ib | ob);
+    } else {
+        ua = ~(ia | oa);
+        ub = ~(ib | ob);
+    }
+    cnt += __popcll(ia) + __popcll(ib);
+}
+
+// one 256-match sub-block (4 evaluations per lane) of hypothesis hh: certified count into cnt, the rest queued
+template <bool PARTIAL>
+__device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &T, int s, int idx0, int hh, int lane, int m, int &cnt,
+                                              volatile uint32_t *q, int &qn) {
+    unsigned long long u0, u1, u2, u3;
+    int c = 0;
+    float ddmin = INFINITY;
+    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s], T.y1[2 * s], T.x2[2 * s], T.y2[2 * s], idx0, lane, m, c, u0, u1, ddmin);
+    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s + 1], T.y1[2 * s + 1], T.x2[2 * s + 1], T.y2[2 * s + 1], idx0 + 128, lane, m, c, u2, u3, ddmin);
+    if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, 9) != 0ull) {   // 9 = unordered or <: some dd is zero / denormal (or NaN)
+        // nothing of this sub-block is certified: all of it is queued
+        c = 0;
+        u0 = __builtin_amdgcn_sicmp(idx0 + lane, m, 40);
+        u1 = __builtin_amdgcn_sicmp(idx0 + 64 + lane, m, 40);
+        u2 = __builtin_amdgcn_sicmp(idx0 + 128 + lane, m, 40);
+        u3 = __builtin_amdgcn_sicmp(idx0 + 192 + lane, m, 40);
+    }
+    cnt += c;
+    if ((u0 | u1 | u2 | u3) != 0ull) {
+        if (u0) cnt_push(q, qn, u0, hh, idx0, lane);
+        if (u1) cnt_push(q, qn, u1, hh, idx0 + 64, lane);
+        if (u2) cnt_push(q, qn, u2, hh, idx0 + 128, lane);
+        if (u3) cnt_push(q, qn, u3, hh, idx0 + 192, lane);
+    }
+}
+
+// grid = (ceil(hyp / 64), batch), block = 64 * ceil(kp_stride / 1024) threads
+__global__ __launch_bounds__(1024) void ransac_count_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
+    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler may know it
+    const int nw = (int)(blockDim.x >> 6);
+    const int hbase = blockIdx.x * kCntHyps;
+    const int nh = min(kCntHyps, hyp - hbase);
+    const int m = min(m_arr[b], kp_stride);
+    if (m < VSLAM_SET_SIZE) return;   // uniform per workgroup
+
+    __shared__ __align__(16) float s_rec[kCntHyps * kCntRec];
+    __shared__ int s_cnt[kCntHyps];
+    __shared__ float s_cmax[2 * kCntMaxWaves];
+    extern __shared__ uint32_t s_queue[];   // kCntQueue words per wave
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+
+    // this wave's matches: the pair's 256-match sub-blocks dealt evenly over the waves (at most 4 each)
+    const int total_sub = (m + 255) >> 8;
+    const int sub_lo = (total_sub * wave) / nw, sub_hi = (total_sub * (wave + 1)) / nw;
+    const int nsub = sub_hi - sub_lo;
+    const int base = sub_lo * 256;
+    const bool part = sub_hi == total_sub && (m & 255) != 0;   // this wave's last sub-block has lanes beyond m
+    const int nfull = part ? nsub - 1 : nsub;
+
+    CntCoords T;
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float2 a[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, c[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+        if ((j >> 1) < nsub) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int i = min(base + (2 * j + k) * 64 + lane, m - 1);   // lanes beyond m repeat the last match (masked later)
+                const int2 pr = PR[i];
+                a[k] = P1[pr.x];
+                c[k] = P2[pr.y];
+                c1 = fmaxf(c1, fmaxf(fabsf(a[k].x), fabsf(a[k].y)));
+                c2 = fmaxf(c2, fmaxf(fabsf(c[k].x), fabsf(c[k].y)));
+            }
+        }
+        T.x1[j].x = a[0].x; T.x1[j].y = a[1].x;
+        T.y1[j].x = a[0].y; T.y1[j].y = a[1].y;
+        T.x2[j].x = c[0].x; T.x2[j].y = c[1].x;
+        T.y2[j].x = c[0].y; T.y2[j].y = c[1].y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c1 = fmaxf(c1, __shfl_xor(c1, off, 64));
+        c2 = fmaxf(c2, __shfl_xor(c2, off, 64));
+    }
+    if (lane == 0) {
+        s_cmax[2 * wave] = c1;
+        s_cmax[2 * wave + 1] = c2;
+    }
+    if (tid < kCntHyps) s_cnt[tid] = 0;
+    __syncthreads();
+
+    if (tid < kCntHyps) {   // the hypothesis records: F, lo, hi
+        float C1 = 0.f, C2 = 0.f;
+        for (int w = 0; w < nw; w++) {
+            C1 = fmaxf(C1, s_cmax[2 * w]);
+            C2 = fmaxf(C2, s_cmax[2 * w + 1]);
+        }
+        const float *src = hypF + ((size_t)b * hyp + min(hbase + tid, hyp - 1)) * 9;
+        float f[9];
+        bool ok = threshold >= 0x1p-20f && threshold <= 0x1p20f && C1 <= 0x1p20f && C2 <= 0x1p20f;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            f[k] = src[k];
+            ok = ok && fabsf(f[k]) <= 1024.f;   // false for NaN
+        }
+        const double S = ((double)fabsf(f[0]) + (double)fabsf(f[3]) + (double)fabsf(f[1]) + (double)fabsf(f[4])) * (double)C2 +
+                         (double)fabsf(f[6]) + (double)fabsf(f[7]);
+        const double beta = 4.04 * 0x1p-24 * S + 1e-30;
+        const double sq = sqrt((double)threshold);
+        const double lo_r = sq * (1.0 - 0x1p-20) - 1.01 * beta;
+        const double hi_r = sq * (1.0 + 0x1p-20) + 2.5 * beta;
+        float lo = lo_r > 0 ? (float)(lo_r * lo_r * (1.0 - 0x1p-22)) : -1.f;
+        float hi = (float)(hi_r * hi_r * (1.0 + 0x1p-20) * (1.0 + 0x1p-22));
+        if (!ok) {
+            lo = -1.f;       // g >= 0 or NaN: never below lo
+            hi = INFINITY;   // never above hi: every evaluation takes the exact sequence
+        }
+        float *d = s_rec + tid * kCntRec;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            d[2 * k] = f[k];
+            d[2 * k + 1] = f[k];
+        }
+        d[18] = lo;
+        d[19] = hi;
+    }
+    __syncthreads();
+
+    if (nsub > 0) {
+        volatile uint32_t *q = s_queue + wave * kCntQueue;
+        int qn = 0;
+        for (int hh = 0; hh < nh; hh++) {
+            CntRec R;
+            {
+                const float4 *r4 = reinterpret_cast<const float4 *>(s_rec + hh * kCntRec);
+                const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3], v4 = r4[4];
+                R.f[0].x = v0.x; R.f[0].y = v0.y; R.f[1].x = v0.z; R.f[1].y = v0.w;
+                R.f[2].x = v1.x; R.f[2].y = v1.y; R.f[3].x = v1.z; R.f[3].y = v1.w;
+                R.f[4].x = v2.x; R.f[4].y = v2.y; R.f[5].x = v2.z; R.f[5].y = v2.w;
+                R.f[6].x = v3.x; R.f[6].y = v3.y; R.f[7].x = v3.z; R.f[7].y = v3.w;
+                R.f[8].x = v4.x; R.f[8].y = v4.y;
+                R.lo = v4.z;
+                R.hi = v4.w;
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                if (s < nfull)
+                    cnt_sub_block<false>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn);
+                else if (s == nfull && part)
+                    cnt_sub_block<true>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn);
+            }
+            if (lane == 0 && cnt) atomicAdd(&s_cnt[hh], cnt);
+            while (qn >= 64) {   // a hypothesis adds at most 1024 words to the 63 left over: kCntQueue holds them
+                cnt_drain(q, qn - 64, 64, lane, s_rec, s_cnt, P1, P2, PR, threshold);
+                qn -= 64;
+            }
+        }
+        if (qn > 0) cnt_drain(q, 0, qn, lane, s_rec, s_cnt, P1, P2, PR, threshold);
+    }
+    __syncthreads();
+    if (tid < nh) {
+        hyp_count[(size_t)b * hyp + hbase + tid] = s_cnt[tid];
+        hyp_sum[(size_t)b * hyp + hbase + tid] = __int_as_float(0x7FC00000);   // defined by ransac_tiesum_kernel where it matters
+    }
+}
+
+// C* = the pair's largest inlier count and the hypotheses that reach it, in index order.  tie_n[2b] = how many,
+// tie_n[2b+1] = C*.  One workgroup per pair.
+constexpr int kTieThreads = 256;
+__global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t *__restrict__ m_arr, int hyp,
+                                                                  const int32_t *__restrict__ hyp_count,
+                                                                  int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_w[kTieThreads / 64];
+    __shared__ int s_base;
+    if (m_arr[b] < VSLAM_SET_SIZE) {
+        if (tid == 0) {
+            tie_n[2 * b] = 0;
+            tie_n[2 * b + 1] = 0;
+        }
+        return;
+    }
+    const int32_t *C = hyp_count + (size_t)b * hyp;
+    int32_t *TI = tie_idx + (size_t)b * hyp;
+    int mx = 0;
+    for (int i = tid; i < hyp; i += kTieThreads) mx = max(mx, C[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) s_w[wave] = mx;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    mx = s_w[0];
+    for (int w = 1; w < kTieThreads / 64; w++) mx = max(mx, s_w[w]);
+    __syncthreads();
+    for (int i0 = 0; i0 < hyp; i0 += kTieThreads) {
+        const int i = i0 + tid;
+        const bool tie = i < hyp && C[i] == mx;
+        const unsigned long long bal = __ballot(tie);
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_w[w];
+        if (tie) TI[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < kTieThreads / 64; w++) tot += s_w[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        tie_n[2 * b] = s_base;
+        tie_n[2 * b + 1] = mx;
+    }
+}
+
+// The exact residual sum (sequential double accumulation in match order, then one rounding to float: the value
+// RansacFilter.cpp:138 returns) for the hypotheses in the tie list.  grid = (ceil(hyp / 64), batch), one wave each.
+//   few ties : a wave per tied hypothesis; the 64 lanes evaluate 64 consecutive matches, park e in LDS, and the sum
+//              walks them in order (every lane computes the same total from broadcast reads);
+//   many ties: a lane per tied hypothesis walking all matches (the shape of ransac_score_kernel), 64 per wave.
+constexpr int kTieLaneMode = 192;
+__global__ __launch_bounds__(64) void ransac_tiesum_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, const float *__restrict__ hypF,
+    const int32_t *__restrict__ tie_idx, const int32_t *__restrict__ tie_n, float *__restrict__ hyp_sum) {
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int m = min(m_arr[b], kp_stride);
+    if (m < VSLAM_SET_SIZE) return;
+    const int T = tie_n[2 * b];
+    const int32_t *TI = tie_idx + (size_t)b * hyp;
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    __shared__ __align__(16) float buf[64];
+
+    if (T >= kTieLaneMode) {
+        if ((int)blockIdx.x * 64 >= T) return;
+        const int k = blockIdx.x * 64 + lane;
+        const int h = TI[min(k, T - 1)];
+        ResidualF R;
+        const float *src = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; j++) R.f[j] = src[j];
+        residual_prepare(R);
+        double total = 0;
+        for (int i = 0; i < m; i++) {   // uniform addresses: the match is the same for every lane
+            const int2 pr = PR[i];
+            const float2 a = P1[pr.x], c = P2[pr.y];
+            total += (double)residual_e(R, make_float4(a.x, a.y, c.x, c.y), (double)c.x, (double)c.y);
+        }
+        if (k < T) hyp_sum[(size_t)b * hyp + h] = (float)total;
+        return;
+    }
+    for (int k = blockIdx.x; k < T; k += gridDim.x) {
+        const int h = TI[k];
+        ResidualF R;
+        const float *src = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; j++) R.f[j] = src[j];
+        residual_prepare(R);
+        double total = 0;
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            float e = 0.f;
+            if (i < m) {
+                const int2 pr = PR[i];
+                const float2 a = P1[pr.x], c = P2[pr.y];
+                e = residual_e(R, make_float4(a.x, a.y, c.x, c.y), (double)c.x, (double)c.y);
+            }
+            __syncthreads();   // one wave: orders this store after the previous round's reads
+            buf[lane] = e;
+            __syncthreads();
+            const int cnt = min(64, m - i0);
+            int t = 0;
+            for (; t + 4 <= cnt; t += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(buf + t);
+                total += (double)v.x;
+                total += (double)v.y;
+                total += (double)v.z;
+                total += (double)v.w;
+            }
+            for (; t < cnt; t++) total += (double)buf[t];
+        }
+        if (lane == 0) hyp_sum[(size_t)b * hyp + h] = (float)total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // find_fundamental's accept rule + winner mask + inlier filter
 // ------------------------------------------------------------------------------------------
 constexpr int kSelThreads = 256;
@@ -847,11 +1249,40 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
     VS_REQUIRE(ctx, xy1 && xy2 && pairs && m && hypF && F && mask && best && matches, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, hyp_count && hyp_sum, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && hyp > 0, VSLAM_ERR_INVALID);
-    {
+    if (ctx->ransac_all_sums) {
         VsProfScope ps(ctx, "ransac_score_kernel");
         dim3 grid(vs_div_up(hyp, kScoreThreads), batch);
         ransac_score_kernel<<<grid, kScoreThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp,
                                                                      threshold, hypF, hyp_count, hyp_sum);
+    } else {
+        VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
+        int32_t *tie_idx = nullptr, *tie_n = nullptr;
+        int rc;
+        if ((rc = vs_arena_get(ctx, "ransac.tie_idx", sizeof(int32_t) * (size_t)batch * hyp, (void **)&tie_idx))) return rc;
+        if ((rc = vs_arena_get(ctx, "ransac.tie_n", sizeof(int32_t) * 2 * (size_t)batch, (void **)&tie_n))) return rc;
+        {
+            VsProfScope ps(ctx, "ransac_count_kernel");
+            const int waves = min(kCntMaxWaves, vs_div_up(kp_stride, 1024));
+            const size_t queue_bytes = sizeof(uint32_t) * kCntQueue * waves;
+            if (queue_bytes > 40 * 1024 && !ctx->attr_done["ransac_count"]) {   // beyond the default static + dynamic LDS limit
+                VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_count_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * kCntQueue * kCntMaxWaves)));
+                ctx->attr_done["ransac_count"] = true;
+            }
+            dim3 grid(vs_div_up(hyp, kCntHyps), batch);
+            ransac_count_kernel<<<grid, 64 * waves, queue_bytes, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp, threshold, hypF,
+                                                                     hyp_count, hyp_sum);
+        }
+        {
+            VsProfScope ps(ctx, "ransac_ties_kernel");
+            ransac_ties_kernel<<<batch, kTieThreads, 0, ctx->stream>>>(m, hyp, hyp_count, tie_idx, tie_n);
+        }
+        {
+            VsProfScope ps(ctx, "ransac_tiesum_kernel");
+            dim3 grid(vs_div_up(hyp, 64), batch);
+            ransac_tiesum_kernel<<<grid, 64, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp, hypF, tie_idx, tie_n,
+                                                              hyp_sum);
+        }
     }
     {
         VsProfScope ps(ctx, "ransac_select_kernel");
