@@ -52,8 +52,10 @@ const char *vslam_version(void);
 /* Context options (value 0 / 1).
  *   VSLAM_OPT_RANSAC_ALL_SUMS  0 (default): vslam_ransac_* compute the exact inlier count of every hypothesis and the
  *       residual sum only where find_fundamental can consult it — for the hypotheses whose count equals the pair's
- *       maximum (src/RansacFilter.cpp:59: the sum breaks ties at equal count, nothing else).  d_hyp_sum holds NaN
- *       for every other hypothesis.  Winner, mask, F and matches are the reference's either way.
+ *       maximum (src/RansacFilter.cpp:59: the sum breaks ties at equal count, nothing else) and whose sum a
+ *       certified bound does not already place below the winner's.  d_hyp_sum holds NaN for hypotheses below the
+ *       maximum count and -inf for maximum-count hypotheses ruled out by the bound.  Winner, mask, F and matches
+ *       are the reference's either way.
  *       1: the residual sum of EVERY hypothesis is computed as the reference does (:138) — what
  *       RansacFilter::compute_fundamental_residual and the per-hypothesis parity tests ask for; about 2x the
  *       scoring time.                                                                              */

@@ -687,9 +687,11 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
 //   ransac_count_kernel   exact inlier count of every hypothesis, from a cheap evaluation of e with a certified
 //                         error band; the few evaluations that land inside the band are re-done with the exact
 //                         sequence (residual_e) -> the counts are the reference's counts, bit for bit;
-//   ransac_ties_kernel    C* = max count per pair and the list of hypotheses that reach it;
+//   ransac_ties_kernel    C* = max count per pair; of the hypotheses that reach it, those whose sum can still be
+//                         the largest after rounding (the count kernel's cheap sums bound every exact sum);
 //   ransac_tiesum_kernel  the exact, index-ordered double sum (cv::sum, :138) for those hypotheses only;
-//   ransac_select_kernel  unchanged: it only ever reads the sums of hypotheses whose count is C*.
+//   ransac_select_kernel  unchanged: it only ever reads the sums of hypotheses whose count is C*
+//                         (pruned ones hold -inf).
 // ransac_score_kernel above (all counts and all sums, exact) stays behind VSLAM_OPT_RANSAC_ALL_SUMS for callers that
 // want every per-hypothesis sum (the per-hypothesis parity tests, RansacFilter::compute_fundamental_residual).
 //
@@ -761,7 +763,7 @@ struct CntRec {
 template <bool PARTIAL>
 __device__ __forceinline__ void cnt_eval_pair(const CntRec &R, const v2f X1, const v2f Y1, const v2f X2, const v2f Y2, int idx0,
                                               int lane, int m, int &cnt, unsigned long long &ua, unsigned long long &ub,
-                                              float &ddmin) {
+                                              float &ddmin, v2f &acc) {
     const v2f a0 = (R.f[0] * X1 + R.f[1] * Y1) + R.f[2];
     const v2f a1 = (R.f[3] * X1 + R.f[4] * Y1) + R.f[5];
     const v2f a2 = (R.f[6] * X1 + R.f[7] * Y1) + R.f[8];
@@ -780,30 +782,46 @@ __device__ __forceinline__ void cnt_eval_pair(const CntRec &R, const v2f X1, con
     unsigned long long ia = __builtin_amdgcn_fcmpf(g.x, R.lo, 4), oa = __builtin_amdgcn_fcmpf(g.x, R.hi, 2);
     unsigned long long ib = __builtin_amdgcn_fcmpf(g.y, R.lo, 4), ob = __builtin_amdgcn_fcmpf(g.y, R.hi, 2);
     if (PARTIAL) {
-        const unsigned long long va = __builtin_amdgcn_sicmp(idx0 + lane, m, 40);        // 40 = signed <
-        const unsigned long long vb = __builtin_amdgcn_sicmp(idx0 + 64 + lane, m, 40);
+        const bool in_a = idx0 + lane < m, in_b = idx0 + 64 + lane < m;
+        const unsigned long long va = __ballot(in_a), vb = __ballot(in_b);
         ia &= va;
         ib &= vb;
         ua = va & ~(ia | oa);
         ub = vb & ~(ib | ob);
+        g.x = in_a ? g.x : 0.f;
+        g.y = in_b ? g.y : 0.f;
     } else {
         ua = ~(ia | oa);
         ub = ~(ib | ob);
     }
     cnt += __popcll(ia) + __popcll(ib);
+    acc += g;   // running sum of the cheap values: ransac_ties_kernel prunes the tie list with it
+}
+
+// sum over the 64 lanes, in a fixed order, left in lane 63 (row butterflies, then row_bcast 15 / 31)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    const int z = 0;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(z, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(z, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(z, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(z, __float_as_int(v), 0x140, 0xF, 0xF, false));   // row_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(z, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(z, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+    return v;
 }
 
 // one 256-match sub-block (4 evaluations per lane) of hypothesis hh: certified count into cnt, the rest queued
 template <bool PARTIAL>
 __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &T, int s, int idx0, int hh, int lane, int m, int &cnt,
-                                              volatile uint32_t *q, int &qn) {
+                                              volatile uint32_t *q, int &qn, v2f &acc, int *s_unk) {
     unsigned long long u0, u1, u2, u3;
     int c = 0;
     float ddmin = INFINITY;
-    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s], T.y1[2 * s], T.x2[2 * s], T.y2[2 * s], idx0, lane, m, c, u0, u1, ddmin);
-    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s + 1], T.y1[2 * s + 1], T.x2[2 * s + 1], T.y2[2 * s + 1], idx0 + 128, lane, m, c, u2, u3, ddmin);
+    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s], T.y1[2 * s], T.x2[2 * s], T.y2[2 * s], idx0, lane, m, c, u0, u1, ddmin, acc);
+    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s + 1], T.y1[2 * s + 1], T.x2[2 * s + 1], T.y2[2 * s + 1], idx0 + 128, lane, m, c, u2, u3, ddmin, acc);
     if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, 9) != 0ull) {   // 9 = unordered or <: some dd is zero / denormal (or NaN)
-        // nothing of this sub-block is certified: all of it is queued
+        // nothing of this sub-block is certified: all of it is queued, and the hypothesis' cheap sum means nothing
+        if (lane == 0) s_unk[hh] = 1;
         c = 0;
         u0 = __builtin_amdgcn_sicmp(idx0 + lane, m, 40);
         u1 = __builtin_amdgcn_sicmp(idx0 + 64 + lane, m, 40);
@@ -823,7 +841,7 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &
 __global__ __launch_bounds__(1024) void ransac_count_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
-    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum) {
+    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler may know it
     const int nw = (int)(blockDim.x >> 6);
@@ -835,6 +853,8 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     __shared__ __align__(16) float s_rec[kCntHyps * kCntRec];
     __shared__ int s_cnt[kCntHyps];
     __shared__ float s_cmax[2 * kCntMaxWaves];
+    __shared__ float s_part[kCntMaxWaves * kCntHyps];   // per wave and hypothesis: sum of the cheap values
+    __shared__ int s_unk[kCntHyps];                     // hypothesis whose cheap sum is not certified
     extern __shared__ uint32_t s_queue[];   // kCntQueue words per wave
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
     const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
@@ -878,9 +898,15 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
         s_cmax[2 * wave] = c1;
         s_cmax[2 * wave + 1] = c2;
     }
-    if (tid < kCntHyps) s_cnt[tid] = 0;
+    if (tid < kCntHyps) {
+        s_cnt[tid] = 0;
+        s_unk[tid] = 0;
+        for (int w = 0; w < nw; w++) s_part[w * kCntHyps + tid] = 0.f;
+    }
     __syncthreads();
 
+    double my_beta = 0;     // thread t < 64 keeps hypothesis t's beta for the bound on its cheap sum
+    bool my_ok = false;
     if (tid < kCntHyps) {   // the hypothesis records: F, lo, hi
         float C1 = 0.f, C2 = 0.f;
         for (int w = 0; w < nw; w++) {
@@ -907,6 +933,8 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
             lo = -1.f;       // g >= 0 or NaN: never below lo
             hi = INFINITY;   // never above hi: every evaluation takes the exact sequence
         }
+        my_beta = beta;
+        my_ok = ok;
         float *d = s_rec + tid * kCntRec;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
@@ -935,14 +963,19 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
                 R.hi = v4.w;
             }
             int cnt = 0;
+            v2f acc;
+            acc.x = 0.f;
+            acc.y = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (s < nfull)
-                    cnt_sub_block<false>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn);
+                    cnt_sub_block<false>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk);
                 else if (s == nfull && part)
-                    cnt_sub_block<true>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn);
+                    cnt_sub_block<true>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk);
             }
             if (lane == 0 && cnt) atomicAdd(&s_cnt[hh], cnt);
+            const float part_sum = wave_sum_to_lane63(acc.x + acc.y);
+            if (lane == 63) s_part[wave * kCntHyps + hh] = part_sum;
             while (qn >= 64) {   // a hypothesis adds at most 1024 words to the 63 left over: kCntQueue holds them
                 cnt_drain(q, qn - 64, 64, lane, s_rec, s_cnt, P1, P2, PR, threshold);
                 qn -= 64;
@@ -953,18 +986,38 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     __syncthreads();
     if (tid < nh) {
         hyp_count[(size_t)b * hyp + hbase + tid] = s_cnt[tid];
-        hyp_sum[(size_t)b * hyp + hbase + tid] = __int_as_float(0x7FC00000);   // defined by ransac_tiesum_kernel where it matters
+        hyp_sum[(size_t)b * hyp + hbase + tid] = __int_as_float(0x7FC00000);   // defined by ransac_ties / tiesum where it matters
+        // The cheap values' sum S~ and a bound on |S~ - (exact double sum of the e)|: per evaluation
+        // |g - e| <= 12 u max(g, e) + beta (2 sqrt(g) + beta)  (the derivation above), summed with Cauchy-Schwarz
+        // (sum sqrt(g_i) <= sqrt(M sum g_i)), plus 2^-20 S~ for the float additions that formed S~.
+        float S = 0.f;
+        for (int w = 0; w < nw; w++) S += s_part[w * kCntHyps + tid];
+        float err = INFINITY;
+        if (my_ok && !s_unk[tid]) {
+            const double Sd = (double)S;
+            err = (float)((2.02 * my_beta * sqrt((double)m * Sd) + (double)m * my_beta * my_beta + 0x1p-18 * Sd) * (1.0 + 0x1p-20));
+        }
+        float2 *ap = reinterpret_cast<float2 *>(approx) + (size_t)b * hyp + hbase + tid;
+        *ap = make_float2(S, err);
     }
 }
 
-// C* = the pair's largest inlier count and the hypotheses that reach it, in index order.  tie_n[2b] = how many,
-// tie_n[2b+1] = C*.  One workgroup per pair.
+// C* = the pair's largest inlier count, and which of the hypotheses that reach it need their exact residual sum.
+// The accept rule keeps, among the hypotheses with count C*, the one with the largest float sum (first index among equal
+// sums; the NaN cases are spelled out at ransac_select_kernel).  The counting kernel left a cheap sum S~ and a bound err
+// with |S~ - exact sum| <= err for every hypothesis, so a tied hypothesis whose S~ + err lies below the best S~ - err (by
+// more than float rounding can close: factor 1 - 2^-20) cannot win and cannot tie after rounding: its hyp_sum becomes
+// -inf (ordered below every real sum, never NaN).  The others — normally a handful — go on the list for
+// ransac_tiesum_kernel.  Hypotheses with an uncertified cheap sum carry err = inf and always stay.
+// tie_n[2b] = list length, tie_n[2b+1] = C*.  One workgroup per pair.
 constexpr int kTieThreads = 256;
 __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t *__restrict__ m_arr, int hyp,
                                                                   const int32_t *__restrict__ hyp_count,
+                                                                  const float *__restrict__ approx, float *__restrict__ hyp_sum,
                                                                   int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_w[kTieThreads / 64];
+    __shared__ float s_f[kTieThreads / 64];
     __shared__ int s_base;
     if (m_arr[b] < VSLAM_SET_SIZE) {
         if (tid == 0) {
@@ -974,6 +1027,8 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
         return;
     }
     const int32_t *C = hyp_count + (size_t)b * hyp;
+    const float2 *A = reinterpret_cast<const float2 *>(approx) + (size_t)b * hyp;
+    float *Sm = hyp_sum + (size_t)b * hyp;
     int32_t *TI = tie_idx + (size_t)b * hyp;
     int mx = 0;
     for (int i = tid; i < hyp; i += kTieThreads) mx = max(mx, C[i]);
@@ -984,16 +1039,36 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
     __syncthreads();
     mx = s_w[0];
     for (int w = 1; w < kTieThreads / 64; w++) mx = max(mx, s_w[w]);
+    // best certified lower bound among the tied hypotheses
+    float L = -INFINITY;
+    for (int i = tid; i < hyp; i += kTieThreads)
+        if (C[i] == mx) {
+            const float2 a = A[i];
+            const float lowb = a.x - a.y;
+            if (lowb > L) L = lowb;   // false for NaN
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) L = fmaxf(L, __shfl_xor(L, off, 64));
+    if (lane == 0) s_f[wave] = L;
+    __syncthreads();
+    L = s_f[0];
+    for (int w = 1; w < kTieThreads / 64; w++) L = fmaxf(L, s_f[w]);
+    const float cut = L > 0.f ? L * (1.f - 0x1p-20f) : -INFINITY;   // sums are >= 0: nothing is pruned against a bound <= 0
     __syncthreads();
     for (int i0 = 0; i0 < hyp; i0 += kTieThreads) {
         const int i = i0 + tid;
-        const bool tie = i < hyp && C[i] == mx;
-        const unsigned long long bal = __ballot(tie);
+        bool keep = false;
+        if (i < hyp && C[i] == mx) {
+            const float2 a = A[i];
+            keep = !(a.x + a.y < cut);   // NaN or inf bounds stay
+            if (!keep) Sm[i] = -INFINITY;
+        }
+        const unsigned long long bal = __ballot(keep);
         if (lane == 0) s_w[wave] = __popcll(bal);
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < wave; w++) off += s_w[w];
-        if (tie) TI[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        if (keep) TI[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
         __syncthreads();
         if (tid == 0) {
             int tot = 0;
@@ -1037,11 +1112,19 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
 #pragma unroll
         for (int j = 0; j < 9; j++) R.f[j] = src[j];
         residual_prepare(R);
+        __shared__ float4 sc[64];
         double total = 0;
-        for (int i = 0; i < m; i++) {   // uniform addresses: the match is the same for every lane
-            const int2 pr = PR[i];
+        for (int i0 = 0; i0 < m; i0 += 64) {   // 64 matches staged by the wave, then walked in order as broadcasts
+            const int2 pr = PR[min(i0 + lane, m - 1)];
             const float2 a = P1[pr.x], c = P2[pr.y];
-            total += (double)residual_e(R, make_float4(a.x, a.y, c.x, c.y), (double)c.x, (double)c.y);
+            __syncthreads();
+            sc[lane] = make_float4(a.x, a.y, c.x, c.y);
+            __syncthreads();
+            const int cnt = min(64, m - i0);
+            for (int t = 0; t < cnt; t++) {
+                const float4 v = sc[t];
+                total += (double)residual_e(R, v, (double)v.z, (double)v.w);
+            }
         }
         if (k < T) hyp_sum[(size_t)b * hyp + h] = (float)total;
         return;
@@ -1257,7 +1340,9 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
     } else {
         VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
         int32_t *tie_idx = nullptr, *tie_n = nullptr;
+        float *approx = nullptr;
         int rc;
+        if ((rc = vs_arena_get(ctx, "ransac.approx", sizeof(float) * 2 * (size_t)batch * hyp, (void **)&approx))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.tie_idx", sizeof(int32_t) * (size_t)batch * hyp, (void **)&tie_idx))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.tie_n", sizeof(int32_t) * 2 * (size_t)batch, (void **)&tie_n))) return rc;
         {
@@ -1271,11 +1356,11 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
             }
             dim3 grid(vs_div_up(hyp, kCntHyps), batch);
             ransac_count_kernel<<<grid, 64 * waves, queue_bytes, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp, threshold, hypF,
-                                                                     hyp_count, hyp_sum);
+                                                                     hyp_count, hyp_sum, approx);
         }
         {
             VsProfScope ps(ctx, "ransac_ties_kernel");
-            ransac_ties_kernel<<<batch, kTieThreads, 0, ctx->stream>>>(m, hyp, hyp_count, tie_idx, tie_n);
+            ransac_ties_kernel<<<batch, kTieThreads, 0, ctx->stream>>>(m, hyp, hyp_count, approx, hyp_sum, tie_idx, tie_n);
         }
         {
             VsProfScope ps(ctx, "ransac_tiesum_kernel");
