@@ -7,6 +7,12 @@
 #include "cvlite.h"
 #include "vslam_internal.h"
 
+namespace vslam {
+namespace detail {
+struct RansacAccess;   // the device-side paths in libvslam_host (match_features chains match -> sets -> RANSAC on the GPU)
+}
+}  // namespace vslam
+
 class RansacFilter {
    public:
     const int min_items;        // reference: include/RansacFilter.h:12-14
@@ -36,6 +42,7 @@ class RansacFilter {
     const std::vector<std::vector<int>> &sets() const { return ransac_sets; }
 
    private:
+    friend struct vslam::detail::RansacAccess;
     std::vector<std::vector<int>> ransac_sets;   // reference :24
     u32 seed_ = 0;
     bool has_seed_ = false;

@@ -58,8 +58,12 @@ const char *vslam_version(void);
  *       are the reference's either way.
  *       1: the residual sum of EVERY hypothesis is computed as the reference does (:138) — what
  *       RansacFilter::compute_fundamental_residual and the per-hypothesis parity tests ask for; about 2x the
- *       scoring time.                                                                              */
+ *       scoring time.
+ *   VSLAM_OPT_RANSAC_MIN_MATCHES  8 (default) .. 1: vslam_ransac_evaluate skips items with fewer matches than this
+ *       (no model: winner -1).  find_fundamental needs 8 to draw a set (src/RansacFilter.cpp:24), but
+ *       compute_fundamental_residual scores a GIVEN F on any number of matches (:105-140): its adapter sets 1.   */
 #define VSLAM_OPT_RANSAC_ALL_SUMS 1
+#define VSLAM_OPT_RANSAC_MIN_MATCHES 2
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

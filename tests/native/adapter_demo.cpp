@@ -110,6 +110,89 @@ int main(int argc, char **argv) {
         wr(fo, g.descriptors.data, (size_t)g.descriptors.rows * 32);
         wr(fo, copy.data(), copy.size());            // frame.image aliases the buffer: outlines must be in it
     }
+    // --- compute_fundamental_residual on fewer than 8 matches (the reference's method has no lower limit)
+    {
+        std::vector<std::pair<int, int>> few(matches.begin(), matches.begin() + 5);
+        std::vector<bool> in5;
+        auto r5 = rf.compute_fundamental_residual(frames[0].points, frames[1].points, few, F8, in5);
+        wr_i(fo, r5.first);
+        wr(fo, &r5.second, 4);
+        for (size_t k = 0; k < in5.size(); k++) wr_i(fo, in5[k] ? 1 : 0);
+        std::vector<std::pair<int, int>> none;
+        auto r0 = rf.compute_fundamental_residual(frames[0].points, frames[1].points, none, F8, in5);
+        wr_i(fo, r0.first == 0 && r0.second == 0.f && in5.empty() ? 1 : 0);
+    }
+    // --- the device copy of a tree is validated, not trusted: (1) points edited in place, (2) a tree freed and another
+    // one allocated at the same address with the same point count
+    {
+        std::vector<cv::Point2f> pts(f1.points.begin(), f1.points.begin() + 200);
+        frame_kdtree t1;
+        t1.root = nullptr;
+        construct_kdtree(t1, pts);
+        const cv::Point2f q(pts[7].x + 0.5f, pts[7].y);
+        std::vector<usize> before = radius_search(t1, pts, q, 2);
+        int ok = 1;
+        bool had7 = false;
+        for (usize v : before) had7 |= v == 7;
+        ok &= had7 ? 1 : 0;
+        // (1) move point 7 far away without rebuilding: the reference's search would now test the moved coordinates
+        std::vector<cv::Point2f> moved = pts;
+        moved[7] = cv::Point2f(pts[7].x + 500.f, pts[7].y + 500.f);
+        std::vector<usize> after;
+        radius_search(t1.root, moved, q, after, 2.f, 4.f, 0);                  // host walk of the same nodes = ground truth
+        ok &= radius_search(t1, moved, q, 2) == after ? 1 : 0;
+        // (2) free, then build trees over different points until one lands on the old address
+        void *old_root = t1.root;
+        free(t1.root);
+        std::vector<cv::Point2f> other(f1.points.begin() + 200, f1.points.begin() + 400);
+        int reused = 0;
+        for (int attempt = 0; attempt < 8 && !reused; attempt++) {
+            frame_kdtree t2;
+            t2.root = nullptr;
+            // hand-built (not through construct_kdtree, which would refresh the cache entry): the public recursive overload
+            t2.root = static_cast<frame_kdtree::KDTreeNode *>(malloc(other.size() * sizeof(frame_kdtree::KDTreeNode)));
+            std::vector<usize> idx(other.size());
+            for (usize k = 0; k < idx.size(); k++) idx[k] = k;
+            t2.size = 0;
+            construct_kdtree(t2, other, idx, idx.begin(), idx.end(), 0);
+            if (t2.root == old_root) {
+                reused = 1;
+                const cv::Point2f q2(other[3].x, other[3].y + 0.25f);
+                std::vector<usize> want;
+                radius_search(t2.root, other, q2, want, 2.f, 4.f, 0);
+                ok &= radius_search(t2, other, q2, 2) == want ? 1 : 0;
+                bool has3 = false;
+                for (usize v : want) has3 |= v == 3;
+                ok &= has3 ? 1 : 0;
+            }
+            free(t2.root);
+        }
+        wr_i(fo, ok);
+        wr_i(fo, reused);
+    }
+    // --- the public node-pointer overloads agree with the device entry points, and the macros exist
+    {
+        int ok = 1;
+        const cv::Point2f q(100.5f, 80.25f);
+        cv::Point2f bp;
+        float bd = INFINITY;
+        nearest(kd.root, q, 0, &bp, &bd);
+        ok &= bp == nn ? 1 : 0;
+        std::vector<cv::Point2f> host_hits;
+        radius_search(kd.root, q, host_hits, 12.f, SQ(12.f), 0);
+        ok &= host_hits == near ? 1 : 0;
+        KDTree kd2;
+        kd2.root = static_cast<KDTree::KDTreeNode *>(malloc(f1.points.size() * sizeof(KDTree::KDTreeNode)));
+        kd2.size = 0;
+        std::vector<cv::Point2f> copy = f1.points;
+        construct_kdtree(kd2, copy, copy.begin(), copy.end(), 0);
+        for (size_t k = 0; k < f1.points.size(); k++) ok &= kd2.root[k].pt == kd.root[k].pt ? 1 : 0;   // same pre-order array as the device build
+        free(kd2.root);
+        float neg = -2.5f;
+        cv::Point2f pp(3.f, 4.f);
+        ok &= (ABS(neg) == 2.5f && P(pp, 1) == 4.f) ? 1 : 0;
+        wr_i(fo, ok);
+    }
     fclose(fo);
     for (auto &fr : frames) free(fr.kdtree.root);    // src/vslam.cpp:295-297
     free(kd.root);

@@ -93,4 +93,15 @@ def test_cpp_surfaces_match_oracle(oracle, tmp_path):
     assert np.array_equal(take(np.float32, 2 * gn).reshape(gn, 2).view(np.uint32), gxy.view(np.uint32))
     assert np.array_equal(take(np.uint8, 32 * gn).reshape(gn, 32), gdesc)
     assert np.array_equal(take(np.uint8, w * h * 3).reshape(h, w, 3), ref_img)
+    # compute_fundamental_residual on 5 matches, then on none (src/RansacFilter.cpp:105-140 has no lower limit)
+    mask5, c5, s5 = oracle.residual(ex[0]["xy"], ex[1]["xy"], matches[:5], F8, 10.0)
+    assert int(take(np.int32, 1)[0]) == c5
+    assert take(np.float32, 1).view(np.uint32)[0] == np.float32(s5).view(np.uint32)
+    assert np.array_equal(take(np.int32, 5), mask5.astype(np.int32))
+    assert int(take(np.int32, 1)[0]) == 1
+    # device tree copies are validated: edited points and a recycled root address both give the fresh answer
+    assert int(take(np.int32, 1)[0]) == 1
+    take(np.int32, 1)                      # whether malloc really handed the old address back (usually 1; informational)
+    # node-pointer overloads == device entry points; ABS / P macros
+    assert int(take(np.int32, 1)[0]) == 1
     assert off == len(buf)

@@ -112,3 +112,27 @@ def test_capture_loop_records(oracle, tmp_path, monkeypatch):
     (tmp_path / "one.bgr").write_bytes(clip[0].tobytes())
     frames, pairs = run_sequence(tmp_path / "one.bgr", tmp_path / "none.bin", 3, seed)
     assert pairs == 0 and len((tmp_path / "none.bin").read_bytes()) == 40
+
+
+def test_blank_frames_give_empty_records_whatever_the_batch(tmp_path, monkeypatch):
+    """A dark / blank frame yields no corners, so both pairs it takes part in have fewer than 8 matches: winner -1,
+    no matches, and F all zero in the record (the device leaves F untouched when nothing is accepted — stale values
+    of an earlier batch must not leak into the file, and the file must not depend on the batch size)."""
+    clip = video(6, 92).copy()
+    clip[2] = 40                                              # blank frame: pairs (1,2) and (2,3) have nothing to match
+    vid = tmp_path / "blank.bgr"
+    vid.write_bytes(clip.tobytes())
+    patfile = tmp_path / "pattern.i8"
+    patfile.write_bytes(synth.brief_pattern().tobytes())
+    monkeypatch.setenv("VSLAM_BRIEF_PATTERN", str(patfile))
+    blobs = []
+    for batch in (2, 3, 6):
+        out = tmp_path / f"rec_{batch}.bin"
+        assert run_sequence(vid, out, batch, 7) == (6, 5)
+        blobs.append(out.read_bytes())
+    assert all(b == blobs[0] for b in blobs)
+    _, recs = records.read_records(tmp_path / "rec_3.bin")
+    for i in (1, 2):
+        assert recs[i]["winner"] == -1 and recs[i]["inliers"] == 0 and len(recs[i]["matches"]) == 0
+        assert not recs[i]["F"].any()
+    assert recs[0]["winner"] >= 0 and recs[4]["winner"] >= 0 and recs[0]["F"].any()   # frames (0,1) and (4,5) are real pairs

@@ -111,3 +111,12 @@ def test_cpp_reader_and_writer_agree_with_python(tmp_path):
     cut = str(tmp_path / "cut.bin")
     open(cut, "wb").write(open(f2, "rb").read()[:-3])
     assert subprocess.run([exe, "read", cut], capture_output=True).returncode == 1
+    # so does a corrupt match count (it must not be trusted as an allocation size)
+    blob = bytearray(open(f2, "rb").read())
+    blob[40 + 56:40 + 60] = (0x7FFFFFF0).to_bytes(4, "little")       # first record's n
+    bad = str(tmp_path / "bad_n.bin")
+    open(bad, "wb").write(bytes(blob))
+    r = subprocess.run([exe, "read", bad], capture_output=True, text=True)
+    assert r.returncode == 1 and "corrupt" in r.stderr
+    with pytest.raises(ValueError):
+        records.read_records(bad)

@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
 
 
 HOST_LIB = os.path.join(HERE, "libvslam_host.so")
-HOST_SRCS = [os.path.join(HERE, "host", f) for f in ("adapters.cpp", "ingest.cpp")]
+HOST_SRCS = [os.path.join(HERE, "host", f) for f in ("adapters.cpp", "kdtree_nodes.cpp", "ingest.cpp")]
 HOST_HDRS = [os.path.join(HERE, "host", "host_internal.h")]
 INCLUDE = os.path.join(HERE, "..", "include")
 

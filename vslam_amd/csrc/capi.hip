@@ -198,8 +198,16 @@ const char *vslam_last_error(vslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "
 
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
     if (!ctx) return VSLAM_ERR_INVALID;
-    VS_REQUIRE(ctx, option == VSLAM_OPT_RANSAC_ALL_SUMS, VSLAM_ERR_INVALID);
-    ctx->ransac_all_sums = value != 0;
+    if (option == VSLAM_OPT_RANSAC_ALL_SUMS) {
+        ctx->ransac_all_sums = value != 0;
+        return VSLAM_OK;
+    }
+    if (option == VSLAM_OPT_RANSAC_MIN_MATCHES) {
+        VS_REQUIRE(ctx, value >= 1 && value <= VSLAM_SET_SIZE, VSLAM_ERR_INVALID);
+        ctx->ransac_min_matches = value;
+        return VSLAM_OK;
+    }
+    VS_REQUIRE(ctx, false && "unknown option", VSLAM_ERR_INVALID);
     return VSLAM_OK;
 }
 

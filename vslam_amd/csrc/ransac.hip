@@ -613,12 +613,12 @@ constexpr int kScoreTile = 1024;   // correspondences per LDS tile (16 B floats 
 // (converted once per match, not once per hypothesis).  grid = (ceil(hyp/256), batch).
 __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
-    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
     const float *__restrict__ hypF, int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const int h = blockIdx.x * kScoreThreads + tid;
     const int m = m_arr[b];
-    if (m < VSLAM_SET_SIZE) return;
+    if (m < min_m) return;
 
     __shared__ __align__(16) float corr[kScoreTile * 4];
     __shared__ double2 corrd[kScoreTile];
@@ -840,7 +840,7 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &
 // grid = (ceil(hyp / 64), batch), block = 64 * ceil(kp_stride / 1024) threads
 __global__ __launch_bounds__(1024) void ransac_count_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
-    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
     int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler may know it
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     const int hbase = blockIdx.x * kCntHyps;
     const int nh = min(kCntHyps, hyp - hbase);
     const int m = min(m_arr[b], kp_stride);
-    if (m < VSLAM_SET_SIZE) return;   // uniform per workgroup
+    if (m < min_m) return;   // uniform per workgroup
 
     __shared__ __align__(16) float s_rec[kCntHyps * kCntRec];
     __shared__ int s_cnt[kCntHyps];
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
 // ransac_tiesum_kernel.  Hypotheses with an uncertified cheap sum carry err = inf and always stay.
 // tie_n[2b] = list length, tie_n[2b+1] = C*.  One workgroup per pair.
 constexpr int kTieThreads = 256;
-__global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t *__restrict__ m_arr, int hyp,
+__global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t *__restrict__ m_arr, int min_m, int hyp,
                                                                   const int32_t *__restrict__ hyp_count,
                                                                   const float *__restrict__ approx, float *__restrict__ hyp_sum,
                                                                   int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n) {
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
     __shared__ int s_w[kTieThreads / 64];
     __shared__ float s_f[kTieThreads / 64];
     __shared__ int s_base;
-    if (m_arr[b] < VSLAM_SET_SIZE) {
+    if (m_arr[b] < min_m) {
         if (tid == 0) {
             tie_n[2 * b] = 0;
             tie_n[2 * b + 1] = 0;
@@ -1091,11 +1091,11 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
 constexpr int kTieLaneMode = 192;
 __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
-    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, const float *__restrict__ hypF,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, const float *__restrict__ hypF,
     const int32_t *__restrict__ tie_idx, const int32_t *__restrict__ tie_n, float *__restrict__ hyp_sum) {
     const int b = blockIdx.y, lane = threadIdx.x;
     const int m = min(m_arr[b], kp_stride);
-    if (m < VSLAM_SET_SIZE) return;
+    if (m < min_m) return;
     const int T = tie_n[2 * b];
     const int32_t *TI = tie_idx + (size_t)b * hyp;
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
@@ -1191,7 +1191,7 @@ __device__ __forceinline__ uint32_t float_order(float f) {
 //                                     (for C* == 0 only if that sum > 0.0f, else nothing accepted)
 __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
-    const int32_t *__restrict__ m_arr, int kp_stride, int hyp, float threshold,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
     const float *__restrict__ hypF, const int32_t *__restrict__ hyp_count,
     const float *__restrict__ hyp_sum, float *__restrict__ F_out, uint8_t *__restrict__ mask,
     int32_t *__restrict__ best, int32_t *__restrict__ matches) {
@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
 
     int winner = -1, win_count = 0;
     float win_sum = 0.f;
-    if (m >= VSLAM_SET_SIZE) {
+    if (m >= min_m) {
         const int32_t *C = hyp_count + (size_t)b * hyp;
         const float *Sm = hyp_sum + (size_t)b * hyp;
         unsigned long long k = 0;
@@ -1332,10 +1332,11 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
     VS_REQUIRE(ctx, xy1 && xy2 && pairs && m && hypF && F && mask && best && matches, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, hyp_count && hyp_sum, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && hyp > 0, VSLAM_ERR_INVALID);
+    const int min_m = ctx->ransac_min_matches;   // items with fewer matches get no model (8 unless the caller brought its own F)
     if (ctx->ransac_all_sums) {
         VsProfScope ps(ctx, "ransac_score_kernel");
         dim3 grid(vs_div_up(hyp, kScoreThreads), batch);
-        ransac_score_kernel<<<grid, kScoreThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp,
+        ransac_score_kernel<<<grid, kScoreThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp,
                                                                      threshold, hypF, hyp_count, hyp_sum);
     } else {
         VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
@@ -1355,23 +1356,23 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
                 ctx->attr_done["ransac_count"] = true;
             }
             dim3 grid(vs_div_up(hyp, kCntHyps), batch);
-            ransac_count_kernel<<<grid, 64 * waves, queue_bytes, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp, threshold, hypF,
+            ransac_count_kernel<<<grid, 64 * waves, queue_bytes, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, threshold, hypF,
                                                                      hyp_count, hyp_sum, approx);
         }
         {
             VsProfScope ps(ctx, "ransac_ties_kernel");
-            ransac_ties_kernel<<<batch, kTieThreads, 0, ctx->stream>>>(m, hyp, hyp_count, approx, hyp_sum, tie_idx, tie_n);
+            ransac_ties_kernel<<<batch, kTieThreads, 0, ctx->stream>>>(m, min_m, hyp, hyp_count, approx, hyp_sum, tie_idx, tie_n);
         }
         {
             VsProfScope ps(ctx, "ransac_tiesum_kernel");
             dim3 grid(vs_div_up(hyp, 64), batch);
-            ransac_tiesum_kernel<<<grid, 64, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp, hypF, tie_idx, tie_n,
+            ransac_tiesum_kernel<<<grid, 64, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, hypF, tie_idx, tie_n,
                                                               hyp_sum);
         }
     }
     {
         VsProfScope ps(ctx, "ransac_select_kernel");
-        ransac_select_kernel<<<batch, kSelThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, hyp,
+        ransac_select_kernel<<<batch, kSelThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp,
                                                                      threshold, hypF, hyp_count, hyp_sum,
                                                                      F, mask, best, matches);
     }

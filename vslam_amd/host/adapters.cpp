@@ -3,15 +3,27 @@
 // computes runs on the device; this file only marshals std::vector / cv::Mat data across the
 // boundary and rebuilds the pointer-linked node arrays the consumers expect.  No CPU fallback:
 // if no device is available the first call throws.
+//
+// Latency shape of one call: the reference's consumers call these one frame / one query at a time, so
+// what a call costs here is round trips, not arithmetic.  Every entry point therefore
+//   * takes its device and page-locked staging memory from a grow-only scratch owned by the process-wide
+//     context (no hipMalloc / hipFree per call),
+//   * packs all of its inputs into ONE host->device copy and all of its outputs into ONE device->host copy,
+//   * chains its kernels on the device (match -> sets -> RANSAC without the matches visiting the host).
+// Entry points are serialised by one lock: one context, one stream, one scratch (the reference's hot path is
+// single-threaded, src/vslam.cpp:53-294).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/vslam/Frame.h"
 #include "../../include/vslam_amd.h"
@@ -19,8 +31,17 @@
 
 namespace {
 
+struct Block {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+void drop_cached_trees();   // defined with the tree cache below
+
 struct Device {
     vslam_ctx *ctx = nullptr;
+    std::map<std::string, Block> dev, pinned;   // grow-only scratch, released with the context
+    std::vector<Block> tree_blocks;             // device blocks of dropped trees, reused by the next ones
     Device() {
         const char *d = std::getenv("VSLAM_DEVICE");
         vslam::settings().device = d ? std::atoi(d) : vslam::settings().device;
@@ -30,14 +51,26 @@ struct Device {
                                      "); the front-end has no CPU fallback");
     }
     ~Device() {
-        if (ctx) vslam_ctx_destroy(ctx);
+        if (!ctx) return;
+        drop_cached_trees();
+        for (auto &b : tree_blocks)
+            if (b.p) vslam_dev_free(ctx, b.p);
+        for (auto &kv : dev)
+            if (kv.second.p) vslam_dev_free(ctx, kv.second.p);
+        for (auto &kv : pinned)
+            if (kv.second.p) vslam_host_free(ctx, kv.second.p);
+        vslam_ctx_destroy(ctx);
     }
 };
 
-vslam_ctx *ctx() {
+Device &device() {
     static Device dev;
-    return dev.ctx;
+    return dev;
 }
+vslam_ctx *ctx() { return device().ctx; }
+
+std::recursive_mutex g_mu;
+using Lock = std::lock_guard<std::recursive_mutex>;
 
 void check(int rc, const char *what) {
     if (rc != VSLAM_OK)
@@ -45,71 +78,181 @@ void check(int rc, const char *what) {
                                  vslam_last_error(ctx()));
 }
 
-// RAII device buffer
-template <typename T>
-struct DBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    DBuf() {}
-    explicit DBuf(size_t count) { alloc(count); }
-    DBuf(const DBuf &) = delete;
-    DBuf &operator=(const DBuf &) = delete;
-    void alloc(size_t count) {
-        release();
-        n = count;
-        check(vslam_dev_alloc(ctx(), sizeof(T) * (count ? count : 1), reinterpret_cast<void **>(&p)), "dev_alloc");
+// grow-only named scratch: device memory and page-locked host staging
+void *dev_scratch(const char *name, size_t bytes) {
+    Block &b = device().dev[name];
+    if (b.bytes < bytes) {
+        if (b.p) check(vslam_dev_free(ctx(), b.p), "dev_free");
+        b.p = nullptr;
+        const size_t want = bytes + bytes / 4 + 256;
+        check(vslam_dev_alloc(ctx(), want, &b.p), "dev_alloc");
+        b.bytes = want;
     }
-    void release() {
-        if (p) vslam_dev_free(ctx(), p);
-        p = nullptr;
+    return b.p;
+}
+void *pinned_scratch(const char *name, size_t bytes) {
+    Block &b = device().pinned[name];
+    if (b.bytes < bytes) {
+        if (b.p) check(vslam_host_free(ctx(), b.p), "host_free");
+        b.p = nullptr;
+        const size_t want = bytes + bytes / 4 + 256;
+        check(vslam_host_alloc(ctx(), want, &b.p), "host_alloc");
+        b.bytes = want;
     }
-    ~DBuf() { release(); }
-    void upload(const T *h, size_t count) { check(vslam_copy_h2d(ctx(), p, h, sizeof(T) * count), "copy_h2d"); }
-    void download(T *h, size_t count) const { check(vslam_copy_d2h(ctx(), h, p, sizeof(T) * count), "copy_d2h"); }
+    return b.p;
+}
+
+// offsets of the pieces of one packed transfer (256-byte aligned: every piece can be read with 16-byte loads)
+struct Layout {
+    size_t total = 0;
+    size_t add(size_t bytes) {
+        const size_t off = (total + 255) & ~(size_t)255;
+        total = off + bytes;
+        return off;
+    }
 };
 
-// device copies of trees built through this adapter, keyed by the host root pointer
+// One call's memory: `in` travels host -> device in one copy, `out` device -> host in one copy, `work` stays there.
+struct Call {
+    uint8_t *h_in = nullptr, *d_in = nullptr, *h_out = nullptr, *d_out = nullptr, *d_work = nullptr;
+    Call(const Layout &in, const Layout &out, const Layout &work) {
+        h_in = static_cast<uint8_t *>(pinned_scratch("call.in", in.total + 1));
+        d_in = static_cast<uint8_t *>(dev_scratch("call.in", in.total + 1));
+        h_out = static_cast<uint8_t *>(pinned_scratch("call.out", out.total + 1));
+        d_out = static_cast<uint8_t *>(dev_scratch("call.out", out.total + 1));
+        d_work = static_cast<uint8_t *>(dev_scratch("call.work", work.total + 1));
+        n_in = in.total;
+        n_out = out.total;
+    }
+    void upload() {
+        if (n_in) check(vslam_copy_h2d(ctx(), d_in, h_in, n_in), "copy_h2d");
+    }
+    void download() {
+        if (n_out) check(vslam_copy_d2h(ctx(), h_out, d_out, n_out), "copy_d2h");
+    }
+    template <class T>
+    T *hin(size_t off) { return reinterpret_cast<T *>(h_in + off); }
+    template <class T>
+    T *din(size_t off) { return reinterpret_cast<T *>(d_in + off); }
+    template <class T>
+    T *hout(size_t off) { return reinterpret_cast<T *>(h_out + off); }
+    template <class T>
+    T *dout(size_t off) { return reinterpret_cast<T *>(d_out + off); }
+    template <class T>
+    T *work(size_t off) { return reinterpret_cast<T *>(d_work + off); }
+
+   private:
+    size_t n_in = 0, n_out = 0;
+};
+
+// ---------------------------------------------------------------------------------------- device copies of trees
+// A tree handed to radius_search / nearest lives in host memory the caller owns; its device copy is cached under the
+// root pointer and VALIDATED on every use by a hash of what the kernels would read (the pre-order pt_index column and
+// the points): a tree freed and rebuilt at the same address, or points edited in place, re-uploads instead of
+// answering for the old tree.
 struct DevTree {
-    DBuf<int32_t> nodes;
-    DBuf<float> xy;
-    DBuf<int32_t> n;
+    void *block = nullptr;   // [n : int32][nodes : int32 x stride][xy : float x 2 stride]
+    size_t block_bytes = 0;
+    int32_t *n = nullptr, *nodes = nullptr;
+    float *xy = nullptr;
     int count = 0, stride = 0;
+    uint64_t hash = 0, stamp = 0;
+    ~DevTree() {   // the block goes back to the pool, not to hipFree
+        if (block) device().tree_blocks.push_back(Block{block, block_bytes});
+    }
 };
-std::mutex g_mu;
 std::map<const void *, std::shared_ptr<DevTree>> g_trees;
+void drop_cached_trees() { g_trees.clear(); }
+uint64_t g_stamp = 0;
+constexpr size_t kTreeCache = 64;
 
-std::shared_ptr<DevTree> upload_tree(const std::vector<int32_t> &pre_idx, const float *xy, int n) {
+inline uint64_t mix(uint64_t h, uint64_t v) {
+    h ^= v;
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+uint64_t hash_points(uint64_t h, const cv::Point2f *p, size_t n) {
+    static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f is two floats");
+    for (size_t i = 0; i < n; i++) {
+        uint64_t v;
+        std::memcpy(&v, &p[i], 8);
+        h = mix(h, v);
+    }
+    return h;
+}
+uint64_t hash_tree(const frame_kdtree &kd, const std::vector<cv::Point2f> &points) {
+    uint64_t h = mix(0x5EED, points.size());
+    for (size_t i = 0; i < points.size(); i++) h = mix(h, (uint64_t)kd.root[i].pt_index);
+    return hash_points(h, points.data(), points.size());
+}
+
+std::shared_ptr<DevTree> alloc_tree(int n) {
     auto t = std::make_shared<DevTree>();
     t->count = n;
     t->stride = n > 0 ? n : 1;
-    t->nodes.alloc(t->stride);
-    t->xy.alloc(2 * (size_t)t->stride);
-    t->n.alloc(1);
-    if (n > 0) {
-        t->nodes.upload(pre_idx.data(), n);
-        t->xy.upload(xy, 2 * (size_t)n);
+    Layout L;
+    const size_t o_n = L.add(4), o_nodes = L.add(4 * (size_t)t->stride), o_xy = L.add(8 * (size_t)t->stride);
+    auto &pool = device().tree_blocks;
+    for (size_t i = 0; i < pool.size() && !t->block; i++)
+        if (pool[i].bytes >= L.total) {
+            t->block = pool[i].p;
+            t->block_bytes = pool[i].bytes;
+            pool.erase(pool.begin() + (long)i);
+        }
+    if (!t->block) {
+        t->block_bytes = L.total + L.total / 4;   // head room: frames have similar keypoint counts
+        check(vslam_dev_alloc(ctx(), t->block_bytes, &t->block), "dev_alloc");
     }
-    const int32_t nn = n;
-    t->n.upload(&nn, 1);
+    uint8_t *base = static_cast<uint8_t *>(t->block);
+    t->n = reinterpret_cast<int32_t *>(base + o_n);
+    t->nodes = reinterpret_cast<int32_t *>(base + o_nodes);
+    t->xy = reinterpret_cast<float *>(base + o_xy);
     return t;
 }
 
-// build on the device, return the pre-order pt_index column
+void remember_tree(const void *root, const std::shared_ptr<DevTree> &t) {
+    t->stamp = ++g_stamp;
+    if (g_trees.size() >= kTreeCache && g_trees.find(root) == g_trees.end()) {   // drop the least recently used
+        auto old = g_trees.begin();
+        for (auto it = g_trees.begin(); it != g_trees.end(); ++it)
+            if (it->second->stamp < old->second->stamp) old = it;
+        g_trees.erase(old);
+    }
+    g_trees[root] = t;
+}
+
+// upload (count, pre-order index column, points) in one copy
+std::shared_ptr<DevTree> upload_tree(const int32_t *pre_idx, const cv::Point2f *pts, int n) {
+    auto t = alloc_tree(n);
+    const size_t bytes = (size_t)(reinterpret_cast<uint8_t *>(t->xy) - static_cast<uint8_t *>(t->block)) + 8 * (size_t)t->stride;
+    uint8_t *h = static_cast<uint8_t *>(pinned_scratch("tree.stage", bytes));
+    std::memset(h, 0, 4);
+    const int32_t nn = n;
+    std::memcpy(h, &nn, 4);
+    if (n > 0) {
+        std::memcpy(h + (reinterpret_cast<uint8_t *>(t->nodes) - static_cast<uint8_t *>(t->block)), pre_idx, 4 * (size_t)n);
+        std::memcpy(h + (reinterpret_cast<uint8_t *>(t->xy) - static_cast<uint8_t *>(t->block)), pts, 8 * (size_t)n);
+    }
+    check(vslam_copy_h2d(ctx(), t->block, h, bytes), "copy_h2d");
+    return t;
+}
+
+// build on the device; returns the pre-order pt_index column, keeps the device copy
 std::vector<int32_t> device_build(const std::vector<cv::Point2f> &points, std::shared_ptr<DevTree> *keep) {
     const int n = (int)points.size();
     std::vector<int32_t> pre(n);
-    auto t = std::make_shared<DevTree>();
-    t->count = n;
-    t->stride = n > 0 ? n : 1;
-    t->nodes.alloc(t->stride);
-    t->xy.alloc(2 * (size_t)t->stride);
-    t->n.alloc(1);
+    auto t = alloc_tree(n);
+    // count + points up in one copy (the node column in between is written by the kernel)
+    const size_t xy_off = (size_t)(reinterpret_cast<uint8_t *>(t->xy) - static_cast<uint8_t *>(t->block));
+    const size_t bytes = xy_off + 8 * (size_t)t->stride;
+    uint8_t *h = static_cast<uint8_t *>(pinned_scratch("tree.stage", bytes));
     const int32_t nn = n;
-    t->n.upload(&nn, 1);
+    std::memcpy(h, &nn, 4);
+    if (n > 0) std::memcpy(h + xy_off, points.data(), 8 * (size_t)n);
+    check(vslam_copy_h2d(ctx(), t->block, h, bytes), "copy_h2d");
     if (n > 0) {
-        t->xy.upload(reinterpret_cast<const float *>(points.data()), 2 * (size_t)n);
-        check(vslam_kdtree_build(ctx(), t->xy.p, t->n.p, 1, t->stride, t->nodes.p), "kdtree_build");
-        t->nodes.download(pre.data(), n);
+        check(vslam_kdtree_build(ctx(), t->xy, t->n, 1, t->stride, t->nodes), "kdtree_build");
+        check(vslam_copy_d2h(ctx(), pre.data(), t->nodes, 4 * (size_t)n), "copy_d2h");
     }
     if (keep) *keep = t;
     return pre;
@@ -128,19 +271,40 @@ Node *link_preorder(Node *base, int pos, int len) {
 u8 tree_height(int n) { return (u8)(std::floor(std::log2((double)n)) + 1); }   // src/KDTree.cpp:33,119
 
 std::shared_ptr<DevTree> device_tree_for(const frame_kdtree &kd, const std::vector<cv::Point2f> &points) {
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_trees.find(kd.root);
-        if (it != g_trees.end() && it->second->count == (int)points.size()) return it->second;
+    const uint64_t h = hash_tree(kd, points);
+    auto it = g_trees.find(kd.root);
+    if (it != g_trees.end() && it->second->count == (int)points.size() && it->second->hash == h) {
+        it->second->stamp = ++g_stamp;
+        return it->second;
     }
-    // tree built elsewhere (or forgotten): its array is already in pre-order, re-upload it
+    // built elsewhere, forgotten, or changed since it was uploaded: its array is in pre-order, upload it
     const int n = (int)points.size();
     std::vector<int32_t> pre(n);
     for (int i = 0; i < n; i++) pre[i] = (int32_t)kd.root[i].pt_index;
-    auto t = upload_tree(pre, reinterpret_cast<const float *>(points.data()), n);
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_trees.size() > 64) g_trees.clear();
-    g_trees[kd.root] = t;
+    auto t = upload_tree(pre.data(), points.data(), n);
+    t->hash = h;
+    remember_tree(kd.root, t);
+    return t;
+}
+
+int node_count(const KDTree::KDTreeNode *nd) { return nd ? 1 + node_count(nd->left) + node_count(nd->right) : 0; }
+
+// a KDTree carries its points inside the nodes (array order == pre-order): identity index column over them
+std::shared_ptr<DevTree> device_tree_for(const KDTree &kd, std::vector<cv::Point2f> &pts) {
+    const int n = node_count(kd.root);
+    pts.resize(n);
+    for (int i = 0; i < n; i++) pts[i] = kd.root[i].pt;
+    const uint64_t h = hash_points(mix(0x7EE, (uint64_t)n), pts.data(), (size_t)n);
+    auto it = g_trees.find(kd.root);
+    if (it != g_trees.end() && it->second->count == n && it->second->hash == h) {
+        it->second->stamp = ++g_stamp;
+        return it->second;
+    }
+    std::vector<int32_t> pre(n);
+    for (int i = 0; i < n; i++) pre[i] = i;
+    auto t = upload_tree(pre.data(), pts.data(), n);
+    t->hash = h;
+    remember_tree(kd.root, t);
     return t;
 }
 
@@ -165,6 +329,29 @@ const std::vector<s8> &pattern() {
     return st.brief_pattern;
 }
 
+// the pattern on the device, uploaded when it changes
+const int8_t *device_pattern() {
+    static std::vector<s8> uploaded;
+    const std::vector<s8> &pat = pattern();
+    int8_t *d = static_cast<int8_t *>(dev_scratch("pattern", 1024));
+    if (uploaded != pat) {
+        check(vslam_copy_h2d(ctx(), d, pat.data(), 1024), "pattern upload");
+        uploaded = pat;
+    }
+    return d;
+}
+
+void fill_params(vslam_extract_params &p, int max_corners, const int8_t *d_pattern) {
+    auto &st = vslam::settings();
+    p.max_corners = max_corners;
+    p.quality = st.quality;
+    p.min_distance = st.min_distance;
+    const float a = st.keypoint_angle_deg * (float)(3.14159265358979323846 / 180.f);   // angle *= CV_PI/180
+    p.cos_a = (float)std::cos((double)a);
+    p.sin_a = (float)std::sin((double)a);
+    p.d_pattern = d_pattern;
+}
+
 }  // namespace
 
 namespace vslam {
@@ -177,20 +364,22 @@ namespace detail {
 vslam_ctx *context() { return ctx(); }
 void check(int rc, const char *what) { ::check(rc, what); }
 const std::vector<s8> &brief_pattern() { return pattern(); }
-void fill_extract_params(vslam_extract_params &p, int max_corners, const int8_t *d_pattern) {
-    auto &st = vslam::settings();
-    p.max_corners = max_corners;
-    p.quality = st.quality;
-    p.min_distance = st.min_distance;
-    const float a = st.keypoint_angle_deg * (float)(3.14159265358979323846 / 180.f);   // angle *= CV_PI/180
-    p.cos_a = (float)std::cos((double)a);
-    p.sin_a = (float)std::sin((double)a);
-    p.d_pattern = d_pattern;
-}
+void fill_extract_params(vslam_extract_params &p, int max_corners, const int8_t *d_pattern) { fill_params(p, max_corners, d_pattern); }
+
+// RansacFilter's device-side paths (friend of the class: they read its seed and refresh its private ransac_sets)
+struct RansacAccess {
+    // sets drawn on the device for `m` matches (src/RansacFilter.cpp:6-34) straight into d_sets; host copy refreshed by the caller
+    static u32 seed(RansacFilter &rf) { return rf.next_seed(); }
+    static void store_sets(RansacFilter &rf, const int32_t *flat) {
+        rf.ransac_sets.assign(rf.max_iterations, std::vector<int>(8, 0));
+        for (int i = 0; i < rf.max_iterations; i++)
+            for (int j = 0; j < 8; j++) rf.ransac_sets[i][j] = flat[(size_t)i * 8 + j];
+    }
+};
 }  // namespace detail
 
 void forget_kdtree(const void *root) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Lock lk(g_mu);
     g_trees.erase(root);
 }
 
@@ -199,28 +388,30 @@ std::vector<std::vector<usize>> radius_search_batch(const frame_kdtree &kdtree,
                                                     const std::vector<cv::Point2f> &queries, float radius) {
     std::vector<std::vector<usize>> out(queries.size());
     if (queries.empty() || points.empty() || kdtree.root == nullptr) return out;
+    Lock lk(g_mu);
     auto t = device_tree_for(kdtree, points);
     const int q = (int)queries.size();
     int cap = 16;
     while (true) {
-        DBuf<float> dq(2 * (size_t)q);
-        DBuf<int32_t> dnq(1), dhits((size_t)q * cap), dcnt(q);
-        dq.upload(reinterpret_cast<const float *>(queries.data()), 2 * (size_t)q);
-        const int32_t nq = q;
-        dnq.upload(&nq, 1);
-        check(vslam_kdtree_radius(ctx(), t->nodes.p, t->xy.p, t->n.p, 1, t->stride, dq.p, dnq.p, q, radius, dhits.p,
-                                  dcnt.p, cap),
+        Layout in, res, work;
+        const size_t o_nq = in.add(4), o_q = in.add(8 * (size_t)q);
+        const size_t o_cnt = res.add(4 * (size_t)q), o_hits = res.add(4 * (size_t)q * cap);
+        Call c(in, res, work);
+        *c.hin<int32_t>(o_nq) = q;
+        std::memcpy(c.hin<float>(o_q), queries.data(), 8 * (size_t)q);
+        c.upload();
+        check(vslam_kdtree_radius(ctx(), t->nodes, t->xy, t->n, 1, t->stride, c.din<float>(o_q), c.din<int32_t>(o_nq), q, radius,
+                                  c.dout<int32_t>(o_hits), c.dout<int32_t>(o_cnt), cap),
               "kdtree_radius");
-        std::vector<int32_t> hits((size_t)q * cap), cnt(q);
-        dhits.download(hits.data(), hits.size());
-        dcnt.download(cnt.data(), q);
+        c.download();
+        const int32_t *cnt = c.hout<int32_t>(o_cnt), *hits = c.hout<int32_t>(o_hits);
         int mx = 0;
-        for (int c : cnt) mx = c > mx ? c : mx;
+        for (int i = 0; i < q; i++) mx = cnt[i] > mx ? cnt[i] : mx;
         if (mx > cap) {   // rare: more hits than slots, retry with room for all
             cap = mx;
             continue;
         }
-        for (int i = 0; i < q; i++) out[i].assign(hits.begin() + (size_t)i * cap, hits.begin() + (size_t)i * cap + cnt[i]);
+        for (int i = 0; i < q; i++) out[i].assign(hits + (size_t)i * cap, hits + (size_t)i * cap + cnt[i]);
         return out;
     }
 }
@@ -233,6 +424,7 @@ void construct_kdtree(frame_kdtree &kdtree, const std::vector<cv::Point2f> &poin
         kdtree.root = nullptr;   // src/KDTree.cpp:109-110
         return;
     }
+    Lock lk(g_mu);
     std::shared_ptr<DevTree> dev;
     const std::vector<int32_t> pre = device_build(points, &dev);
     auto *nodes = static_cast<frame_kdtree::KDTreeNode *>(std::malloc(N * sizeof(frame_kdtree::KDTreeNode)));
@@ -241,9 +433,8 @@ void construct_kdtree(frame_kdtree &kdtree, const std::vector<cv::Point2f> &poin
     kdtree.root = nodes;
     kdtree.size += (u32)N;   // the reference never resets size
     kdtree.height = tree_height((int)N);
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_trees.size() > 64) g_trees.clear();
-    g_trees[nodes] = dev;
+    dev->hash = hash_tree(kdtree, points);
+    remember_tree(nodes, dev);
 }
 
 void construct_kdtree(KDTree &kdtree, const std::vector<cv::Point2f> &points) {
@@ -252,6 +443,7 @@ void construct_kdtree(KDTree &kdtree, const std::vector<cv::Point2f> &points) {
         kdtree.root = nullptr;
         return;
     }
+    Lock lk(g_mu);
     // the point-storing twin makes the same comparisons on the same keys, so it is the index tree
     // with the points substituted (src/KDTree.cpp:3-35)
     const std::vector<int32_t> pre = device_build(points, nullptr);
@@ -268,59 +460,48 @@ std::vector<usize> radius_search(const frame_kdtree kdtree, const std::vector<cv
     return vslam::radius_search_batch(kdtree, points, std::vector<cv::Point2f>{query_pt}, radius)[0];
 }
 
-namespace {
-// a KDTree carries its points inside the nodes: flatten them (array order == pre-order)
-void flatten(const KDTree &kd, int n, std::vector<cv::Point2f> &pts, std::vector<int32_t> &pre) {
-    pts.resize(n);
-    pre.resize(n);
-    for (int i = 0; i < n; i++) {
-        pts[i] = kd.root[i].pt;
-        pre[i] = i;
-    }
-}
-int node_count(const KDTree::KDTreeNode *nd) { return nd ? 1 + node_count(nd->left) + node_count(nd->right) : 0; }
-}  // namespace
-
 std::vector<cv::Point2f> radius_search(const KDTree &kdtree, const cv::Point2f &query_pt, float radius) {
     std::vector<cv::Point2f> out;
     if (!kdtree.root) return out;
-    const int n = node_count(kdtree.root);
+    Lock lk(g_mu);
     std::vector<cv::Point2f> pts;
-    std::vector<int32_t> pre;
-    flatten(kdtree, n, pts, pre);
-    auto t = upload_tree(pre, reinterpret_cast<const float *>(pts.data()), n);
-    DBuf<float> dq(2);
-    DBuf<int32_t> dnq(1), dcnt(1), dhits(n);
-    dq.upload(&query_pt.x, 2);
-    const int32_t one = 1;
-    dnq.upload(&one, 1);
-    check(vslam_kdtree_radius(ctx(), t->nodes.p, t->xy.p, t->n.p, 1, t->stride, dq.p, dnq.p, 1, radius, dhits.p, dcnt.p, n),
+    auto t = device_tree_for(kdtree, pts);
+    const int n = t->count;
+    Layout in, res, work;
+    const size_t o_nq = in.add(4), o_q = in.add(8);
+    const size_t o_cnt = res.add(4), o_hits = res.add(4 * (size_t)n);
+    Call c(in, res, work);
+    *c.hin<int32_t>(o_nq) = 1;
+    std::memcpy(c.hin<float>(o_q), &query_pt, 8);
+    c.upload();
+    check(vslam_kdtree_radius(ctx(), t->nodes, t->xy, t->n, 1, t->stride, c.din<float>(o_q), c.din<int32_t>(o_nq), 1, radius,
+                              c.dout<int32_t>(o_hits), c.dout<int32_t>(o_cnt), n),
           "kdtree_radius");
-    int32_t cnt = 0;
-    dcnt.download(&cnt, 1);
-    std::vector<int32_t> hits(cnt);
-    if (cnt) dhits.download(hits.data(), cnt);
-    for (int32_t h : hits) out.push_back(pts[h]);
+    c.download();
+    const int32_t cnt = *c.hout<int32_t>(o_cnt), *hits = c.hout<int32_t>(o_hits);
+    out.reserve(cnt);
+    for (int i = 0; i < cnt; i++) out.push_back(pts[hits[i]]);
     return out;
 }
 
 cv::Point2f nearest(const KDTree &kdtree, const cv::Point2f &query_pt, float max_distance_sq) {
     cv::Point2f r;   // default {0,0} when nothing qualifies, src/KDTree.cpp:38-42
     if (!kdtree.root) return r;
-    const int n = node_count(kdtree.root);
+    Lock lk(g_mu);
     std::vector<cv::Point2f> pts;
-    std::vector<int32_t> pre;
-    flatten(kdtree, n, pts, pre);
-    auto t = upload_tree(pre, reinterpret_cast<const float *>(pts.data()), n);
-    DBuf<float> dq(2);
-    DBuf<int32_t> dnq(1), dbest(1);
-    dq.upload(&query_pt.x, 2);
-    const int32_t one = 1;
-    dnq.upload(&one, 1);
-    check(vslam_kdtree_nearest(ctx(), t->nodes.p, t->xy.p, t->n.p, 1, t->stride, dq.p, dnq.p, 1, max_distance_sq, dbest.p),
+    auto t = device_tree_for(kdtree, pts);
+    Layout in, res, work;
+    const size_t o_nq = in.add(4), o_q = in.add(8);
+    const size_t o_best = res.add(4);
+    Call c(in, res, work);
+    *c.hin<int32_t>(o_nq) = 1;
+    std::memcpy(c.hin<float>(o_q), &query_pt, 8);
+    c.upload();
+    check(vslam_kdtree_nearest(ctx(), t->nodes, t->xy, t->n, 1, t->stride, c.din<float>(o_q), c.din<int32_t>(o_nq), 1,
+                               max_distance_sq, c.dout<int32_t>(o_best)),
           "kdtree_nearest");
-    int32_t best = -1;
-    dbest.download(&best, 1);
+    c.download();
+    const int32_t best = *c.hout<int32_t>(o_best);
     if (best >= 0) r = pts[best];
     return r;
 }
@@ -335,74 +516,71 @@ u32 RansacFilter::next_seed() {
     return (u32)rd();
 }
 
-void RansacFilter::initialize_sets(const int n_matches) {
-    if (min_items != VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: the device path draws 8-subsets (min_items == 8)");
-    if (n_matches < VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: fewer than 8 matches (undefined in the reference)");
-    const u32 seed = next_seed();
-    DBuf<uint32_t> dseed(1), ddraw((size_t)max_iterations * 8);
-    DBuf<int32_t> dm(1), dsets((size_t)max_iterations * 8);
-    dseed.upload(&seed, 1);
-    const int32_t m = n_matches;
-    dm.upload(&m, 1);
-    check(vslam_ransac_sets(ctx(), dseed.p, dm.p, 1, max_iterations, dsets.p, ddraw.p), "ransac_sets");
-    std::vector<int32_t> flat((size_t)max_iterations * 8);
-    dsets.download(flat.data(), flat.size());
-    ransac_sets.assign(max_iterations, std::vector<int>(8, 0));
-    for (int i = 0; i < max_iterations; i++)
-        for (int j = 0; j < 8; j++) ransac_sets[i][j] = flat[(size_t)i * 8 + j];
-}
-
 namespace {
-struct PairUpload {
-    DBuf<float> xy1, xy2;
-    DBuf<int32_t> pairs, m;
-    int stride = 1;
-    PairUpload(const std::vector<cv::Point2f> &p1, const std::vector<cv::Point2f> &p2,
-               const std::vector<std::pair<int, int>> &matches) {
-        stride = (int)std::max(std::max(p1.size(), p2.size()), std::max(matches.size(), (size_t)1));
-        xy1.alloc(2 * (size_t)stride);
-        xy2.alloc(2 * (size_t)stride);
-        pairs.alloc(2 * (size_t)stride);
-        m.alloc(1);
-        if (!p1.empty()) xy1.upload(reinterpret_cast<const float *>(p1.data()), 2 * p1.size());
-        if (!p2.empty()) xy2.upload(reinterpret_cast<const float *>(p2.data()), 2 * p2.size());
-        std::vector<int32_t> flat(2 * matches.size());
-        for (size_t i = 0; i < matches.size(); i++) {
-            flat[2 * i] = matches[i].first;
-            flat[2 * i + 1] = matches[i].second;
-        }
-        if (!flat.empty()) pairs.upload(flat.data(), flat.size());
-        const int32_t mm = (int32_t)matches.size();
-        m.upload(&mm, 1);
-    }
-};
+void require_sets(const RansacFilter &rf, int n_matches) {
+    if (rf.min_items != VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: the device path draws 8-subsets (min_items == 8)");
+    if (n_matches < VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: fewer than 8 matches (undefined in the reference)");
+}
 }  // namespace
+
+void RansacFilter::initialize_sets(const int n_matches) {
+    require_sets(*this, n_matches);
+    Lock lk(g_mu);
+    const size_t H = (size_t)max_iterations;
+    Layout in, res, work;
+    const size_t o_seed = in.add(4), o_m = in.add(4);
+    const size_t o_sets = res.add(32 * H);
+    const size_t o_draw = work.add(32 * H);
+    Call c(in, res, work);
+    *c.hin<uint32_t>(o_seed) = next_seed();
+    *c.hin<int32_t>(o_m) = n_matches;
+    c.upload();
+    check(vslam_ransac_sets(ctx(), c.din<uint32_t>(o_seed), c.din<int32_t>(o_m), 1, max_iterations, c.dout<int32_t>(o_sets),
+                            c.work<uint32_t>(o_draw)),
+          "ransac_sets");
+    c.download();
+    vslam::detail::RansacAccess::store_sets(*this, c.hout<int32_t>(o_sets));
+}
 
 void RansacFilter::find_fundamental(const std::vector<cv::Point2f> &p1, const std::vector<cv::Point2f> &p2,
                                     const std::vector<std::pair<int, int>> &matches, std::vector<bool> &inliers,
                                     cv::Mat &fundamental) {
-    initialize_sets((int)matches.size());   // src/RansacFilter.cpp:38
     const int H = max_iterations, M = (int)matches.size();
-    PairUpload up(p1, p2, matches);
-    std::vector<int32_t> flat((size_t)H * 8);
-    for (int i = 0; i < H; i++)
-        for (int j = 0; j < 8; j++) flat[(size_t)i * 8 + j] = ransac_sets[i][j];
-    DBuf<int32_t> dsets(flat.size()), dbest(4), dmatches(2 * (size_t)up.stride), dcount(H);
-    DBuf<float> dF(9), dhypF((size_t)H * 9), dsum(H);
-    DBuf<uint8_t> dmask(up.stride);
-    dsets.upload(flat.data(), flat.size());
-    check(vslam_ransac_fundamental(ctx(), up.xy1.p, up.xy2.p, up.pairs.p, up.m.p, dsets.p, 1, up.stride, H, threshold, dF.p,
-                                   dmask.p, dbest.p, dmatches.p, dhypF.p, dcount.p, dsum.p),
+    require_sets(*this, M);   // initialize_sets(matches.size()), src/RansacFilter.cpp:38
+    Lock lk(g_mu);
+    const int stride = (int)std::max(std::max(p1.size(), p2.size()), (size_t)M);
+    Layout in, res, work;
+    const size_t o_seed = in.add(4), o_m = in.add(4), o_xy1 = in.add(8 * (size_t)stride), o_xy2 = in.add(8 * (size_t)stride),
+                 o_pairs = in.add(8 * (size_t)stride);
+    const size_t o_best = res.add(16), o_F = res.add(36), o_mask = res.add((size_t)stride), o_sets = res.add(32 * (size_t)H);
+    const size_t o_draw = work.add(32 * (size_t)H), o_hypF = work.add(36 * (size_t)H), o_cnt = work.add(4 * (size_t)H),
+                 o_sum = work.add(4 * (size_t)H), o_match = work.add(8 * (size_t)stride);
+    Call c(in, res, work);
+    *c.hin<uint32_t>(o_seed) = next_seed();
+    *c.hin<int32_t>(o_m) = M;
+    if (!p1.empty()) std::memcpy(c.hin<float>(o_xy1), p1.data(), 8 * p1.size());
+    if (!p2.empty()) std::memcpy(c.hin<float>(o_xy2), p2.data(), 8 * p2.size());
+    int32_t *flat = c.hin<int32_t>(o_pairs);
+    for (int i = 0; i < M; i++) {
+        flat[2 * i] = matches[i].first;
+        flat[2 * i + 1] = matches[i].second;
+    }
+    c.upload();
+    // sets are drawn on the device and go straight into the hypothesis loop
+    check(vslam_ransac_sets(ctx(), c.din<uint32_t>(o_seed), c.din<int32_t>(o_m), 1, H, c.dout<int32_t>(o_sets), c.work<uint32_t>(o_draw)),
+          "ransac_sets");
+    check(vslam_ransac_fundamental(ctx(), c.din<float>(o_xy1), c.din<float>(o_xy2), c.din<int32_t>(o_pairs), c.din<int32_t>(o_m),
+                                   c.dout<int32_t>(o_sets), 1, stride, H, threshold, c.dout<float>(o_F), c.dout<uint8_t>(o_mask),
+                                   c.dout<int32_t>(o_best), c.work<int32_t>(o_match), c.work<float>(o_hypF), c.work<int32_t>(o_cnt),
+                                   c.work<float>(o_sum)),
           "ransac_fundamental");
-    int32_t best[4];
-    dbest.download(best, 4);
+    c.download();
+    vslam::detail::RansacAccess::store_sets(*this, c.hout<int32_t>(o_sets));
+    const int32_t *best = c.hout<int32_t>(o_best);
     if (best[0] < 0) return;   // nothing accepted: `fundamental` and `inliers` stay as they were (:59-65)
-    float F[9];
-    dF.download(F, 9);
     fundamental.create(3, 3, CV_32FC1);
-    std::memcpy(fundamental.ptr<float>(), F, sizeof(F));
-    std::vector<uint8_t> mask(M);
-    dmask.download(mask.data(), M);
+    std::memcpy(fundamental.ptr<float>(), c.hout<float>(o_F), 36);
+    const uint8_t *mask = c.hout<uint8_t>(o_mask);
     inliers.assign(M, false);
     for (int i = 0; i < M; i++) inliers[i] = mask[i] != 0;
 }
@@ -410,16 +588,25 @@ void RansacFilter::find_fundamental(const std::vector<cv::Point2f> &p1, const st
 void RansacFilter::compute_fundamental(const std::vector<cv::Point2f> &p1_set, const std::vector<cv::Point2f> &p2_set,
                                        cv::Mat &temp_F) {
     if (p1_set.size() != 8 || p2_set.size() != 8) throw std::invalid_argument("compute_fundamental: the device solver takes 8-point sets");
-    std::vector<std::pair<int, int>> ident(8);
-    for (int i = 0; i < 8; i++) ident[i] = {i, i};
-    PairUpload up(p1_set, p2_set, ident);
-    const int32_t set[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-    DBuf<int32_t> dsets(8);
-    DBuf<float> dhypF(9);
-    dsets.upload(set, 8);
-    check(vslam_ransac_solve(ctx(), up.xy1.p, up.xy2.p, up.pairs.p, up.m.p, dsets.p, 1, up.stride, 1, dhypF.p), "ransac_solve");
+    Lock lk(g_mu);
+    Layout in, res, work;
+    const size_t o_m = in.add(4), o_xy1 = in.add(64), o_xy2 = in.add(64), o_pairs = in.add(64), o_set = in.add(32);
+    const size_t o_F = res.add(36);
+    Call c(in, res, work);
+    *c.hin<int32_t>(o_m) = 8;
+    std::memcpy(c.hin<float>(o_xy1), p1_set.data(), 64);
+    std::memcpy(c.hin<float>(o_xy2), p2_set.data(), 64);
+    for (int i = 0; i < 8; i++) {
+        c.hin<int32_t>(o_pairs)[2 * i] = c.hin<int32_t>(o_pairs)[2 * i + 1] = i;
+        c.hin<int32_t>(o_set)[i] = i;
+    }
+    c.upload();
+    check(vslam_ransac_solve(ctx(), c.din<float>(o_xy1), c.din<float>(o_xy2), c.din<int32_t>(o_pairs), c.din<int32_t>(o_m),
+                             c.din<int32_t>(o_set), 1, 8, 1, c.dout<float>(o_F)),
+          "ransac_solve");
+    c.download();
     temp_F.create(3, 3, CV_32FC1);
-    dhypF.download(temp_F.ptr<float>(), 9);
+    std::memcpy(temp_F.ptr<float>(), c.hout<float>(o_F), 36);
 }
 
 std::pair<int, float> RansacFilter::compute_fundamental_residual(const std::vector<cv::Point2f> &p1,
@@ -428,29 +615,39 @@ std::pair<int, float> RansacFilter::compute_fundamental_residual(const std::vect
                                                                  const cv::Mat &F, std::vector<bool> &inliers) {
     const int M = (int)matches.size();
     inliers.resize(M);   // :107
-    if (M < 8) throw std::invalid_argument("compute_fundamental_residual: the device path needs >= 8 matches");
-    PairUpload up(p1, p2, matches);
-    DBuf<float> dhypF(9), dF(9), dsum(1);
-    DBuf<int32_t> dbest(4), dmatches(2 * (size_t)up.stride), dcount(1);
-    DBuf<uint8_t> dmask(up.stride);
-    float f[9];
+    if (M == 0) return {0, 0.f};   // nothing to evaluate: no inliers, cv::sum of an empty row is 0 (:128-138)
+    Lock lk(g_mu);
+    const int stride = (int)std::max(std::max(p1.size(), p2.size()), (size_t)M);
+    Layout in, res, work;
+    const size_t o_m = in.add(4), o_xy1 = in.add(8 * (size_t)stride), o_xy2 = in.add(8 * (size_t)stride),
+                 o_pairs = in.add(8 * (size_t)stride), o_hypF = in.add(36);
+    const size_t o_cnt = res.add(4), o_sum = res.add(4), o_mask = res.add((size_t)stride);
+    const size_t o_best = work.add(16), o_F = work.add(36), o_match = work.add(8 * (size_t)stride);
+    Call c(in, res, work);
+    *c.hin<int32_t>(o_m) = M;
+    if (!p1.empty()) std::memcpy(c.hin<float>(o_xy1), p1.data(), 8 * p1.size());
+    if (!p2.empty()) std::memcpy(c.hin<float>(o_xy2), p2.data(), 8 * p2.size());
+    int32_t *flat = c.hin<int32_t>(o_pairs);
+    for (int i = 0; i < M; i++) {
+        flat[2 * i] = matches[i].first;
+        flat[2 * i + 1] = matches[i].second;
+    }
     for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) f[r * 3 + c] = F.at<float>(r, c);
-    dhypF.upload(f, 9);
-    // threshold -inf..: evaluate reports count and sum for the given F irrespective of acceptance
-    check(vslam_ransac_evaluate(ctx(), up.xy1.p, up.xy2.p, up.pairs.p, up.m.p, dhypF.p, 1, up.stride, 1, threshold, dF.p,
-                                dmask.p, dbest.p, dmatches.p, dcount.p, dsum.p),
-          "ransac_evaluate");
-    int32_t count = 0;
-    float sum = 0;
-    dcount.download(&count, 1);
-    dsum.download(&sum, 1);
-    // the mask of THIS hypothesis: recompute-free because with hyp == 1 the winner is hypothesis 0
-    // whenever anything is accepted; otherwise every e is NaN/over threshold and the mask is all false
-    std::vector<uint8_t> mask(M);
-    dmask.download(mask.data(), M);
+        for (int col = 0; col < 3; col++) c.hin<float>(o_hypF)[r * 3 + col] = F.at<float>(r, col);
+    c.upload();
+    // a GIVEN F is scored on any number of matches (the reference's method has no lower limit, :105-140); with one
+    // hypothesis its count is the maximum, so its sum is computed, and the winner's mask is this hypothesis' mask
+    // whenever anything is an inlier (otherwise it is all false, which is also this hypothesis' mask)
+    check(vslam_ctx_set_option(ctx(), VSLAM_OPT_RANSAC_MIN_MATCHES, 1), "set_option");
+    const int rc = vslam_ransac_evaluate(ctx(), c.din<float>(o_xy1), c.din<float>(o_xy2), c.din<int32_t>(o_pairs), c.din<int32_t>(o_m),
+                                         c.din<float>(o_hypF), 1, stride, 1, threshold, c.work<float>(o_F), c.dout<uint8_t>(o_mask),
+                                         c.work<int32_t>(o_best), c.work<int32_t>(o_match), c.dout<int32_t>(o_cnt), c.dout<float>(o_sum));
+    check(vslam_ctx_set_option(ctx(), VSLAM_OPT_RANSAC_MIN_MATCHES, VSLAM_SET_SIZE), "set_option");
+    check(rc, "ransac_evaluate");
+    c.download();
+    const uint8_t *mask = c.hout<uint8_t>(o_mask);
     for (int i = 0; i < M; i++) inliers[i] = mask[i] != 0;
-    return {count, sum};
+    return {*c.hout<int32_t>(o_cnt), *c.hout<float>(o_sum)};
 }
 
 // -------------------------------------------------------------------------------------- Frame.h
@@ -462,69 +659,67 @@ void initialize_frame(Frame &frame, const cv::Mat &image, long frame_id) {
 void extract_features(Frame &frame, int nrows, int ncols) {
     cv::Mat &img = frame.image;
     if (img.empty() || img.type() != CV_8UC3) throw std::invalid_argument("extract_features: expects a CV_8UC3 BGR image");
+    Lock lk(g_mu);
     const int w = img.cols, h = img.rows;
     const int K = 500 * nrows * ncols + 4096;   // 500 per cell plus room for response ties
-    const std::vector<s8> &pat = pattern();
-    DBuf<uint8_t> dimg((size_t)h * img.step), ddesc((size_t)K * 32);
-    DBuf<int8_t> dpat(1024);
-    DBuf<float> dxy(2 * (size_t)K);
-    DBuf<int32_t> dn(1);
-    dimg.upload(img.data, (size_t)h * img.step);
-    dpat.upload(reinterpret_cast<const int8_t *>(pat.data()), 1024);
-    check(vslam_extract_features_grid(ctx(), dimg.p, 1, w, h, (int)img.step, nrows, ncols, dpat.p, K, dxy.p, ddesc.p, nullptr,
-                                      dn.p),
+    const size_t img_bytes = (size_t)h * img.step;
+    Layout in, res, work;
+    in.add(0);
+    const size_t o_n = res.add(4), o_xy = res.add(8 * (size_t)K), o_desc = res.add(32 * (size_t)K);
+    Call c(in, res, work);
+    // the image goes up and (outlines drawn, src/Frame.cpp:32) comes back through its own buffer
+    uint8_t *dimg = static_cast<uint8_t *>(dev_scratch("frame.image", img_bytes));
+    check(vslam_copy_h2d(ctx(), dimg, img.data, img_bytes), "image upload");
+    check(vslam_extract_features_grid(ctx(), dimg, 1, w, h, (int)img.step, nrows, ncols, device_pattern(), K, c.dout<float>(o_xy),
+                                      c.dout<uint8_t>(o_desc), nullptr, c.dout<int32_t>(o_n)),
           "extract_features_grid");
-    dimg.download(img.data, (size_t)h * img.step);   // cv::rectangle drew into frame.image (src/Frame.cpp:32)
-    int32_t n = 0;
-    dn.download(&n, 1);
+    check(vslam_copy_d2h(ctx(), img.data, dimg, img_bytes), "image download");
+    c.download();
+    const int32_t n = *c.hout<int32_t>(o_n);
     frame.descriptors.create(n, 32, CV_8UC1);
-    if (n) ddesc.download(frame.descriptors.data, (size_t)n * 32);
+    if (n) std::memcpy(frame.descriptors.data, c.hout<uint8_t>(o_desc), (size_t)n * 32);
     const size_t old = frame.points.size();
     frame.points.resize(old + n);   // push_back loop, :47-49; no k-d tree, no map_point_ids (as the reference)
-    if (n) dxy.download(reinterpret_cast<float *>(frame.points.data() + old), 2 * (size_t)n);
+    if (n) std::memcpy(static_cast<void *>(frame.points.data() + old), c.hout<float>(o_xy), 8 * (size_t)n);
 }
 
 void extract_features(Frame &frame) {
     const cv::Mat &img = frame.image;
     if (img.empty() || img.type() != CV_8UC3) throw std::invalid_argument("extract_features: expects a CV_8UC3 BGR image");
+    Lock lk(g_mu);
     auto &st = vslam::settings();
     const int w = img.cols, h = img.rows, K = st.max_corners;
-    const std::vector<s8> &pat = pattern();
-    DBuf<uint8_t> dimg((size_t)h * img.step), ddesc((size_t)K * 32);
-    DBuf<int8_t> dpat(1024);
-    DBuf<float> dxy(2 * (size_t)K);
-    DBuf<int32_t> dnodes(K), dn(1), dnd(1);
-    dimg.upload(img.data, (size_t)h * img.step);
-    dpat.upload(reinterpret_cast<const int8_t *>(pat.data()), 1024);
+    const size_t img_bytes = (size_t)h * img.step;
+    Layout in, res, work;
+    in.add(0);
+    const size_t o_n = res.add(4), o_nd = res.add(4), o_xy = res.add(8 * (size_t)K), o_desc = res.add(32 * (size_t)K),
+                 o_nodes = res.add(4 * (size_t)K);
+    Call c(in, res, work);
+    uint8_t *dimg = static_cast<uint8_t *>(dev_scratch("frame.image", img_bytes));
+    check(vslam_copy_h2d(ctx(), dimg, img.data, img_bytes), "image upload");
     vslam_extract_params p;
-    p.max_corners = K;
-    p.quality = st.quality;
-    p.min_distance = st.min_distance;
-    const float a = st.keypoint_angle_deg * (float)(3.14159265358979323846 / 180.f);   // angle *= CV_PI/180
-    p.cos_a = (float)std::cos((double)a);
-    p.sin_a = (float)std::sin((double)a);
-    p.d_pattern = dpat.p;
-    check(vslam_extract_features(ctx(), dimg.p, 1, w, h, (int)img.step, &p, K, dxy.p, ddesc.p, dnodes.p, dn.p, dnd.p),
+    fill_params(p, K, device_pattern());
+    check(vslam_extract_features(ctx(), dimg, 1, w, h, (int)img.step, &p, K, c.dout<float>(o_xy), c.dout<uint8_t>(o_desc),
+                                 c.dout<int32_t>(o_nodes), c.dout<int32_t>(o_n), c.dout<int32_t>(o_nd)),
           "extract_features");
-    int32_t n = 0, nd = 0;
-    dn.download(&n, 1);
-    dnd.download(&nd, 1);
+    c.download();
+    const int32_t n = *c.hout<int32_t>(o_n), nd = *c.hout<int32_t>(o_nd);
     const size_t old = frame.points.size();
     frame.points.resize(old + n);   // push_back loop, src/Frame.cpp:69-72
-    if (n) dxy.download(reinterpret_cast<float *>(frame.points.data() + old), 2 * (size_t)n);
+    if (n) std::memcpy(static_cast<void *>(frame.points.data() + old), c.hout<float>(o_xy), 8 * (size_t)n);
     frame.descriptors.create(n, 32, CV_8UC1);
-    if (n) ddesc.download(frame.descriptors.data, (size_t)n * 32);
+    if (n) std::memcpy(frame.descriptors.data, c.hout<uint8_t>(o_desc), (size_t)n * 32);
     frame.map_point_ids.resize(nd, -1);   // sized from the PRE-filter count, :73
     // k-d tree (:76): the device already built it over the kept points
     if (old == 0 && n > 0) {
-        std::vector<int32_t> pre(n);
-        dnodes.download(pre.data(), n);
+        const int32_t *pre = c.hout<int32_t>(o_nodes);
         auto *nodes = static_cast<frame_kdtree::KDTreeNode *>(std::malloc((size_t)n * sizeof(frame_kdtree::KDTreeNode)));
         for (int i = 0; i < n; i++) nodes[i].pt_index = (usize)pre[i];
         link_preorder(nodes, 0, n);
         frame.kdtree.root = nodes;
         frame.kdtree.size += (u32)n;
         frame.kdtree.height = tree_height(n);
+        // (its device copy is made by the first radius query that needs it, src/vslam.cpp:149)
     } else {
         construct_kdtree(frame.kdtree, frame.points);
     }
@@ -535,31 +730,47 @@ void match_features(const Frame &frame1, const Frame &frame2, RansacFilter &rf,
     const int n1 = (int)frame1.points.size(), n2 = (int)frame2.points.size();
     if (frame1.descriptors.rows != n1 || frame2.descriptors.rows != n2)
         throw std::invalid_argument("match_features: descriptors and points disagree");
-    const int K = std::max(std::max(n1, n2), 1);
-    DBuf<uint8_t> dd1((size_t)K * 32), dd2((size_t)K * 32);
-    DBuf<float> dxy1(2 * (size_t)K), dxy2(2 * (size_t)K), dF(9);
-    DBuf<int32_t> dn1(1), dn2(1), dpairs(2 * (size_t)K), dm(1);
+    if (rf.min_items != VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: the device path draws 8-subsets (min_items == 8)");
+    Lock lk(g_mu);
+    const int K = std::max(std::max(n1, n2), 1), H = rf.max_iterations;
+    // knnMatch + ratio (src/Frame.cpp:83-94), then rf.find_fundamental (:97) with rf's seed, iterations and threshold,
+    // then the inlier filter (:98-102) — one upload, the kernels chained on the device, one download
+    Layout in, res, work;
+    const size_t o_n1 = in.add(4), o_n2 = in.add(4), o_seed = in.add(4), o_d1 = in.add(32 * (size_t)K), o_d2 = in.add(32 * (size_t)K),
+                 o_xy1 = in.add(8 * (size_t)K), o_xy2 = in.add(8 * (size_t)K);
+    const size_t o_m = res.add(4), o_best = res.add(16), o_F = res.add(36), o_kept = res.add(8 * (size_t)K), o_sets = res.add(32 * (size_t)H);
+    const size_t o_pairs = work.add(8 * (size_t)K), o_mask = work.add((size_t)K), o_draw = work.add(32 * (size_t)H),
+                 o_hypF = work.add(36 * (size_t)H), o_cnt = work.add(4 * (size_t)H), o_sum = work.add(4 * (size_t)H);
+    Call c(in, res, work);
+    *c.hin<int32_t>(o_n1) = n1;
+    *c.hin<int32_t>(o_n2) = n2;
+    *c.hin<uint32_t>(o_seed) = vslam::detail::RansacAccess::seed(rf);
     if (n1) {
-        dd1.upload(frame1.descriptors.data, (size_t)n1 * 32);
-        dxy1.upload(reinterpret_cast<const float *>(frame1.points.data()), 2 * (size_t)n1);
+        std::memcpy(c.hin<uint8_t>(o_d1), frame1.descriptors.data, (size_t)n1 * 32);
+        std::memcpy(c.hin<float>(o_xy1), frame1.points.data(), 8 * (size_t)n1);
     }
     if (n2) {
-        dd2.upload(frame2.descriptors.data, (size_t)n2 * 32);
-        dxy2.upload(reinterpret_cast<const float *>(frame2.points.data()), 2 * (size_t)n2);
+        std::memcpy(c.hin<uint8_t>(o_d2), frame2.descriptors.data, (size_t)n2 * 32);
+        std::memcpy(c.hin<float>(o_xy2), frame2.points.data(), 8 * (size_t)n2);
     }
-    const int32_t a = n1, b = n2;
-    dn1.upload(&a, 1);
-    dn2.upload(&b, 1);
-    // knnMatch + ratio (src/Frame.cpp:83-94), then rf.find_fundamental (:97) with rf's own sets/seed
-    check(vslam_match_knn2_ratio(ctx(), dd1.p, dn1.p, dd2.p, dn2.p, 1, K, dpairs.p, dm.p, nullptr), "match_knn2_ratio");
-    int32_t m = 0;
-    dm.download(&m, 1);
-    std::vector<int32_t> flat(2 * (size_t)m);
-    if (m) dpairs.download(flat.data(), flat.size());
-    std::vector<std::pair<int, int>> i_matches(m);
-    for (int i = 0; i < m; i++) i_matches[i] = {flat[2 * i], flat[2 * i + 1]};
-    std::vector<bool> inliers;
-    rf.find_fundamental(frame1.points, frame2.points, i_matches, inliers, F);
-    for (size_t i = 0; i < inliers.size(); i++)
-        if (inliers[i]) matches.emplace_back(i_matches[i]);   // appended, not cleared (:98-102)
+    c.upload();
+    check(vslam_match_knn2_ratio(ctx(), c.din<uint8_t>(o_d1), c.din<int32_t>(o_n1), c.din<uint8_t>(o_d2), c.din<int32_t>(o_n2), 1, K,
+                                 c.work<int32_t>(o_pairs), c.dout<int32_t>(o_m), nullptr),
+          "match_knn2_ratio");
+    check(vslam_ransac_sets(ctx(), c.din<uint32_t>(o_seed), c.dout<int32_t>(o_m), 1, H, c.dout<int32_t>(o_sets), c.work<uint32_t>(o_draw)),
+          "ransac_sets");
+    check(vslam_ransac_fundamental(ctx(), c.din<float>(o_xy1), c.din<float>(o_xy2), c.work<int32_t>(o_pairs), c.dout<int32_t>(o_m),
+                                   c.dout<int32_t>(o_sets), 1, K, H, rf.threshold, c.dout<float>(o_F), c.work<uint8_t>(o_mask),
+                                   c.dout<int32_t>(o_best), c.dout<int32_t>(o_kept), c.work<float>(o_hypF), c.work<int32_t>(o_cnt),
+                                   c.work<float>(o_sum)),
+          "ransac_fundamental");
+    c.download();
+    if (*c.hout<int32_t>(o_m) < VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: fewer than 8 matches (undefined in the reference)");
+    vslam::detail::RansacAccess::store_sets(rf, c.hout<int32_t>(o_sets));
+    const int32_t *best = c.hout<int32_t>(o_best);
+    if (best[0] < 0) return;   // nothing accepted: F untouched, no inliers (src/RansacFilter.cpp:59-65, src/Frame.cpp:98)
+    F.create(3, 3, CV_32FC1);
+    std::memcpy(F.ptr<float>(), c.hout<float>(o_F), 36);
+    const int32_t *kept = c.hout<int32_t>(o_kept);
+    for (int i = 0; i < best[3]; i++) matches.emplace_back(kept[2 * i], kept[2 * i + 1]);   // appended, not cleared (:98-102)
 }

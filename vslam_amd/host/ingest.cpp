@@ -121,6 +121,7 @@ bool RecordReader::next(PairRecord &r) {
     get(f, &r.score, 4, false);
     get(f, r.F, 36, false);
     get(f, &n, 4, false);
+    if (n > header_.max_corners) throw std::runtime_error("vslam records: corrupt record (more matches than max_corners)");
     std::vector<int32_t> flat(2 * (size_t)n);
     if (n) get(f, flat.data(), 8 * (size_t)n, false);
     r.matches.resize(n);
@@ -278,7 +279,9 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
             r.winner = h_best[4 * i + 0];
             r.inliers = h_best[4 * i + 1];
             std::memcpy(&r.score, &h_best[4 * i + 2], 4);
-            std::memcpy(r.F, &h_F[9 * (size_t)i], 36);
+            // nothing accepted (fewer than 8 matches, e.g. a blank frame, or every sum NaN): the device leaves F
+            // untouched, as find_fundamental leaves `fundamental` (src/RansacFilter.cpp:59-65); the record keeps zeros
+            if (r.winner >= 0) std::memcpy(r.F, &h_F[9 * (size_t)i], 36);
             const int n = h_best[4 * i + 3];
             r.matches.resize((size_t)n);
             for (int j = 0; j < n; j++) r.matches[(size_t)j] = {h_matches[2 * ((size_t)i * K + j)], h_matches[2 * ((size_t)i * K + j) + 1]};

@@ -42,6 +42,8 @@ def read_records(path):
         F = np.frombuffer(data, dtype="<f4", count=9, offset=off + 20).copy()
         (n,) = struct.unpack_from("<I", data, off + 56)
         off += _REC.size
+        if n > maxc:
+            raise ValueError("corrupt record: more matches than max_corners")
         if off + 8 * n > len(data):
             raise ValueError("truncated record")
         m = np.frombuffer(data, dtype="<i4", count=2 * n, offset=off).reshape(n, 2).copy()
