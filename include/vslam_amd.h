@@ -47,9 +47,11 @@ int vslam_ctx_destroy(vslam_ctx *ctx);
  * HIP's default stream.  A fresh context runs on a private non-blocking stream.               */
 int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream);
 int vslam_ctx_synchronize(vslam_ctx *ctx);
+/* Waits for the context's stream and nothing else (vslam_ctx_synchronize also fetches the device-side error word). */
+int vslam_ctx_wait(vslam_ctx *ctx);
 const char *vslam_last_error(vslam_ctx *ctx);
 const char *vslam_version(void);
-/* Context options (value 0 / 1).
+/* Context options.
  *   VSLAM_OPT_RANSAC_ALL_SUMS  0 (default): vslam_ransac_* compute the exact inlier count of every hypothesis and the
  *       residual sum only where find_fundamental can consult it — for the hypotheses whose count equals the pair's
  *       maximum (src/RansacFilter.cpp:59: the sum breaks ties at equal count, nothing else) and whose sum a

@@ -125,7 +125,8 @@ int main(int argc, char **argv) {
     // --- the device copy of a tree is validated, not trusted: (1) points edited in place, (2) a tree freed and another
     // one allocated at the same address with the same point count
     {
-        std::vector<cv::Point2f> pts(f1.points.begin(), f1.points.begin() + 200);
+        const size_t half = f1.points.size() / 2;   // two disjoint point sets of the same size
+        std::vector<cv::Point2f> pts(f1.points.begin(), f1.points.begin() + half);
         frame_kdtree t1;
         t1.root = nullptr;
         construct_kdtree(t1, pts);
@@ -144,7 +145,7 @@ int main(int argc, char **argv) {
         // (2) free, then build trees over different points until one lands on the old address
         void *old_root = t1.root;
         free(t1.root);
-        std::vector<cv::Point2f> other(f1.points.begin() + 200, f1.points.begin() + 400);
+        std::vector<cv::Point2f> other(f1.points.begin() + half, f1.points.begin() + 2 * half);
         int reused = 0;
         for (int attempt = 0; attempt < 8 && !reused; attempt++) {
             frame_kdtree t2;

@@ -16,7 +16,7 @@ ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE
 
 # every symbol include/vslam_amd.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
-    "vslam_ctx_create", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_set_option", "vslam_ctx_synchronize",
+    "vslam_ctx_create", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_set_option", "vslam_ctx_synchronize", "vslam_ctx_wait",
     "vslam_last_error", "vslam_version", "vslam_dev_alloc", "vslam_dev_free", "vslam_copy_h2d",
     "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
@@ -103,7 +103,7 @@ class Context:
     OPT_RANSAC_ALL_SUMS = 1
 
     def set_option(self, option, value):
-        self._check(self.lib.vslam_ctx_set_option(self.handle, C.c_int(option), C.c_int(1 if value else 0)))
+        self._check(self.lib.vslam_ctx_set_option(self.handle, C.c_int(option), C.c_int(int(value))))
 
     # ---------------------------------------------------------------- profiling
     def prof_enable(self, on=True):

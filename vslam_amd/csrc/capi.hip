@@ -194,6 +194,12 @@ int vslam_ctx_synchronize(vslam_ctx *ctx) {
     return VSLAM_OK;
 }
 
+int vslam_ctx_wait(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VSLAM_OK;
+}
+
 const char *vslam_last_error(vslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {

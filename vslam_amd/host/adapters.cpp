@@ -115,20 +115,26 @@ struct Layout {
 // One call's memory: `in` travels host -> device in one copy, `out` device -> host in one copy, `work` stays there.
 struct Call {
     uint8_t *h_in = nullptr, *d_in = nullptr, *h_out = nullptr, *d_out = nullptr, *d_work = nullptr;
+    // Small calls (a single k-d query: a few bytes each way) skip the copies altogether: page-locked host memory is
+    // addressable from the device, so the kernel reads its arguments from and writes its answer to the staging
+    // buffers directly and the call costs one launch and one stream wait.
+    static constexpr size_t kZeroCopyBytes = 4096;
     Call(const Layout &in, const Layout &out, const Layout &work) {
         h_in = static_cast<uint8_t *>(pinned_scratch("call.in", in.total + 1));
-        d_in = static_cast<uint8_t *>(dev_scratch("call.in", in.total + 1));
         h_out = static_cast<uint8_t *>(pinned_scratch("call.out", out.total + 1));
-        d_out = static_cast<uint8_t *>(dev_scratch("call.out", out.total + 1));
+        zero_copy = in.total <= kZeroCopyBytes && out.total <= kZeroCopyBytes;
+        d_in = zero_copy ? h_in : static_cast<uint8_t *>(dev_scratch("call.in", in.total + 1));
+        d_out = zero_copy ? h_out : static_cast<uint8_t *>(dev_scratch("call.out", out.total + 1));
         d_work = static_cast<uint8_t *>(dev_scratch("call.work", work.total + 1));
         n_in = in.total;
         n_out = out.total;
     }
     void upload() {
-        if (n_in) check(vslam_copy_h2d(ctx(), d_in, h_in, n_in), "copy_h2d");
+        if (n_in && !zero_copy) check(vslam_copy_h2d(ctx(), d_in, h_in, n_in), "copy_h2d");
     }
     void download() {
-        if (n_out) check(vslam_copy_d2h(ctx(), h_out, d_out, n_out), "copy_d2h");
+        if (zero_copy) check(vslam_ctx_wait(ctx()), "ctx_wait");
+        else if (n_out) check(vslam_copy_d2h(ctx(), h_out, d_out, n_out), "copy_d2h");
     }
     template <class T>
     T *hin(size_t off) { return reinterpret_cast<T *>(h_in + off); }
@@ -143,6 +149,7 @@ struct Call {
 
    private:
     size_t n_in = 0, n_out = 0;
+    bool zero_copy = false;
 };
 
 // ---------------------------------------------------------------------------------------- device copies of trees
