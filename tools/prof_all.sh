@@ -1,9 +1,13 @@
+# rocprofv3 passes over the default bench command (C3): kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in their own
+# passes, with the calibration copies), SQ counters.  Usage (on the GPU box): bash tools/prof_all.sh <tag>
 set -e
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/final2
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass > $O/stats.log 2>&1
+B="--steps 5 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass"
+rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py $B > $O/stats.log 2>&1
 echo stats done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass --pmc-calibrate > $O/fetch.log 2>&1
 echo fetch done
@@ -12,5 +16,6 @@ echo write done
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $O/sq -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass > $O/sq.log 2>&1
 echo sq done
 cd $R
-python3 bench.py > $O/bench_full.json 2> $O/bench_full.err
-echo bench done
+python3 tools/prof_summary.py $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_summary.csv > /dev/null
+python3 tools/pmc_summary.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_hbm_traffic.csv > /dev/null
+python3 tools/sq_summary.py $(find $O/sq -name "*counter_collection.csv" | head -1) $O/sq_counters.csv

@@ -247,7 +247,7 @@ __device__ __forceinline__ double div_inrange(double x, double y) {
     return __builtin_fma(e, r, q);
 }
 
-template <int M, int N, int N1, bool HASV>
+template <int M, int N, int N1, bool HASV, bool ROWREG = false>
 __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, float *extra_row) {
     static_assert(N1 == N || N1 == N + 1, "FULL_UV asks for at most one row beyond the rank here");
     const double minval = FLT_MIN;
@@ -261,6 +261,7 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
         }
     }
 
+    if (!ROWREG) {
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
         for (int i = 0; i < N - 1; i++)
@@ -329,6 +330,46 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
         if (!changed) break;
     }
 
+    } else {
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < N - 1; i++) {
+            // Row i stays in registers while j walks the rows below it (a rotation updates it in place, under the lane's
+            // mask) and goes back to LDS once per i.  Same operations on the same values as reading both rows per
+            // pair, so the bits do not change; the LDS traffic halves (1.03 -> 0.97 ms at C3).  Fetching row j + 1
+            // ahead of time on top of that was slower (1.06 ms), and the 3x3 instance is faster with the plain form.
+            float ai[M];
+#pragma unroll
+            for (int k = 0; k < M; k++) ai[k] = VS_A(i, k);
+            for (int j = i + 1; j < N; j++) {
+                float aj[M];
+#pragma unroll
+                for (int k = 0; k < M; k++) aj[k] = VS_A(j, k);
+                double a = 0, p = 0, b = 0;
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    const double di = (double)ai[k], dj = (double)aj[k];
+                    p = __builtin_fma(di, dj, p);
+                    a = __builtin_fma(di, di, a);   // W[i]
+                    b = __builtin_fma(dj, dj, b);   // W[j]
+                }
+                if (jacobi_converged(p, a, b)) continue;
+
+                p *= 2;
+                const double beta = a - b;
+                const double g2 = p * p + beta * beta;
+                float c, s;
+                // With g2 and p in this range every operand and quotient below stays within 2^+-500 (gamma <= 2^200,
+                // the two ratios under the square roots lie in [1/2, 1], |p / (gamma * s * 2)| >= 2^-500), where the
+                // short sequences equal the full ones; otherwise the whole wave takes sqrt() and '/'.
+                const bool safe = g2 > 0x1p-400 && g2 < 0x1p400 && fabs(p) > 0x1p-300;
+                if (!__any(!safe)) {
+                    const double gamma = sqrt_inrange(g2);   // pinned hypot
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = (float)sqrt_inrange(div_inrange(delta, gamma));
+                        c = (float)div_inrange(p, gamma * (double)s * 2);
+                    }
     double W[N];   // singular values: registers, every index below is compile-time
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -502,7 +543,7 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
     }
 
     float w8[8], f0[9];
-    jacobi_svd_lanes<9, 8, 9, false>(sA, nullptr, tid, w8, f0);   // SVDecomp(A 8x9), :94; f0 = V_t.row(8), :95
+    jacobi_svd_lanes<9, 8, 9, false, true>(sA, nullptr, tid, w8, f0);   // SVDecomp(A 8x9), :94; f0 = V_t.row(8), :95
 
     // second SVD on the 3x3 (:98): working rows are the COLUMNS of F0 (m == n -> transpose)
     float *sV = sA + 9 * kSolveThreads;
