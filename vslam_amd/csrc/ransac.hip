@@ -359,9 +359,7 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
                 const double beta = a - b;
                 const double g2 = p * p + beta * beta;
                 float c, s;
-                // With g2 and p in this range every operand and quotient below stays within 2^+-500 (gamma <= 2^200,
-                // the two ratios under the square roots lie in [1/2, 1], |p / (gamma * s * 2)| >= 2^-500), where the
-                // short sequences equal the full ones; otherwise the whole wave takes sqrt() and '/'.
+                // see the plain form above for the range argument
                 const bool safe = g2 > 0x1p-400 && g2 < 0x1p400 && fabs(p) > 0x1p-300;
                 if (!__any(!safe)) {
                     const double gamma = sqrt_inrange(g2);   // pinned hypot
@@ -369,7 +367,47 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
                         const double delta = (gamma - beta) * 0.5;
                         s = (float)sqrt_inrange(div_inrange(delta, gamma));
                         c = (float)div_inrange(p, gamma * (double)s * 2);
+                    } else {
+                        c = (float)sqrt_inrange(div_inrange(gamma + beta, gamma * 2));
+                        s = (float)div_inrange(p, gamma * (double)c * 2);
                     }
+                } else {
+                    const double gamma = sqrt(g2);   // pinned hypot
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = (float)sqrt(delta / gamma);
+                        c = (float)(p / (gamma * (double)s * 2));
+                    } else {
+                        c = (float)sqrt((gamma + beta) / (gamma * 2));
+                        s = (float)(p / (gamma * (double)c * 2));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    const float t0 = c * ai[k] + s * aj[k];
+                    const float t1 = (-s) * ai[k] + c * aj[k];
+                    ai[k] = t0;
+                    VS_A(j, k) = t1;
+                }
+                changed = true;
+                if (HASV) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const float vi = VS_V(i, k), vj = VS_V(j, k);
+                        const float t0 = c * vi + s * vj;
+                        const float t1 = (-s) * vi + c * vj;
+                        VS_V(i, k) = t0;
+                        VS_V(j, k) = t1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < M; k++) VS_A(i, k) = ai[k];
+        }
+        if (!changed) break;
+    }
+
+    }
     double W[N];   // singular values: registers, every index below is compile-time
 #pragma unroll
     for (int i = 0; i < N; i++) {
