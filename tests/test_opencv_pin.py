@@ -1,0 +1,80 @@
+"""Pins the oracle to REAL OpenCV output — when somebody has produced it.
+
+Everything the reference computes inside OpenCV (cvtColor, goodFeaturesToTrack,
+ORB::compute, BFMatcher::knnMatch, SVDecomp, the cv::Mat algebra of the residual) is restated in oracle/ from
+OpenCV's published algorithms, and OpenCV is not in this image, so that restatement is unverified: PARITY UNPINNED.
+tools/opencv_dump.cpp runs the reference's own OpenCV calls on the seeded inputs of tests/golden/frontend_v1.npz on a
+machine that has OpenCV; its output, committed as tests/golden/opencv_v1.npz, turns this file from a skip into the pin.
+Until then the test reports the unpinned state and nothing else.  (The round trip of the container format is
+checked either way.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import opencv_case  # noqa: E402
+
+DUMP = os.path.join(ROOT, "tests", "golden", "opencv_v1.npz")
+G = np.load(os.path.join(ROOT, "tests", "golden", "frontend_v1.npz"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_case_file_round_trip(tmp_path):
+    arrays = opencv_case.case_inputs()
+    p = str(tmp_path / "case.bin")
+    opencv_case.write_records(p, arrays)
+    back = opencv_case.read_records(p)
+    assert sorted(back) == sorted(arrays)
+    for k, v in arrays.items():
+        assert back[k].dtype == v.dtype and np.array_equal(back[k], v), k
+
+
+def _dump():
+    if not os.path.exists(DUMP):
+        pytest.skip("PARITY UNPINNED for the OpenCV-internal stages: tests/golden/opencv_v1.npz has not been produced "
+                    "(build tools/opencv_dump.cpp where OpenCV 4 is installed; see its header)")
+    return np.load(DUMP)
+
+
+def test_extraction_matches_opencv(oracle):
+    D = _dump()
+    bgr = G["e_bgr"]
+    for f in range(2):
+        gray = oracle.bgr2gray(bgr[f])
+        assert np.array_equal(gray, D[f"cv_gray{f}"]), "cvtColor(BGR2GRAY)"
+        assert np.array_equal(bits(oracle.min_eigen(gray)), bits(D[f"cv_eig{f}"])), "cornerMinEigenVal"
+        assert np.array_equal(oracle.good_features(gray, 150), D[f"cv_corners{f}"]), "goodFeaturesToTrack"
+        assert np.array_equal(oracle.gaussian7(gray), D[f"cv_blur{f}"]), "GaussianBlur 7x7 sigma 2"
+        # which keypoints ORB::compute keeps (border filter) does not depend on the bit pattern; the descriptors do:
+        # they can be compared once OpenCV's learned pattern is supplied (VSLAM_BRIEF_PATTERN, 1024 int8)
+        pat_path = os.environ.get("VSLAM_BRIEF_PATTERN")
+        pat = np.fromfile(pat_path, np.int8).reshape(256, 4) if pat_path else G["e_pattern"]
+        ca, sa = map(float, G["e_rot"])
+        e = oracle.extract_features(bgr[f], 150, ca, sa, pat)
+        assert np.array_equal(e["xy"], D[f"cv_kept_xy{f}"]), "ORB::compute border filter"
+        if pat_path:
+            assert np.array_equal(e["desc"], D[f"cv_desc{f}"]), "rBRIEF descriptors"
+
+
+def test_matching_matches_opencv(oracle):
+    D = _dump()
+    assert np.array_equal(np.stack(oracle.match_knn2(G["m_d1"], G["m_d2"]), 1), D["cv_knn"]), "BFMatcher::knnMatch(k=2)"
+    p, rc = oracle.match_knn2_ratio(G["m_d1"], G["m_d2"])
+    assert rc == 0 and np.array_equal(p, D["cv_pairs"]), "ratio test"
+
+
+def test_ransac_arithmetic_matches_opencv(oracle):
+    D = _dump()
+    if int(D["opencv_have_lapack_macro"][0]):
+        pytest.skip("this OpenCV build routes SVDecomp through LAPACK: its F differs from the built-in Jacobi by design "
+                    "(DESIGN.md section 2); dump with a non-LAPACK build to pin a11")
+    r = oracle.find_fundamental(G["r_p1"], G["r_p2"], G["r_pairs"], G["r_fsets"], 10.0)
+    assert np.array_equal(bits(r["hypF"]), bits(D["cv_hypF"])), "two SVDecomp + U diag(D) Vt"
+    assert np.array_equal(r["hyp_count"], D["cv_hyp_count"]), "inlier counts"
+    assert np.array_equal(bits(r["hyp_sum"]), bits(D["cv_hyp_sum"])), "cv::sum(e_sq) (element order inside cv::sum is build dependent)"

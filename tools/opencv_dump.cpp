@@ -1,0 +1,222 @@
+// OpenCV-side vector dumper: the only way the OpenCV-dependent rows of the hot path
+// can ever be pinned.  It runs the reference's own OpenCV calls on the seeded inputs of tests/golden/make_golden.py
+// and writes what they return, so that tests/test_opencv_pin.py can hold the oracle (and through it the kernels) to
+// real OpenCV output.  NOT part of the product, never built by build(), never shipped to the GPU box; it builds only
+// on a machine that has OpenCV 4 (the reference's dependency, makefile:4,7):
+//
+//     python tools/opencv_case.py export /tmp/case.bin                       # inputs, from tests/golden/frontend_v1.npz
+//     g++ -O2 -std=c++17 tools/opencv_dump.cpp -o /tmp/opencv_dump $(pkg-config --cflags --libs opencv4)
+//     /tmp/opencv_dump /tmp/case.bin /tmp/dump.bin
+//     python tools/opencv_case.py import /tmp/dump.bin tests/golden/opencv_v1.npz   # commit the npz
+//
+// Each block below names the reference line whose OpenCV call it repeats.  Container format (both files): a sequence of
+// records { u32 name_len, name, u32 dtype (0 u8, 1 i32, 2 f32, 3 f64), u32 ndim, u32 dims[ndim], data }.
+#if !__has_include(<opencv2/core.hpp>)
+#error "tools/opencv_dump.cpp needs OpenCV 4 headers (it is a maintainer-side tool, not part of the build)"
+#else
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <opencv2/core.hpp>
+#include <opencv2/features2d.hpp>
+#include <opencv2/imgproc.hpp>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct Arr {
+    uint32_t dtype = 0;
+    std::vector<uint32_t> dims;
+    std::vector<uint8_t> data;
+    size_t count() const {
+        size_t n = 1;
+        for (uint32_t d : dims) n *= d;
+        return n;
+    }
+    template <class T>
+    const T *as() const { return reinterpret_cast<const T *>(data.data()); }
+};
+static const size_t kElem[4] = {1, 4, 4, 8};
+
+static std::map<std::string, Arr> read_all(const char *path) {
+    std::map<std::string, Arr> out;
+    FILE *f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    uint32_t nl;
+    while (fread(&nl, 4, 1, f) == 1) {
+        std::string name(nl, ' ');
+        Arr a;
+        uint32_t nd;
+        if (fread(&name[0], 1, nl, f) != nl || fread(&a.dtype, 4, 1, f) != 1 || fread(&nd, 4, 1, f) != 1) throw std::runtime_error("truncated case file");
+        a.dims.resize(nd);
+        if (nd && fread(a.dims.data(), 4, nd, f) != nd) throw std::runtime_error("truncated case file");
+        a.data.resize(a.count() * kElem[a.dtype]);
+        if (!a.data.empty() && fread(a.data.data(), 1, a.data.size(), f) != a.data.size()) throw std::runtime_error("truncated case file");
+        out[name] = a;
+    }
+    fclose(f);
+    return out;
+}
+
+static FILE *g_out = nullptr;
+static void put(const std::string &name, uint32_t dtype, std::vector<uint32_t> dims, const void *data) {
+    const uint32_t nl = (uint32_t)name.size(), nd = (uint32_t)dims.size();
+    size_t n = kElem[dtype];
+    for (uint32_t d : dims) n *= d;
+    fwrite(&nl, 4, 1, g_out);
+    fwrite(name.data(), 1, nl, g_out);
+    fwrite(&dtype, 4, 1, g_out);
+    fwrite(&nd, 4, 1, g_out);
+    if (nd) fwrite(dims.data(), 4, nd, g_out);
+    if (n) fwrite(data, 1, n, g_out);
+}
+static void put_mat(const std::string &name, const cv::Mat &m) {
+    cv::Mat c = m.isContinuous() ? m : m.clone();
+    const uint32_t dtype = c.depth() == CV_8U ? 0 : c.depth() == CV_32S ? 1 : c.depth() == CV_32F ? 2 : 3;
+    if (c.depth() != CV_8U && c.depth() != CV_32S && c.depth() != CV_32F && c.depth() != CV_64F) throw std::runtime_error("put_mat: depth");
+    put(name, dtype, {(uint32_t)c.rows, (uint32_t)(c.cols * c.channels())}, c.data);
+}
+
+int main(int argc, char **argv) {
+    if (argc != 3) {
+        fprintf(stderr, "usage: opencv_dump <case.bin> <dump.bin>\n");
+        return 2;
+    }
+    try {
+        auto in = read_all(argv[1]);
+        g_out = fopen(argv[2], "wb");
+        if (!g_out) throw std::runtime_error("cannot write the dump");
+        const std::string ver = CV_VERSION;
+        put("opencv_version", 0, {(uint32_t)ver.size()}, ver.data());
+#ifdef HAVE_LAPACK
+        const uint8_t lapack = 1;   // cv::SVDecomp goes through sgesdd then: the built-in Jacobi is NOT what this build runs
+#else
+        const uint8_t lapack = 0;
+#endif
+        put("opencv_have_lapack_macro", 0, {1}, &lapack);
+
+        // ---------------------------------------------------------------- extraction, src/Frame.cpp:53-80
+        const Arr &bgr = in.at("e_bgr");   // [2][h][w][3] u8
+        const int frames = (int)bgr.dims[0], h = (int)bgr.dims[1], w = (int)bgr.dims[2];
+        const int maxc = in.at("e_maxc").as<int32_t>()[0];
+        for (int f = 0; f < frames; f++) {
+            const std::string t = std::to_string(f);
+            cv::Mat image(h, w, CV_8UC3, const_cast<uint8_t *>(bgr.as<uint8_t>()) + (size_t)f * h * w * 3);
+            cv::Mat gray;
+            cv::cvtColor(image, gray, cv::COLOR_BGR2GRAY);                                  // :56
+            put_mat("cv_gray" + t, gray);
+            cv::Mat eig;
+            cv::cornerMinEigenVal(gray, eig, 3, 3);                                          // inside goodFeaturesToTrack
+            put_mat("cv_eig" + t, eig);
+            std::vector<cv::Point2f> corners;
+            cv::goodFeaturesToTrack(gray, corners, maxc, 0.01, 3);                           // :61 (3000 there)
+            put("cv_corners" + t, 2, {(uint32_t)corners.size(), 2}, corners.data());
+            cv::Mat blurred;
+            cv::GaussianBlur(gray, blurred, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);    // ORB::compute's blur
+            put_mat("cv_blur" + t, blurred);
+            std::vector<cv::KeyPoint> kps;
+            for (const cv::Point2f &p : corners) kps.push_back(cv::KeyPoint(p, 20));          // :64-67
+            cv::Ptr<cv::ORB> orb = cv::ORB::create();                                         // :57
+            cv::Mat desc;
+            orb->compute(gray, kps, desc);                                                    // :68 (may drop border keypoints)
+            std::vector<cv::Point2f> kept;
+            for (const cv::KeyPoint &k : kps) kept.push_back(k.pt);                           // :69-72
+            put("cv_kept_xy" + t, 2, {(uint32_t)kept.size(), 2}, kept.data());
+            put_mat("cv_desc" + t, desc);                                                     // OpenCV's own learned pattern
+        }
+
+        // ---------------------------------------------------------------- matching, src/Frame.cpp:83-94
+        {
+            const Arr &d1 = in.at("m_d1"), &d2 = in.at("m_d2");
+            cv::Mat m1((int)d1.dims[0], 32, CV_8UC1, const_cast<uint8_t *>(d1.as<uint8_t>()));
+            cv::Mat m2((int)d2.dims[0], 32, CV_8UC1, const_cast<uint8_t *>(d2.as<uint8_t>()));
+            cv::Ptr<cv::BFMatcher> matcher = cv::BFMatcher::create(cv::NORM_HAMMING);         // :83
+            std::vector<std::vector<cv::DMatch>> knn;
+            matcher->knnMatch(m1, m2, knn, 2);                                                // :85
+            std::vector<int32_t> flat;   // idx0, dist0, idx1, dist1 per query
+            std::vector<int32_t> pairs;
+            for (auto &m : knn) {
+                flat.push_back(m[0].trainIdx);
+                flat.push_back((int32_t)m[0].distance);
+                flat.push_back(m[1].trainIdx);
+                flat.push_back((int32_t)m[1].distance);
+                if (m[0].distance < m[1].distance * 0.7) {                                    // :91
+                    pairs.push_back(m[0].queryIdx);
+                    pairs.push_back(m[0].trainIdx);
+                }
+            }
+            put("cv_knn", 1, {(uint32_t)knn.size(), 4}, flat.data());
+            put("cv_pairs", 1, {(uint32_t)(pairs.size() / 2), 2}, pairs.data());
+        }
+
+        // ---------------------------------------------------------------- RANSAC arithmetic, src/RansacFilter.cpp:69-140
+        {
+            const Arr &p1 = in.at("r_p1"), &p2 = in.at("r_p2"), &pr = in.at("r_pairs"), &sets = in.at("r_fsets");
+            const int M = (int)pr.dims[0], H = (int)sets.dims[0];
+            const float thr = in.at("r_thr").as<float>()[0];
+            const float *P1 = p1.as<float>(), *P2 = p2.as<float>();
+            const int32_t *PR = pr.as<int32_t>(), *S = sets.as<int32_t>();
+            std::vector<float> allF((size_t)H * 9), allD8((size_t)H * 8), allVt8((size_t)H * 81), allD3((size_t)H * 3), allSum(H);
+            std::vector<int32_t> allCount(H);
+            cv::Mat x1(3, M, CV_32FC1), x2(3, M, CV_32FC1);                                   // :108-117
+            for (int i = 0; i < M; i++) {
+                x1.at<float>(0, i) = P1[2 * PR[2 * i]];
+                x1.at<float>(1, i) = P1[2 * PR[2 * i] + 1];
+                x1.at<float>(2, i) = 1;
+                x2.at<float>(0, i) = P2[2 * PR[2 * i + 1]];
+                x2.at<float>(1, i) = P2[2 * PR[2 * i + 1] + 1];
+                x2.at<float>(2, i) = 1;
+            }
+            for (int hh = 0; hh < H; hh++) {
+                cv::Mat A(8, 9, CV_32FC1);                                                    // :75-90
+                for (int i = 0; i < 8; i++) {
+                    const int idx = S[hh * 8 + i];
+                    const float u1 = P1[2 * PR[2 * idx]], v1 = P1[2 * PR[2 * idx] + 1];
+                    const float u2 = P2[2 * PR[2 * idx + 1]], v2 = P2[2 * PR[2 * idx + 1] + 1];
+                    float *r = A.ptr<float>(i);
+                    r[0] = u2 * u1; r[1] = u2 * v1; r[2] = u2;
+                    r[3] = v2 * u1; r[4] = v2 * v1; r[5] = v2;
+                    r[6] = u1;      r[7] = v1;      r[8] = 1;
+                }
+                cv::Mat D, U, V_t;
+                cv::SVDecomp(A, D, U, V_t, cv::SVD::MODIFY_A | cv::SVD::FULL_UV);              // :94
+                std::memcpy(&allD8[(size_t)hh * 8], D.ptr<float>(), 32);
+                cv::Mat Vc = V_t.isContinuous() ? V_t : V_t.clone();
+                std::memcpy(&allVt8[(size_t)hh * 81], Vc.ptr<float>(), 81 * 4);
+                cv::Mat temp_F = V_t.row(8).reshape(0, 3);                                    // :95
+                cv::SVDecomp(temp_F, D, U, V_t, cv::SVD::MODIFY_A | cv::SVD::FULL_UV);         // :98
+                std::memcpy(&allD3[(size_t)hh * 3], D.ptr<float>(), 12);
+                D.at<float>(2) = 0;                                                           // :99
+                temp_F = U * cv::Mat::diag(D) * V_t;                                          // :101
+                cv::Mat Fc = temp_F.isContinuous() ? temp_F : temp_F.clone();
+                std::memcpy(&allF[(size_t)hh * 9], Fc.ptr<float>(), 36);
+                // compute_fundamental_residual, :119-138
+                cv::Mat F_x1 = temp_F * x1;
+                cv::Mat F_t_x2 = temp_F.t() * x2;
+                cv::Mat x2_t_F_x1 = x2.mul(F_x1);
+                cv::reduce(x2_t_F_x1, x2_t_F_x1, 0, cv::REDUCE_SUM);
+                cv::Mat e_sq = x2_t_F_x1.mul(x2_t_F_x1) / F_x1.row(0).mul(F_x1.row(0)) + F_x1.row(1).mul(F_x1.row(1)) +
+                               F_t_x2.row(0).mul(F_t_x2.row(0)) + F_t_x2.row(1).mul(F_t_x2.row(1));
+                int n_in = 0;
+                for (int i = 0; i < M; i++) n_in += e_sq.at<float>(i) <= thr ? 1 : 0;         // :130
+                allCount[hh] = n_in;
+                allSum[hh] = (float)cv::sum(e_sq)[0];                                         // :138
+                if (hh == 0) put_mat("cv_esq_h0", e_sq);
+            }
+            put("cv_hypF", 2, {(uint32_t)H, 9}, allF.data());
+            put("cv_svd8_D", 2, {(uint32_t)H, 8}, allD8.data());
+            put("cv_svd8_Vt", 2, {(uint32_t)H, 81}, allVt8.data());
+            put("cv_svd3_D", 2, {(uint32_t)H, 3}, allD3.data());
+            put("cv_hyp_count", 1, {(uint32_t)H}, allCount.data());
+            put("cv_hyp_sum", 2, {(uint32_t)H}, allSum.data());
+        }
+        fclose(g_out);
+        printf("wrote %s (OpenCV %s)\n", argv[2], CV_VERSION);
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "opencv_dump: %s\n", e.what());
+        return 1;
+    }
+}
+#endif
