@@ -66,13 +66,16 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
 #    command, committed under profiles/ -- an instruction count per wave is a property of the code and the
 #    workload, not of the run) x 2 cycles per wave instruction (a 64-lane wave on a SIMD-32) against
 #    SIMDs x clock.  Both fractions are <= 1 by construction.
-FP32_PEAK_TFLOPS = 157.3
+FP32_PEAK_TFLOPS = 157.3                       # FMA counted as 2: 256 CUs x 4 SIMDs x 32 lanes x 2 x 2.4 GHz
+INT32_PEAK_TOPS = FP32_PEAK_TFLOPS / 2.0       # one 32-bit integer op per lane and clock
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
 ALG_OPS = {
-    # kernel: (what one unit is, algorithmic ops per unit, kind)
-    "ransac_count_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop"),
-    "ransac_score_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop"),
-    "match_knn2_kernel": ("(query, train) descriptor pairs", 16.0, "int op (8 x 32-bit xor + 8 x popcount)"),
+    # kernel: (what one unit is, algorithmic ops per unit, kind, peak in Tops/s)
+    "ransac_count_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop", FP32_PEAK_TFLOPS),
+    "ransac_score_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop", FP32_PEAK_TFLOPS),
+    "ransac_solve_kernel": ("hypotheses (two SVDs, about 3000 flop each: SURVEY.md 8d)", 3000.0, "flop", FP32_PEAK_TFLOPS),
+    "min_eigen_kernel": ("pixels (stencil work, about 60 int/flop per pixel: SURVEY.md 8d)", 60.0, "flop", FP32_PEAK_TFLOPS),
+    "match_knn2_kernel": ("(query, train) descriptor pairs", 16.0, "int op (8 x 32-bit xor + 8 x popcount)", INT32_PEAK_TOPS),
 }
 SQ_PROFILE = os.path.join(ROOT, "profiles", "r02_sq_counters.csv")
 
@@ -94,12 +97,12 @@ def arithmetic_view(kernel, units, ms_per_launch, full_batch):
     """flops / issue fractions of one launch of `kernel` that processed `units` units of work."""
     if kernel not in ALG_OPS or ms_per_launch <= 0:
         return None
-    what, ops, kind = ALG_OPS[kernel]
+    what, ops, kind, peak = ALG_OPS[kernel]
     t = ms_per_launch * 1e-3
     tops = units * ops / t / 1e12
     view = {"unit_of_work": what, "units_per_launch": units, "ops_per_unit": ops, "op_kind": kind,
-            "achieved": tops, "peak": FP32_PEAK_TFLOPS, "unit": "Tops/s vs the FP32 vector peak (TFLOP/s)",
-            "frac": tops / FP32_PEAK_TFLOPS}
+            "achieved": tops, "peak": peak, "unit": "Tops/s (vector ALU peak for this kind of op)",
+            "frac": tops / peak}
     sq = sq_counters(kernel) if full_batch else None
     if sq:
         waves, insts = sq
@@ -240,6 +243,9 @@ def main():
     ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
                     help="pairs per process for the all-host-cores CPU figure (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--solver", default="exact", choices=["exact", "gram"],
+                    help="gram = the opt-in MFMA / normal-matrix 8-point solver (VSLAM_OPT_RANSAC_SOLVER 1): NOT bit-exact, "
+                         "never the headline number; the line is labelled")
     ap.add_argument("--lanes", type=int, default=1,
                     help="split each GPU's batch over this many contexts (own stream + workspaces) that run concurrently")
     ap.add_argument("--pmc-calibrate", action="store_true",
@@ -289,6 +295,8 @@ def main():
     thr = 10.0                                    # RansacFilter rf(8, 100, 10), src/vslam.cpp:19
     seed = 0x5EED0000 + sorted(WORKLOADS).index(args.workload)
     ctx = Context(local_rank)
+    if args.solver == "gram":
+        ctx.set_option(ctx.OPT_RANSAC_SOLVER, 1)
     lanes = max(1, args.lanes)
     assert P % lanes == 0
     PL = P // lanes
@@ -384,6 +392,9 @@ def main():
                        "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}" + (f", {backend_label} all_gather of result records" if multi else "")},
             "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
         }
+        if args.solver != "exact":
+            result["solver"] = "gram-mfma: opt-in approximate 8-point solver, results NOT bit-exact with the reference path"
+            result["metric"] += " [NON-PARITY SOLVER]"
 
     # ---- separate pass: per-kernel durations with HIP events on the kernels' own stream
     if rank == 0 and not args.no_profile_pass:
@@ -412,6 +423,10 @@ def main():
         full_batch = args.workload == "C3" and P == WORKLOADS["C3"][4]   # the shape the committed counter passes ran
 
         def units_of(kname):   # units of work one launch processes (M = inlier matches, a lower bound of the evaluated ones)
+            if kname == "min_eigen_kernel":
+                return 2.0 * w * h * P
+            if kname == "ransac_solve_kernel":
+                return float(H) * P
             return (H * m_prelim if kname.startswith("ransac") else float(n_kp.mean()) ** 2) * P
 
         by_name = {k["kernel"]: k for k in kernels}

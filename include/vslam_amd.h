@@ -63,9 +63,15 @@ const char *vslam_version(void);
  *       scoring time.
  *   VSLAM_OPT_RANSAC_MIN_MATCHES  8 (default) .. 1: vslam_ransac_evaluate skips items with fewer matches than this
  *       (no model: winner -1).  find_fundamental needs 8 to draw a set (src/RansacFilter.cpp:24), but
- *       compute_fundamental_residual scores a GIVEN F on any number of matches (:105-140): its adapter sets 1.   */
+ *       compute_fundamental_residual scores a GIVEN F on any number of matches (:105-140): its adapter sets 1.
+ *   VSLAM_OPT_RANSAC_SOLVER  0 (default): compute_fundamental as the reference computes it (OpenCV's Jacobi SVD replayed
+ *       operation by operation; bit-exact with the oracle).  1: opt-in APPROXIMATE solver for throughput experiments
+ *       (BASELINE.json configs[4]): conditioned 9x9 normal matrix on the matrix cores (v_mfma_f32_16x16x4_f32) +
+ *       inverse iteration.  NOT bit-exact: F equals the exact solver's up to sign and about 1e-4 (unit-norm F) on
+ *       well-conditioned samples; inlier masks may differ.  Never used unless set.                              */
 #define VSLAM_OPT_RANSAC_ALL_SUMS 1
 #define VSLAM_OPT_RANSAC_MIN_MATCHES 2
+#define VSLAM_OPT_RANSAC_SOLVER 3
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

@@ -245,3 +245,43 @@ def test_threshold_and_scale_outside_certified_range(ctx, oracle, sums_mode):
             n = int(m[b])
             ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], thr)
             _compare(out, ref, b, n, sums_mode)
+
+
+def test_mfma_solver_is_opt_in_and_agrees_within_its_stated_tolerance(ctx, oracle):
+    """VSLAM_OPT_RANSAC_SOLVER = 1 (BASELINE.json configs[4]: the 8-point solve as an MFMA contraction) is an
+    approximate solver and says so: it is off unless asked for, and what it promises is
+      * per hypothesis: F equal to the exact solver's up to sign, relative Frobenius error <= 1e-3 for at least 85 % of
+        the hypotheses (median <= 2e-5; measured: 92 % and 3.5e-7).  The remainder are ill-conditioned 8-point samples
+        — un-normalised pixel coordinates give the design matrix a condition number around 1e6, so where the two
+        smallest singular values are close the reference's own float Jacobi is no more "right" than this solver;
+      * per hypothesis: where F agrees to 1e-4 the inlier counts agree to within 2 % of the matches for at least 95 %
+        of those hypotheses (a count changes only through matches whose residual sits at the threshold);
+      * per pair: the best inlier count found is at least 90 % of the exact path's (which hypothesis wins may differ:
+        the accept rule is a tie-break over near-equal counts, so the mask agreement is reported, not promised).
+    The default path is untouched by the option (re-checked bit for bit after switching it off)."""
+    K, Hy, thr = 1600, 512, 10.0
+    sizes = [1500, 800, 300]
+    xy1, xy2, pairs, m = _batch(4100, sizes, K, 1920, 1080)
+    sets = np.stack([oracle.ransac_sets(90 + b, n, Hy) for b, n in enumerate(sizes)])
+    exact = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
+    ctx.set_option(ctx.OPT_RANSAC_SOLVER, 1)
+    try:
+        approx = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
+    finally:
+        ctx.set_option(ctx.OPT_RANSAC_SOLVER, 0)
+    again = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
+    assert np.array_equal(bits(again["hypF"]), bits(exact["hypF"])) and np.array_equal(again["mask"], exact["mask"])
+    for b, n in enumerate(sizes):
+        Fe, Fa = exact["hypF"][b].astype(np.float64), approx["hypF"][b].astype(np.float64)
+        sign = np.sign((Fe * Fa).sum(1, keepdims=True))
+        err = np.linalg.norm(Fa * sign - Fe, axis=1) / np.linalg.norm(Fe, axis=1)
+        ok = np.isfinite(err)
+        frac = float((err[ok] <= 1e-3).mean())
+        print(f"pair {b}: median rel. error {np.median(err[ok]):.2e}, within 1e-3: {100 * frac:.1f} %, "
+              f"winner inliers exact {exact['best'][b, 1]} approx {approx['best'][b, 1]}, "
+              f"mask agreement {100 * (exact['mask'][b, :n] == approx['mask'][b, :n]).mean():.2f} %")
+        assert ok.mean() > 0.99 and np.median(err[ok]) <= 2e-5 and frac >= 0.85, (b, np.median(err[ok]), frac)
+        close = ok & (err <= 1e-4)
+        dc = np.abs(exact["hyp_count"][b][close].astype(np.int64) - approx["hyp_count"][b][close])
+        assert (dc <= 0.02 * n).mean() >= 0.95, (b, float((dc <= 0.02 * n).mean()))
+        assert int(approx["best"][b, 1]) >= 0.9 * int(exact["best"][b, 1]), b

@@ -101,6 +101,8 @@ class Context:
         self._check(self.lib.vslam_ctx_synchronize(self.handle))
 
     OPT_RANSAC_ALL_SUMS = 1
+    OPT_RANSAC_MIN_MATCHES = 2
+    OPT_RANSAC_SOLVER = 3
 
     def set_option(self, option, value):
         self._check(self.lib.vslam_ctx_set_option(self.handle, C.c_int(option), C.c_int(int(value))))

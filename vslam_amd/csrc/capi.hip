@@ -213,6 +213,11 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
         ctx->ransac_min_matches = value;
         return VSLAM_OK;
     }
+    if (option == VSLAM_OPT_RANSAC_SOLVER) {
+        VS_REQUIRE(ctx, value == 0 || value == 1, VSLAM_ERR_INVALID);
+        ctx->ransac_solver = value;
+        return VSLAM_OK;
+    }
     VS_REQUIRE(ctx, false && "unknown option", VSLAM_ERR_INVALID);
     return VSLAM_OK;
 }

@@ -36,6 +36,7 @@ struct vslam_ctx {
     int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, 1 fork after bgr2gray, 2 fork after min_eigen
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     int ransac_min_matches = VSLAM_SET_SIZE;   // VSLAM_OPT_RANSAC_MIN_MATCHES
+    int ransac_solver = 0;                      // VSLAM_OPT_RANSAC_SOLVER: 0 exact Jacobi replay, 1 Gram / MFMA (not bit-exact)
     bool ransac_all_sums = false;   // VSLAM_OPT_RANSAC_ALL_SUMS: exact residual sum of every hypothesis (ransac_score_kernel)
     std::string err;
 

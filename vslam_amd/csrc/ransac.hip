@@ -627,6 +627,237 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
         for (int k = 0; k < 9; k++) o[k] = F[k];
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// compute_fundamental, opt-in approximate form: the 8-point system as a dense contraction on the matrix cores
+// (BASELINE.json configs[4]; VSLAM_OPT_RANSAC_SOLVER = 1).  NOT bit-exact with the reference and never the default:
+// the parity bar pins the default solver to OpenCV's sequential Jacobi sweeps (ransac_solve_kernel above).
+//   1. Hartley-style conditioning with ONE similarity per frame of the pair (centroid and mean distance of the
+//      pair's matched points; ransac_condition_kernel), so the 9x9 normal matrix is formed from O(1) numbers;
+//   2. G = A^T A (9 x 9, A the 8 x 9 design matrix) on v_mfma_f32_16x16x4_f32: the A operand and the B operand of the
+//      instruction are the same register (lane l holds design[row 4 step + (l >> 4)][column l & 15]), two
+//      instructions per hypothesis, results through LDS to the lane that owns the hypothesis;
+//   3. the null vector of A = the eigenvector of G's smallest eigenvalue, by inverse iteration on G + mu I
+//      (Cholesky + 4 solves in f64, one lane per hypothesis);
+//   4. back to pixel coordinates (F0 = T2^T F^ T1), unit Frobenius norm like V_t.row(8), then the SAME rank-2 step as
+//      the exact kernel (jacobi_svd_lanes<3,3,3,true>, RansacFilter.cpp:98-101).
+// F agrees with the exact solver up to sign and rounding (tests/test_gpu_ransac.py states the tolerance and measures the
+// inlier-mask agreement); on degenerate samples (rank < 8) the two pick different vectors of the null space.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// the pair's two similarities: cond[b] = (cx1, cy1, s1, cx2, cy2, s2); one workgroup per pair
+__global__ __launch_bounds__(256) void ransac_condition_kernel(const float *__restrict__ xy1, const float *__restrict__ xy2,
+                                                               const int32_t *__restrict__ pairs, const int32_t *__restrict__ m_arr,
+                                                               int kp_stride, float *__restrict__ cond) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int m = min(m_arr[b], kp_stride);
+    if (m < VSLAM_SET_SIZE) return;
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    __shared__ double red[4][4];
+    __shared__ float cen[4];
+    auto block_sum4 = [&](double v0, double v1, double v2, double v3, double out[4]) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64);
+            v2 += __shfl_xor(v2, off, 64); v3 += __shfl_xor(v3, off, 64);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            red[tid >> 6][0] = v0; red[tid >> 6][1] = v1; red[tid >> 6][2] = v2; red[tid >> 6][3] = v3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    };
+    double s[4] = {0, 0, 0, 0}, tot[4];
+    for (int i = tid; i < m; i += 256) {
+        const int2 pr = PR[i];
+        const float2 a = P1[pr.x], c = P2[pr.y];
+        s[0] += a.x; s[1] += a.y; s[2] += c.x; s[3] += c.y;
+    }
+    block_sum4(s[0], s[1], s[2], s[3], tot);
+    if (tid < 4) cen[tid] = (float)(tot[tid] / m);
+    __syncthreads();
+    const float cx1 = cen[0], cy1 = cen[1], cx2 = cen[2], cy2 = cen[3];
+    double d1 = 0, d2 = 0;
+    for (int i = tid; i < m; i += 256) {
+        const int2 pr = PR[i];
+        const float2 a = P1[pr.x], c = P2[pr.y];
+        d1 += sqrtf((a.x - cx1) * (a.x - cx1) + (a.y - cy1) * (a.y - cy1));
+        d2 += sqrtf((c.x - cx2) * (c.x - cx2) + (c.y - cy2) * (c.y - cy2));
+    }
+    block_sum4(d1, d2, 0, 0, tot);
+    if (tid == 0) {
+        float *o = cond + (size_t)b * 6;
+        o[0] = cx1; o[1] = cy1; o[2] = tot[0] > 0 ? (float)(1.4142135623730951 * m / tot[0]) : 1.f;
+        o[3] = cx2; o[4] = cy2; o[5] = tot[1] > 0 ? (float)(1.4142135623730951 * m / tot[1]) : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(kSolveThreads) void ransac_solve_gram_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, const int32_t *__restrict__ sets, const float *__restrict__ cond, int kp_stride, int hyp,
+    float *__restrict__ hypF) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int h = blockIdx.x * kSolveThreads + tid;
+    const int m = min(m_arr[b], kp_stride);
+    if (m < VSLAM_SET_SIZE) return;   // uniform per workgroup
+
+    __shared__ float4 s_pts[kSolveThreads * 8];          // conditioned (u1, v1, u2, v2) of the 8 points of each hypothesis
+    __shared__ float s_G[kSolveThreads * 45];            // lower triangle of G per hypothesis; the 3x3 solver's scratch afterwards
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    const float cx1 = cond[b * 6 + 0], cy1 = cond[b * 6 + 1], sc1 = cond[b * 6 + 2];
+    const float cx2 = cond[b * 6 + 3], cy2 = cond[b * 6 + 4], sc2 = cond[b * 6 + 5];
+
+    // ---- conditioned sample points of this lane's hypothesis
+    const bool live = h < hyp;
+    const int hc = live ? h : hyp - 1;
+    const int32_t *S = sets + ((size_t)b * hyp + hc) * VSLAM_SET_SIZE;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int2 pr = PR[S[r]];
+        const float2 a = P1[pr.x], c = P2[pr.y];
+        s_pts[tid * 8 + r] = make_float4((a.x - cx1) * sc1, (a.y - cy1) * sc1, (c.x - cx2) * sc2, (c.y - cy2) * sc2);
+    }
+    __syncthreads();
+
+    // ---- 2. G = A^T A on the matrix cores, one hypothesis per pair of instructions
+    const int col = tid & 15, grp = tid >> 4;
+    for (int hh = 0; hh < kSolveThreads; hh++) {
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int step = 0; step < 2; step++) {
+            const float4 q = s_pts[hh * 8 + 4 * step + grp];   // (u1, v1, u2, v2) of design row 4 step + grp
+            // column `col` of the row [u2u1, u2v1, u2, v2u1, v2v1, v2, u1, v1, 1] (RansacFilter.cpp:81-89); 0 beyond 8
+            const float left = col < 3 ? q.z : (col < 6 ? q.w : (col < 9 ? 1.f : 0.f));
+            const int c3 = col - 3 * (col / 3);
+            const float right = c3 == 0 ? q.x : (c3 == 1 ? q.y : 1.f);
+            const float e = left * right;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e, e, acc, 0, 0, 0);   // D[i][j] += sum_k design[k][i] design[k][j]
+        }
+        // D: column = lane & 15, row = 4 (lane >> 4) + register; G is symmetric, the lower triangle is kept
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int row = 4 * grp + v;
+            if (row < 9 && col <= row) s_G[hh * 45 + row * (row + 1) / 2 + col] = acc[v];
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. smallest eigenvector of G by inverse iteration on G + mu I (f64, this lane's hypothesis)
+    double L[45];   // lower triangle, row-major: L[i(i+1)/2 + j]
+    double tr = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tr += (double)s_G[tid * 45 + i * (i + 1) / 2 + i];
+    const double mu = tr * 1e-7 + 1e-30;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            double v = (double)s_G[tid * 45 + i * (i + 1) / 2 + j] + (i == j ? mu : 0.0);
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+            L[i * (i + 1) / 2 + j] = i == j ? sqrt(v) : v / L[j * (j + 1) / 2 + j];
+        }
+    double x[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[i] = (i & 1) ? -1.0 / 3.0 : 1.0 / 3.0;
+#pragma unroll 1
+    for (int it = 0; it < 4; it++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {   // L y = x
+            double v = x[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) v -= L[i * (i + 1) / 2 + k] * x[k];
+            x[i] = v / L[i * (i + 1) / 2 + i];
+        }
+#pragma unroll
+        for (int i = 8; i >= 0; i--) {   // L^T z = y
+            double v = x[i];
+#pragma unroll
+            for (int k = i + 1; k < 9; k++) v -= L[k * (k + 1) / 2 + i] * x[k];
+            x[i] = v / L[i * (i + 1) / 2 + i];
+        }
+        double nn = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nn += x[i] * x[i];
+        const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+        for (int i = 0; i < 9; i++) x[i] *= inv;
+    }
+
+    // ---- 4. F0 = T2^T F^ T1 with T = [[s, 0, -s cx], [0, s, -s cy], [0, 0, 1]], then unit norm
+    double f0[9];
+    {
+        const double s1 = sc1, s2 = sc2, tx1 = -(double)sc1 * cx1, ty1 = -(double)sc1 * cy1, tx2 = -(double)sc2 * cx2, ty2 = -(double)sc2 * cy2;
+        double Mx[9];   // F^ T1
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            Mx[r * 3 + 0] = x[r * 3 + 0] * s1;
+            Mx[r * 3 + 1] = x[r * 3 + 1] * s1;
+            Mx[r * 3 + 2] = x[r * 3 + 0] * tx1 + x[r * 3 + 1] * ty1 + x[r * 3 + 2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {   // T2^T (F^ T1)
+            f0[0 * 3 + c] = s2 * Mx[0 * 3 + c];
+            f0[1 * 3 + c] = s2 * Mx[1 * 3 + c];
+            f0[2 * 3 + c] = tx2 * Mx[0 * 3 + c] + ty2 * Mx[1 * 3 + c] + Mx[2 * 3 + c];
+        }
+        double nn = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nn += f0[i] * f0[i];
+        const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+        for (int i = 0; i < 9; i++) f0[i] *= inv;
+    }
+    __syncthreads();   // every lane is done with its G: the buffer becomes the 3x3 solver's scratch
+
+    // the rank-2 step of the exact kernel (RansacFilter.cpp:98-101)
+    float *sA = s_G;
+    float *sV = s_G + 9 * kSolveThreads;
+    {
+        constexpr int M = 3;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) VS_A(i, k) = (float)f0[3 * k + i];
+    }
+    float d3[3];
+    jacobi_svd_lanes<3, 3, 3, true>(sA, sV, tid, d3, nullptr);
+    d3[2] = 0.f;
+    float U[9], Vt[9];
+    {
+        constexpr int M = 3, N = 3;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                U[r * 3 + c] = VS_A(c, r);
+                Vt[r * 3 + c] = VS_V(r, c);
+            }
+    }
+    const float Dg[9] = {d3[0], 0.f, 0.f, 0.f, d3[1], 0.f, 0.f, 0.f, d3[2]};
+    float UD[9], F[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            UD[i * 3 + j] = U[i * 3 + 0] * Dg[0 * 3 + j] + U[i * 3 + 1] * Dg[1 * 3 + j] + U[i * 3 + 2] * Dg[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            F[i * 3 + j] = UD[i * 3 + 0] * Vt[0 * 3 + j] + UD[i * 3 + 1] * Vt[1 * 3 + j] + UD[i * 3 + 2] * Vt[2 * 3 + j];
+    if (live) {
+        float *o = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = F[k];
+    }
+}
 #undef VS_A
 #undef VS_V
 
@@ -1397,8 +1628,18 @@ int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, c
                            float *hypF) {
     VS_REQUIRE(ctx, xy1 && xy2 && pairs && m && sets && hypF, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0 && hyp > 0, VSLAM_ERR_INVALID);
-    VsProfScope ps(ctx, "ransac_solve_kernel");
     dim3 grid(vs_div_up(hyp, kSolveThreads), batch);
+    if (ctx->ransac_solver == 1) {   // opt-in, not bit-exact (VSLAM_OPT_RANSAC_SOLVER)
+        float *cond = nullptr;
+        int rc = vs_arena_get(ctx, "ransac.cond", sizeof(float) * 6 * (size_t)batch, (void **)&cond);
+        if (rc) return rc;
+        VsProfScope ps(ctx, "ransac_solve_gram_kernel");
+        ransac_condition_kernel<<<batch, 256, 0, ctx->stream>>>(xy1, xy2, pairs, m, kp_stride, cond);
+        ransac_solve_gram_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, sets, cond, kp_stride, hyp, hypF);
+        VS_HIP(ctx, hipGetLastError());
+        return VSLAM_OK;
+    }
+    VsProfScope ps(ctx, "ransac_solve_kernel");
     ransac_solve_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, sets, kp_stride, hyp, hypF);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
