@@ -35,3 +35,8 @@ for p in range(P):
     print(p, *rows[-1])
 r = np.array(rows)
 print("mean", r.mean(0).round(1), "max tied", r[:, 2].max())
+
+# how many of the tied hypotheses survive the bound-based pruning (hyp_sum is -inf for the pruned ones)
+hs = out["hyp_sum"].cpu().numpy()
+kept = [(int(((cnt[p] == cnt[p].max()) & ~np.isneginf(hs[p])).sum())) for p in range(P)]
+print("candidates kept per pair:", kept, "mean", float(np.mean(kept)), "max", max(kept))

@@ -1394,11 +1394,13 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
 }
 
 // The exact residual sum (sequential double accumulation in match order, then one rounding to float: the value
-// RansacFilter.cpp:138 returns) for the hypotheses in the tie list.  grid = (ceil(hyp / 64), batch), one wave each.
-//   few ties : a wave per tied hypothesis; the 64 lanes evaluate 64 consecutive matches, park e in LDS, and the sum
-//              walks them in order (every lane computes the same total from broadcast reads);
+// RansacFilter.cpp:138 returns) for the hypotheses in the tie list.  grid = (kTieGrid, batch), one wave each, looping over
+// the list (normally one entry: a larger grid of workgroups that find nothing to do costs more than the work itself).
+//   few ties : a wave per tied hypothesis; the lanes evaluate all matches (64 at a time), park every e in LDS, and the
+//              sum then walks them in order (every lane computes the same total from broadcast reads);
 //   many ties: a lane per tied hypothesis walking all matches (the shape of ransac_score_kernel), 64 per wave.
 constexpr int kTieLaneMode = 192;
+constexpr int kTieGrid = 4;
 __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, const float *__restrict__ hypF,
@@ -1411,34 +1413,35 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
     const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
     const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
-    __shared__ __align__(16) float buf[64];
 
     if (T >= kTieLaneMode) {
-        if ((int)blockIdx.x * 64 >= T) return;
-        const int k = blockIdx.x * 64 + lane;
-        const int h = TI[min(k, T - 1)];
-        ResidualF R;
-        const float *src = hypF + ((size_t)b * hyp + h) * 9;
-#pragma unroll
-        for (int j = 0; j < 9; j++) R.f[j] = src[j];
-        residual_prepare(R);
         __shared__ float4 sc[64];
-        double total = 0;
-        for (int i0 = 0; i0 < m; i0 += 64) {   // 64 matches staged by the wave, then walked in order as broadcasts
-            const int2 pr = PR[min(i0 + lane, m - 1)];
-            const float2 a = P1[pr.x], c = P2[pr.y];
-            __syncthreads();
-            sc[lane] = make_float4(a.x, a.y, c.x, c.y);
-            __syncthreads();
-            const int cnt = min(64, m - i0);
-            for (int t = 0; t < cnt; t++) {
-                const float4 v = sc[t];
-                total += (double)residual_e(R, v, (double)v.z, (double)v.w);
+        for (int blk = blockIdx.x; blk * 64 < T; blk += gridDim.x) {
+            const int k = blk * 64 + lane;
+            const int h = TI[min(k, T - 1)];
+            ResidualF R;
+            const float *src = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+            for (int j = 0; j < 9; j++) R.f[j] = src[j];
+            residual_prepare(R);
+            double total = 0;
+            for (int i0 = 0; i0 < m; i0 += 64) {   // 64 matches staged by the wave, then walked in order as broadcasts
+                const int2 pr = PR[min(i0 + lane, m - 1)];
+                const float2 a = P1[pr.x], c = P2[pr.y];
+                __syncthreads();
+                sc[lane] = make_float4(a.x, a.y, c.x, c.y);
+                __syncthreads();
+                const int cnt = min(64, m - i0);
+                for (int t = 0; t < cnt; t++) {
+                    const float4 v = sc[t];
+                    total += (double)residual_e(R, v, (double)v.z, (double)v.w);
+                }
             }
+            if (k < T) hyp_sum[(size_t)b * hyp + h] = (float)total;
         }
-        if (k < T) hyp_sum[(size_t)b * hyp + h] = (float)total;
         return;
     }
+    extern __shared__ __align__(16) float s_e[];   // kp_stride floats: every e of the hypothesis, then summed in order
     for (int k = blockIdx.x; k < T; k += gridDim.x) {
         const int h = TI[k];
         ResidualF R;
@@ -1446,29 +1449,43 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
 #pragma unroll
         for (int j = 0; j < 9; j++) R.f[j] = src[j];
         residual_prepare(R);
-        double total = 0;
-        for (int i0 = 0; i0 < m; i0 += 64) {
-            const int i = i0 + lane;
-            float e = 0.f;
-            if (i < m) {
-                const int2 pr = PR[i];
-                const float2 a = P1[pr.x], c = P2[pr.y];
-                e = residual_e(R, make_float4(a.x, a.y, c.x, c.y), (double)c.x, (double)c.y);
+        __syncthreads();   // one wave: the previous hypothesis' reads are done
+        // every e first, four matches per lane and round so that their gathers are in flight together ...
+        for (int i0 = 0; i0 < m; i0 += 256) {
+            int2 pr[4];
+            float2 a[4], c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pr[u] = PR[min(i0 + u * 64 + lane, m - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = P1[pr[u].x];
+                c[u] = P2[pr[u].y];
             }
-            __syncthreads();   // one wave: orders this store after the previous round's reads
-            buf[lane] = e;
-            __syncthreads();
-            const int cnt = min(64, m - i0);
-            int t = 0;
-            for (; t + 4 <= cnt; t += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(buf + t);
-                total += (double)v.x;
-                total += (double)v.y;
-                total += (double)v.z;
-                total += (double)v.w;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 64 + lane;
+                const float e = residual_e(R, make_float4(a[u].x, a[u].y, c[u].x, c[u].y), (double)c[u].x, (double)c[u].y);
+                if (i < m) s_e[i] = e;
             }
-            for (; t < cnt; t++) total += (double)buf[t];
         }
+        __syncthreads();
+        // ... then the sum, in match order (every lane walks the same broadcast reads and computes the same total);
+        // sixteen values are fetched ahead of the dependent additions
+        double total = 0;
+        int t = 0;
+        for (; t + 16 <= m; t += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4 *>(s_e + t + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                total += (double)v[u].x;
+                total += (double)v[u].y;
+                total += (double)v[u].z;
+                total += (double)v[u].w;
+            }
+        }
+        for (; t < m; t++) total += (double)s_e[t];
         if (lane == 0) hyp_sum[(size_t)b * hyp + h] = (float)total;
     }
 }
@@ -1685,8 +1702,13 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         }
         {
             VsProfScope ps(ctx, "ransac_tiesum_kernel");
-            dim3 grid(vs_div_up(hyp, 64), batch);
-            ransac_tiesum_kernel<<<grid, 64, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, hypF, tie_idx, tie_n,
+            dim3 grid(min(kTieGrid, vs_div_up(hyp, 64)), batch);
+            if (sizeof(float) * (size_t)kp_stride > 40 * 1024 && !ctx->attr_done["ransac_tiesum"]) {
+                VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_tiesum_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * VSLAM_MAX_KP)));
+                ctx->attr_done["ransac_tiesum"] = true;
+            }
+            ransac_tiesum_kernel<<<grid, 64, sizeof(float) * (size_t)kp_stride, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, hypF, tie_idx, tie_n,
                                                               hyp_sum);
         }
     }
