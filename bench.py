@@ -48,7 +48,8 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
         "kdtree_build_kernel": 2 * (K * 8 + K * 4),
         "match_knn2_kernel": 2 * K * 32 + K * 4,
         "match_compact_kernel": K * 4 + K * 8,
-        "ransac_sets_kernel": H * 32,
+        "ransac_mt_kernel": 4 + H * 32,                # seed in, raw generator outputs out
+        "ransac_sets_kernel": 2 * H * 32,              # raw outputs in, sets out
         "ransac_solve_kernel": H * 32 + M * 24 + H * 36,
         "ransac_score_kernel": H * 36 + M * 24 + H * 8,
         "ransac_count_kernel": H * 36 + M * 24 + H * 4,

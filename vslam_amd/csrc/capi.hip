@@ -131,6 +131,7 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
         return VSLAM_ERR_HIP;
     }
     if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_raw, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return VSLAM_ERR_HIP;
@@ -160,6 +161,7 @@ int vslam_ctx_destroy(vslam_ctx *ctx) {
         (void)hipStreamDestroy(ctx->copy_stream);
     }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    if (ctx->ev_raw) (void)hipEventDestroy(ctx->ev_raw);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -534,9 +536,42 @@ int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_de
     if ((rc = vs_arena_get(ctx, "mf.mask", bk, (void **)&mask))) return rc;
 
     if ((rc = vs_launch_match(ctx, d_desc1, d_n1, d_desc2, d_n2, batch, kp_stride, pairs, m, nullptr))) return rc;
-    if ((rc = vs_launch_ransac_sets(ctx, d_seeds, m, batch, hyp, sets, draws))) return rc;
+    if (ctx->raw_seeds == d_seeds && ctx->raw_batch == batch && ctx->raw_hyp == hyp) {
+        // the raw generator outputs were produced ahead of time (vs_sets_prefetch): only the mapping is left
+        uint32_t *raw = nullptr;
+        if ((rc = vs_arena_get(ctx, "mf.raw", sizeof(uint32_t) * vs_ransac_raw_words(hyp) * (size_t)batch, (void **)&raw))) return rc;
+        ctx->raw_seeds = nullptr;
+        VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_raw, 0));
+        if ((rc = vs_launch_ransac_map(ctx, m, batch, hyp, raw, sets, draws))) return rc;
+    } else if ((rc = vs_launch_ransac_sets(ctx, d_seeds, m, batch, hyp, sets, draws))) {
+        return rc;
+    }
     return vs_launch_ransac(ctx, d_xy1, d_xy2, pairs, m, sets, batch, kp_stride, hyp, threshold, d_F, mask,
                             d_best, d_matches, hypF, hyp_count, hyp_sum);
+}
+
+// The mt19937 outputs RANSAC will draw its sets from depend on the seeds alone: generate them on the auxiliary stream
+// while the frames are being extracted.  vslam_match_features picks them up when called with the same (seeds, batch, hyp).
+static int vs_sets_prefetch(vslam_ctx *ctx, const uint32_t *d_seeds, int batch, int hyp) {
+    ctx->raw_seeds = nullptr;
+    if (!d_seeds || batch <= 0 || hyp <= 0) return VSLAM_OK;   // the entry point proper reports bad arguments
+    uint32_t *raw = nullptr;
+    int rc = vs_arena_get(ctx, "mf.raw", sizeof(uint32_t) * vs_ransac_raw_words(hyp) * (size_t)batch, (void **)&raw);
+    if (rc) return rc;
+    hipStream_t main_stream = ctx->stream;
+    if (!ctx->prof) {   // everything queued so far (the previous step's mapping kernel reads `raw`) comes first
+        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        ctx->stream = ctx->aux_stream;
+    }
+    rc = vs_launch_ransac_mt(ctx, d_seeds, batch, hyp, raw);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    VS_HIP(ctx, hipEventRecord(ctx->ev_raw, ctx->prof ? ctx->stream : ctx->aux_stream));
+    ctx->raw_seeds = d_seeds;
+    ctx->raw_batch = batch;
+    ctx->raw_hyp = hyp;
+    return VSLAM_OK;
 }
 
 // extract both frames of every pair, then match_features on (frame p, frame pairs + p)
@@ -551,7 +586,9 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     // auxiliary stream beside the matching stages (fork after extraction, join at the end).  With
     // per-kernel timing on, everything stays on one stream so the event brackets are clean.
     const bool overlap = d_nodes && !ctx->prof;
-    int rc = vslam_extract_features(ctx, d_bgr, 2 * pairs, width, height, row_stride, params, kp_stride,
+    int rc = vs_sets_prefetch(ctx, d_seeds, pairs, hyp);
+    if (rc) return rc;
+    rc = vslam_extract_features(ctx, d_bgr, 2 * pairs, width, height, row_stride, params, kp_stride,
                                     d_xy, d_desc, overlap ? nullptr : d_nodes, d_n, nullptr);
     if (rc) return rc;
     if (overlap) {
@@ -611,7 +648,9 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
     if (!ctx) return VSLAM_ERR_INVALID;
     VS_REQUIRE(ctx, frames >= 2, VSLAM_ERR_INVALID);
     const bool overlap = d_nodes && !ctx->prof;   // k-d trees beside the matching stages, as in vslam_frontend_pairs
-    int rc = vslam_extract_features(ctx, d_bgr, frames, width, height, row_stride, params, kp_stride, d_xy, d_desc,
+    int rc = vs_sets_prefetch(ctx, d_seeds, frames - 1, hyp);
+    if (rc) return rc;
+    rc = vslam_extract_features(ctx, d_bgr, frames, width, height, row_stride, params, kp_stride, d_xy, d_desc,
                                     overlap ? nullptr : d_nodes, d_n, nullptr);
     if (rc) return rc;
     if (overlap) {

@@ -33,6 +33,11 @@ struct vslam_ctx {
     // uploads (frame ingest) run on their own stream; ev_upload marks the last one enqueued
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_upload = nullptr;
+    // raw mt19937 outputs produced ahead of time on the auxiliary stream (vslam_frontend_pairs / _sequence): valid for
+    // exactly the (seeds, batch, hyp) recorded here until vslam_match_features consumes them
+    hipEvent_t ev_raw = nullptr;
+    const uint32_t *raw_seeds = nullptr;
+    int raw_batch = 0, raw_hyp = 0;
     int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, 1 fork after bgr2gray, 2 fork after min_eigen
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     int ransac_min_matches = VSLAM_SET_SIZE;   // VSLAM_OPT_RANSAC_MIN_MATCHES
@@ -123,6 +128,11 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
                     int32_t *knn);
 int vs_launch_ransac_sets(vslam_ctx *ctx, const uint32_t *seeds, const int32_t *m, int batch, int hyp,
                           int32_t *sets, uint32_t *draws);
+// the same sets in two steps: raw mt19937 outputs (seed only; can run ahead on another stream), then the mapping
+size_t vs_ransac_raw_words(int hyp);   // uint32 words of raw outputs per item
+int vs_launch_ransac_mt(vslam_ctx *ctx, const uint32_t *seeds, int batch, int hyp, uint32_t *raw);
+int vs_launch_ransac_map(vslam_ctx *ctx, const int32_t *m, int batch, int hyp, const uint32_t *raw, int32_t *sets,
+                         uint32_t *draws);
 int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
                      const int32_t *m, const int32_t *sets, int batch, int kp_stride, int hyp,
                      float threshold, float *F, uint8_t *mask, int32_t *best, int32_t *matches,

@@ -1,7 +1,7 @@
 // RANSAC fundamental-matrix loop for gfx950.
 //
 // Replaces RansacFilter (/root/reference/src/RansacFilter.cpp):
-//   initialize_sets              :6-34    -> ransac_sets_kernel   (mt19937 + Lemire, on device)
+//   initialize_sets              :6-34    -> ransac_mt_kernel + ransac_map_kernel (mt19937, then Lemire + draws, on device)
 //   compute_fundamental          :69-103  -> ransac_solve_kernel  (one lane per hypothesis)
 //   compute_fundamental_residual :105-140 -> ransac_score_kernel  (one lane per hypothesis,
 //                                            matches broadcast from LDS)
@@ -43,31 +43,21 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// One workgroup per frame pair.  The 624-word state lives in LDS; a block of 624 outputs is
-// produced in three dependency phases (i < 227 | 227 <= i < 454 | i >= 454), then mapped to
-// draws with libstdc++'s uniform_int_distribution<int>(0, size-1) for a 32-bit URBG:
-// Lemire multiply-shift with rejection (bits/uniform_int_dist.h _S_nd).  A rejection shifts
-// every later draw by one raw output, so each block is resolved left to right: evaluate all
-// lanes under the current shift, find the first rejected raw output, finalise everything
-// before it, bump the shift, repeat (almost always zero iterations: p(reject) ~ n / 2^32).
-__global__ __launch_bounds__(kSetThreads) void ransac_sets_kernel(const uint32_t *__restrict__ seeds,
-                                                                  const int32_t *__restrict__ m_arr,
-                                                                  int hyp, int32_t *__restrict__ sets,
-                                                                  uint32_t *__restrict__ draws) {
+// The draws come from two kernels.  The raw mt19937 outputs depend on the seed alone (ransac_mt_kernel: one workgroup per
+// frame pair, the 624-word state in LDS, a block of 624 outputs per three dependency phases i < 227 | 227 <= i < 454 |
+// i >= 454), so the batched front-end produces them on the auxiliary stream while the frames are still being extracted;
+// only the mapping to draws, which needs the match count, sits between the matcher and the solver (ransac_map_kernel).
+// A pair consumes hyp * 8 raw outputs plus one per Lemire rejection (p ~ n / 2^32 each, i.e. a handful per batch);
+// kMtSpare extra outputs are generated, and a pair that would need more raises bit 1 of the context's device error word
+// (vslam_ctx_synchronize reports VSLAM_ERR_CAPACITY) instead of reading past them.
+constexpr int kMtSpare = kMtN;
+static inline int vs_mt_blocks(int hyp) { return (hyp * VSLAM_SET_SIZE + kMtSpare + kMtN - 1) / kMtN; }
+
+__global__ __launch_bounds__(kSetThreads) void ransac_mt_kernel(const uint32_t *__restrict__ seeds, int nblk,
+                                                                uint32_t *__restrict__ raw) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = m_arr[b];
-    int32_t *S = sets + (size_t)b * hyp * VSLAM_SET_SIZE;
-    uint32_t *D = draws + (size_t)b * hyp * VSLAM_SET_SIZE;
-    const int total = hyp * VSLAM_SET_SIZE;
-    if (n < VSLAM_SET_SIZE) {   // reference: UB (distribution over (0,-1)); defined here as zeros
-        for (int i = tid; i < total; i += kSetThreads) S[i] = 0;
-        return;
-    }
-
+    uint32_t *R = raw + (size_t)b * nblk * kMtN;
     __shared__ uint32_t mt[kMtN];
-    __shared__ uint32_t out[kMtN];
-    __shared__ int s_first;
-
     if (tid == 0) {   // std::mt19937(seed) seeding recurrence
         uint32_t x = seeds[b];
         mt[0] = x;
@@ -77,80 +67,75 @@ __global__ __launch_bounds__(kSetThreads) void ransac_sets_kernel(const uint32_t
         }
     }
     __syncthreads();
-
-    int raw_base = 0;   // raw outputs consumed before this block
-    int rej = 0;        // rejections so far (identical in every lane)
-    while (raw_base - rej < total) {
-        // ---- twist: three phases, each read -> barrier -> write -> barrier
-        {
-            uint32_t v = 0;
-            if (tid < kMtN - kMtM) v = mt_twist(mt[tid], mt[tid + 1], mt[tid + kMtM]);
-            __syncthreads();
-            if (tid < kMtN - kMtM) mt[tid] = v;
-            __syncthreads();
-            const int i1 = tid + (kMtN - kMtM);   // 227 .. 453
-            if (tid < kMtN - kMtM) v = mt_twist(mt[i1], mt[i1 + 1], mt[i1 - (kMtN - kMtM)]);
-            __syncthreads();
-            if (tid < kMtN - kMtM) mt[i1] = v;
-            __syncthreads();
-            const int i2 = tid + 2 * (kMtN - kMtM);   // 454 .. 623
-            if (i2 < kMtN) v = mt_twist(mt[i2], mt[i2 == kMtN - 1 ? 0 : i2 + 1], mt[i2 - (kMtN - kMtM)]);
-            __syncthreads();
-            if (i2 < kMtN) mt[i2] = v;
-            __syncthreads();
-        }
-        for (int i = tid; i < kMtN; i += kSetThreads) out[i] = mt_temper(mt[i]);
+    for (int blk = 0; blk < nblk; blk++) {
+        uint32_t v = 0;
+        if (tid < kMtN - kMtM) v = mt_twist(mt[tid], mt[tid + 1], mt[tid + kMtM]);
         __syncthreads();
+        if (tid < kMtN - kMtM) mt[tid] = v;
+        __syncthreads();
+        const int i1 = tid + (kMtN - kMtM);   // 227 .. 453
+        if (tid < kMtN - kMtM) v = mt_twist(mt[i1], mt[i1 + 1], mt[i1 - (kMtN - kMtM)]);
+        __syncthreads();
+        if (tid < kMtN - kMtM) mt[i1] = v;
+        __syncthreads();
+        const int i2 = tid + 2 * (kMtN - kMtM);   // 454 .. 623
+        if (i2 < kMtN) v = mt_twist(mt[i2], mt[i2 == kMtN - 1 ? 0 : i2 + 1], mt[i2 - (kMtN - kMtM)]);
+        __syncthreads();
+        if (i2 < kMtN) mt[i2] = v;
+        __syncthreads();
+        for (int i = tid; i < kMtN; i += kSetThreads) R[(size_t)blk * kMtN + i] = mt_temper(mt[i]);
+    }
+}
 
-        // ---- map raw outputs to draws, resolving rejections in order
-        int lo = 0;
-        while (true) {
-            if (tid == 0) s_first = 0x7FFFFFFF;
-            __syncthreads();
-            uint32_t res[3];
-            bool live[3];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const int t = tid + r * kSetThreads;
-                live[r] = false;
-                res[r] = 0;
-                if (t < kMtN && t >= lo) {
-                    const int d = raw_base + t - rej;
-                    if (d < total) {
-                        const uint32_t range = (uint32_t)(n - (d & 7));
-                        const uint64_t prod = (uint64_t)out[t] * (uint64_t)range;
-                        const uint32_t low = (uint32_t)prod;
-                        bool rejected = false;
-                        if (low < range) {
-                            const uint32_t thr = (0u - range) % range;
-                            rejected = low < thr;
-                        }
-                        if (rejected) atomicMin(&s_first, t);
-                        live[r] = true;
-                        res[r] = (uint32_t)(prod >> 32);
-                    }
-                }
-            }
-            __syncthreads();
-            const int first = s_first;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const int t = tid + r * kSetThreads;
-                if (live[r] && t < first) D[raw_base + t - rej] = res[r];
-            }
-            if (first == 0x7FFFFFFF) break;
-            rej += 1;
-            lo = first + 1;
-            __syncthreads();
+// Mapping of the raw outputs to draws: libstdc++'s uniform_int_distribution<int>(0, size-1) for a 32-bit URBG is Lemire's
+// multiply-shift with rejection (bits/uniform_int_dist.h _S_nd); a rejected output is consumed and the same draw retries
+// with the next one, so a rejection shifts every later draw by one raw output.  With all outputs in memory every output
+// is mapped in parallel under the current count of rejections; the earliest rejected output (if any: p ~ n / 2^32 per
+// draw) finalises everything before it, bumps the count, and the pass repeats from there.  Usually one pass, a second
+// one for about one pair in a hundred.  Then draws -> indices without replacement: available[r] = available.back();
+// pop_back() (RansacFilter.cpp:26-31) tracked as a <= 8-entry sparse overlay on the identity array.
+constexpr int kMapThreads = 1024;
+__global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *__restrict__ m_arr, int hyp, int nblk,
+                                                                 const uint32_t *__restrict__ raw, int32_t *__restrict__ sets,
+                                                                 uint32_t *__restrict__ draws, int32_t *__restrict__ errflag) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = m_arr[b];
+    int32_t *S = sets + (size_t)b * hyp * VSLAM_SET_SIZE;
+    uint32_t *D = draws + (size_t)b * hyp * VSLAM_SET_SIZE;
+    const uint32_t *R = raw + (size_t)b * nblk * kMtN;
+    const int total = hyp * VSLAM_SET_SIZE, avail = nblk * kMtN;
+    if (n < VSLAM_SET_SIZE) {   // reference: UB (distribution over (0,-1)); defined here as zeros
+        for (int i = tid; i < total; i += kMapThreads) S[i] = 0;
+        return;
+    }
+    __shared__ int s_first;
+    int lo = 0, rej = 0;
+    while (true) {
+        if (tid == 0) s_first = 0x7FFFFFFF;
+        __syncthreads();
+        if (total + rej > avail) {   // more rejections than spare outputs: practically unreachable; reported, never read past
+            if (tid == 0) atomicOr(errflag, 2);
+            for (int d = lo - rej + tid; d < total; d += kMapThreads) D[d] = 0;
+            break;
         }
-        raw_base += kMtN;
+        for (int t = lo + tid; t < total + rej; t += kMapThreads) {
+            const int d = t - rej;
+            const uint32_t range = (uint32_t)(n - (d & 7));
+            const uint64_t prod = (uint64_t)R[t] * (uint64_t)range;
+            const uint32_t low = (uint32_t)prod;
+            if (low < range && low < (0u - range) % range) atomicMin(&s_first, t);   // rejected: consumed, yields no draw
+            else D[d] = (uint32_t)(prod >> 32);   // final if t lies before the first rejection, rewritten otherwise
+        }
+        __syncthreads();
+        const int first = s_first;
+        if (first == 0x7FFFFFFF) break;
+        rej += 1;
+        lo = first + 1;
         __syncthreads();
     }
     __syncthreads();
-
-    // ---- draws -> indices without replacement: available[r] = available.back(); pop_back()
-    // (RansacFilter.cpp:26-31) tracked as a <= 8-entry sparse overlay on the identity array.
-    for (int h = tid; h < hyp; h += kSetThreads) {
+    __threadfence_block();
+    for (int h = tid; h < hyp; h += kMapThreads) {
         int pos[VSLAM_SET_SIZE], val[VSLAM_SET_SIZE];
         int cnt = 0, size = n;
 #pragma unroll
@@ -1630,14 +1615,40 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
 
 }  // namespace
 
+size_t vs_ransac_raw_words(int hyp) { return (size_t)vs_mt_blocks(hyp) * kMtN; }
+
+int vs_launch_ransac_mt(vslam_ctx *ctx, const uint32_t *seeds, int batch, int hyp, uint32_t *raw) {
+    VS_REQUIRE(ctx, seeds && raw, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && hyp > 0, VSLAM_ERR_INVALID);
+    VsProfScope ps(ctx, "ransac_mt_kernel");
+    ransac_mt_kernel<<<batch, kSetThreads, 0, ctx->stream>>>(seeds, vs_mt_blocks(hyp), raw);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_ransac_map(vslam_ctx *ctx, const int32_t *m, int batch, int hyp, const uint32_t *raw, int32_t *sets,
+                         uint32_t *draws) {
+    VS_REQUIRE(ctx, m && raw && sets && draws, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && hyp > 0, VSLAM_ERR_INVALID);
+    int32_t *flag = nullptr;
+    int rc = vs_device_errflag(ctx, &flag);
+    if (rc) return rc;
+    VsProfScope ps(ctx, "ransac_sets_kernel");
+    ransac_map_kernel<<<batch, kMapThreads, 0, ctx->stream>>>(m, hyp, vs_mt_blocks(hyp), raw, sets, draws, flag);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
 int vs_launch_ransac_sets(vslam_ctx *ctx, const uint32_t *seeds, const int32_t *m, int batch, int hyp,
                           int32_t *sets, uint32_t *draws) {
     VS_REQUIRE(ctx, seeds && m && sets && draws, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, batch > 0 && hyp > 0, VSLAM_ERR_INVALID);
-    VsProfScope ps(ctx, "ransac_sets_kernel");
-    ransac_sets_kernel<<<batch, kSetThreads, 0, ctx->stream>>>(seeds, m, hyp, sets, draws);
-    VS_HIP(ctx, hipGetLastError());
-    return VSLAM_OK;
+    uint32_t *raw = nullptr;
+    int rc = vs_arena_get(ctx, "mf.raw", sizeof(uint32_t) * vs_ransac_raw_words(hyp) * (size_t)batch, (void **)&raw);
+    if (rc) return rc;
+    ctx->raw_seeds = nullptr;   // the buffer is being rewritten: whatever was produced ahead of time is gone
+    if ((rc = vs_launch_ransac_mt(ctx, seeds, batch, hyp, raw))) return rc;
+    return vs_launch_ransac_map(ctx, m, batch, hyp, raw, sets, draws);
 }
 
 int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *pairs,
