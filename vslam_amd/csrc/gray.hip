@@ -6,6 +6,8 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // cvtColor(BGR2GRAY), 8U: (b*3735 + g*19235 + r*9798 + 2^14) >> 15
 // ------------------------------------------------------------------------------------------
+constexpr int kGrayIter = 4;
+
 __device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) {
     return (b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15;
 }
@@ -15,21 +17,26 @@ __global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t *__restrict
                                                        int aligned) {
     const int f = blockIdx.y;
     const int qpr = (w + 3) >> 2;   // 4-pixel groups per row
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= qpr * h) return;
-    const int y = q / qpr, x = (q - y * qpr) * 4;
-    const uint8_t *src = bgr + ((size_t)f * h + y) * stride + 3 * x;
-    uint8_t *dst = gray + ((size_t)f * h + y) * w + x;
-    if (aligned && x + 3 < w) {
-        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
-        const uint32_t a = s4[0], b = s4[1], c = s4[2];   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-        const uint32_t g0 = gray_of(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
-        const uint32_t g1 = gray_of(a >> 24, b & 0xFF, (b >> 8) & 0xFF);
-        const uint32_t g2 = gray_of((b >> 16) & 0xFF, b >> 24, c & 0xFF);
-        const uint32_t g3 = gray_of((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24);
-        *reinterpret_cast<uint32_t *>(dst) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-    } else {
-        for (int i = 0; i < 4 && x + i < w; i++) dst[i] = (uint8_t)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+    // kGrayIter consecutive 256-group chunks per workgroup: a quarter of the workgroups to dispatch, and a lane's
+    // loads of all its chunks are in flight together
+#pragma unroll
+    for (int it = 0; it < kGrayIter; it++) {
+        const int q = (blockIdx.x * kGrayIter + it) * 256 + threadIdx.x;
+        if (q >= qpr * h) return;
+        const int y = q / qpr, x = (q - y * qpr) * 4;
+        const uint8_t *src = bgr + ((size_t)f * h + y) * stride + 3 * x;
+        uint8_t *dst = gray + ((size_t)f * h + y) * w + x;
+        if (aligned && x + 3 < w) {
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+            const uint32_t a = s4[0], b = s4[1], c = s4[2];   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+            const uint32_t g0 = gray_of(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
+            const uint32_t g1 = gray_of(a >> 24, b & 0xFF, (b >> 8) & 0xFF);
+            const uint32_t g2 = gray_of((b >> 16) & 0xFF, b >> 24, c & 0xFF);
+            const uint32_t g3 = gray_of((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24);
+            *reinterpret_cast<uint32_t *>(dst) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        } else {
+            for (int i = 0; i < 4 && x + i < w; i++) dst[i] = (uint8_t)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+        }
     }
 }
 
@@ -42,7 +49,7 @@ int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, in
     const int aligned = (stride % 4 == 0) && (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(bgr) & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && (((size_t)h * stride) % 4 == 0);
     VsProfScope ps(ctx, "bgr2gray_kernel");
-    dim3 grid(vs_div_up(((w + 3) / 4) * h, 256), frames);
+    dim3 grid(vs_div_up(((w + 3) / 4) * h, 256 * kGrayIter), frames);
     bgr2gray_kernel<<<grid, 256, 0, ctx->stream>>>(bgr, w, h, stride, gray, aligned);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
