@@ -196,6 +196,9 @@ def dry_run(args, rank, world):
     """VSLAM_BENCH_DRY=1: the launcher, process group, record gather and max-over-ranks timing with made-up
     records and NO kernels (no GPU needed) -- what tests/test_bench_launch.py runs on a CPU-only box.  The line it
     prints carries no measurement (value null, metric says so)."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)   # one line on stdout: see main()
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -223,13 +226,16 @@ def dry_run(args, rank, world):
     ok = torch.equal(F.view(torch.int32), F_all.view(torch.int32)) and torch.equal(best, best_all) and torch.equal(m, m_all)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if rank == 0:
-        print(json.dumps({"metric": "DRY RUN: launcher + record gather only, no kernels, not a measurement", "value": None,
-                          "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": None, "gather_ok": bool(flag.item()), "data": "synthetic",
-                          "config": {"workload": "dry", "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}, gloo all_gather of result records"}}))
+    line = json.dumps({"metric": "DRY RUN: launcher + record gather only, no kernels, not a measurement", "value": None,
+                       "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                       "ms_per_step": None, "gather_ok": bool(flag.item()), "data": "synthetic",
+                       "config": {"workload": "dry", "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}, gloo all_gather of result records"}})
     dist.barrier()
     dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (line + "\n").encode())
+    os.close(real_stdout)
     return 0 if flag.item() else 1
 
 
@@ -258,6 +264,13 @@ def main():
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if os.environ.get("VSLAM_BENCH_DRY"):
         sys.exit(dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))))
+
+    # The contract is ONE line on stdout.  RCCL prints a version banner there when its communicator comes up and gloo its
+    # connection notes, from C code: hand every such write to stderr by pointing fd 1 at it for the whole run, and write
+    # the result line to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -461,12 +474,14 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_pairs, seed)
         if args.cpu_all_cores_pairs > 0:
             result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, args.cpu_all_cores_pairs, seed)
-    if rank == 0:
-        print(json.dumps(result))
     if multi:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

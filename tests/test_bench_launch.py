@@ -34,3 +34,21 @@ def test_world_size_mismatch_is_an_error_not_an_assert():
     r = _run(2, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999",
                  "VSLAM_BENCH_DRY": ""})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_under_the_drivers_launcher_stdout_is_one_json_line():
+    """For N > 1 the driver starts the ranks itself (`python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N ...`).  Libraries write to stdout from C code while the process group comes up (gloo's connection notes
+    here, RCCL's version banner on the GPU box); none of that may reach stdout."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VSLAM_BENCH_DRY="1", VSLAM_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, r.stdout
