@@ -447,10 +447,11 @@ def main():
         av = arithmetic_view(top["kernel"], units_of(top["kernel"]), top["ms_per_launch"], full_batch)
         if av:
             result["roofline"]["arithmetic"] = av
-            result["roofline"]["note"] = ("VALU-bound by construction (SURVEY.md 8d): the compulsory bytes of this kernel are a "
-                                          "rounding error next to its arithmetic, so the HBM fraction is small by design; "
-                                          "`arithmetic` gives its algorithmic op rate against the FP32 vector peak and its issued "
-                                          "VALU instructions against the chip's issue rate")
+            why = ("a streaming stencil held by its exact f64 box sums and correctly rounded square roots, not by bandwidth"
+                   if top["kernel"] == "min_eigen_kernel" else
+                   "VALU-bound by construction (SURVEY.md 8d): its compulsory bytes are a rounding error next to its arithmetic")
+            result["roofline"]["note"] = (why + ", so the HBM fraction is small by design; `arithmetic` gives its algorithmic op rate "
+                                          "against the vector ALU peak and its issued VALU instructions against the chip's issue rate")
         if "match_knn2_kernel" in by_name:   # north_star names the match kernel: always report it
             mk = by_name["match_knn2_kernel"]
             result["roofline_match"] = {"kernel": "match_knn2_kernel", "bound": "hbm", "achieved": mk["alg_GBps"], "peak": HBM_PEAK_GBS,
