@@ -52,15 +52,16 @@ int vslam_ctx_wait(vslam_ctx *ctx);
 const char *vslam_last_error(vslam_ctx *ctx);
 const char *vslam_version(void);
 /* Context options.
- *   VSLAM_OPT_RANSAC_ALL_SUMS  0 (default): vslam_ransac_* compute the exact inlier count of every hypothesis and the
- *       residual sum only where find_fundamental can consult it — for the hypotheses whose count equals the pair's
- *       maximum (src/RansacFilter.cpp:59: the sum breaks ties at equal count, nothing else) and whose sum a
- *       certified bound does not already place below the winner's.  d_hyp_sum holds NaN for hypotheses below the
- *       maximum count and -inf for maximum-count hypotheses ruled out by the bound.  Winner, mask, F and matches
- *       are the reference's either way.
- *       1: the residual sum of EVERY hypothesis is computed as the reference does (:138) — what
- *       RansacFilter::compute_fundamental_residual and the per-hypothesis parity tests ask for; about 2x the
- *       scoring time.
+ *   VSLAM_OPT_RANSAC_ALL_SUMS  0 (default): vslam_ransac_* compute what find_fundamental's accept rule can observe
+ *       (src/RansacFilter.cpp:59: a hypothesis matters only if its inlier count is the pair's maximum, and its
+ *       residual sum only breaks ties among those).  Every hypothesis that reaches the maximum count is counted in
+ *       full and exactly; a hypothesis is abandoned as soon as it can no longer reach a count already verified for
+ *       the pair.  d_hyp_count holds the maximum for the hypotheses that reach it and -1 for all others; d_hyp_sum
+ *       holds the exact sum where it can still decide the winner, -inf for maximum-count hypotheses a certified bound
+ *       places below the winner's, NaN below the maximum count.  Winner, mask, F and matches are the reference's
+ *       either way.
+ *       1: the count and the residual sum of EVERY hypothesis are computed as the reference does (:105-140) — what
+ *       the per-hypothesis parity tests ask for; about 3x the scoring time.
  *   VSLAM_OPT_RANSAC_MIN_MATCHES  8 (default) .. 1: vslam_ransac_evaluate skips items with fewer matches than this
  *       (no model: winner -1).  find_fundamental needs 8 to draw a set (src/RansacFilter.cpp:24), but
  *       compute_fundamental_residual scores a GIVEN F on any number of matches (:105-140): its adapter sets 1.
@@ -129,8 +130,8 @@ int vslam_ransac_sets(vslam_ctx *ctx, const uint32_t *d_seeds, const int32_t *d_
  *          d_mask [batch][kp_stride] u8, d_best [batch][4] int32 = winner, count, bits(sum), n_out,
  *          d_matches [batch][kp_stride][2] int32 compacted inlier matches (n_out of them).
  * Workspaces: d_hypF [batch][hyp][9] f32, d_hyp_count [batch][hyp] int32, d_hyp_sum [batch][hyp] f32
- * (also the per-hypothesis outputs the parity tests read: every F and every count always; every
- * sum with VSLAM_OPT_RANSAC_ALL_SUMS, otherwise the sums of the maximum-count hypotheses).   */
+ * (also the per-hypothesis outputs the parity tests read: every F always; every count and sum
+ * with VSLAM_OPT_RANSAC_ALL_SUMS, otherwise those of the maximum-count hypotheses, see above). */
 int vslam_ransac_fundamental(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2,
                              const int32_t *d_pairs, const int32_t *d_m, const int32_t *d_sets,
                              int batch, int kp_stride, int hyp, float threshold, float *d_F,

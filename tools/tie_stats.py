@@ -22,6 +22,7 @@ xy, desc, n = ex["xy"], ex["desc"], ex["n"]
 pairs, m = ctx.match_knn2_ratio(desc[:P].contiguous(), n[:P].contiguous(), desc[P:].contiguous(), n[P:].contiguous())
 seeds = torch.from_numpy(shard.pair_seeds(seed, 0, P).view(np.int32)).to(dev)
 sets = ctx.ransac_sets(seeds, m, H)
+ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, True)     # every count, not only the maximal ones
 out = ctx.ransac_fundamental(xy[:P].contiguous(), xy[P:].contiguous(), pairs, m, sets, 10.0)
 ctx.synchronize()
 cnt = out["hyp_count"].cpu().numpy()
@@ -37,6 +38,26 @@ r = np.array(rows)
 print("mean", r.mean(0).round(1), "max tied", r[:, 2].max())
 
 # how many of the tied hypotheses survive the bound-based pruning (hyp_sum is -inf for the pruned ones)
-hs = out["hyp_sum"].cpu().numpy()
+ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
+hs = ctx.ransac_fundamental(xy[:P].contiguous(), xy[P:].contiguous(), pairs, m, sets, 10.0)["hyp_sum"].cpu().numpy()
+ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, True)
 kept = [(int(((cnt[p] == cnt[p].max()) & ~np.isneginf(hs[p])).sum())) for p in range(P)]
 print("candidates kept per pair:", kept, "mean", float(np.mean(kept)), "max", max(kept))
+
+# --- would early bail-out pay?  Score every hypothesis on the first 512 matches only, then see how many could be
+# dropped because even with all remaining matches as inliers they cannot reach the pair's best full count.
+m512 = torch.clamp(m, max=512)
+out512 = ctx.ransac_fundamental(xy[:P].contiguous(), xy[P:].contiguous(), pairs, m512, sets, 10.0)
+ctx.synchronize()
+c512 = out512["hyp_count"].cpu().numpy()
+drop, work = [], []
+for p in range(P):
+    full, part, M = cnt[p], c512[p], int(mm[p])
+    best = full.max()
+    can_reach = part + (M - min(M, 512)) >= best
+    drop.append(1.0 - can_reach.mean())
+    work.append((min(M, 512) + can_reach.mean() * (M - min(M, 512))) / M)
+print("hypotheses droppable after 512 matches: mean %.3f (min %.3f max %.3f); evaluations left: mean %.3f of all" %
+      (np.mean(drop), np.min(drop), np.max(drop), np.mean(work)))
+q = np.array([np.quantile(cnt[p] / mm[p], [0.1, 0.25, 0.5, 0.75]) for p in range(P)])
+print("inlier ratio quantiles over hypotheses (10/25/50/75 %), mean over pairs:", q.mean(0).round(3))

@@ -979,9 +979,10 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
 // find_fundamental consults a hypothesis' residual SUM only to break ties among hypotheses whose inlier COUNT
 // equals the running maximum (RansacFilter.cpp:59); every other sum is computed by the reference and thrown away.
 // So the scoring is split:
-//   ransac_count_kernel   exact inlier count of every hypothesis, from a cheap evaluation of e with a certified
-//                         error band; the few evaluations that land inside the band are re-done with the exact
-//                         sequence (residual_e) -> the counts are the reference's counts, bit for bit;
+//   ransac_count_kernel   exact inlier count of every hypothesis that can matter (those reaching the pair's maximum
+//                         count are always counted in full), from a cheap evaluation of e with a certified error
+//                         band; the few evaluations that land inside the band are re-done with the exact sequence
+//                         (residual_e) -> these counts are the reference's counts, bit for bit;
 //   ransac_ties_kernel    C* = max count per pair; of the hypotheses that reach it, those whose sum can still be
 //                         the largest after rounding (the count kernel's cheap sums bound every exact sum);
 //   ransac_tiesum_kernel  the exact, index-ordered double sum (cv::sum, :138) for those hypotheses only;
@@ -1008,6 +1009,12 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
 // data the band is about 0.3 % of thr wide (beta is a few 1e-3: f32 cancellation in t~), i.e. about one evaluation
 // in a thousand, so uncertain evaluations are not handled in place (a wave would leave the fast path for 6 % of its
 // evaluations) but queued per wave in LDS as (hypothesis, match) words and evaluated 64 at a time with full lanes.
+//
+// Bail-out: a hypothesis matters to the accept rule only if its count is the pair's maximum, so a wave stops working
+// on a hypothesis once the matches it has looked at contain more certain outliers than ANY maximum-count hypothesis
+// can have: potential inliers seen + all matches not seen < a count some hypothesis of the pair verifiably reaches.
+// Such hypotheses report -1 (ransac_ties_kernel then writes -1 for every hypothesis below the maximum, so the array
+// does not depend on timing).  On the bench data 60 % of the (hypothesis, wave) units stop after their first 256 matches.
 //
 // Mapping: one workgroup = 64 hypotheses x all matches of a pair; a wave owns up to 1024 matches, 16 per lane, held
 // in registers for the 64 hypotheses; the hypothesis' record (F, lo, hi) is a broadcast read from LDS;
@@ -1108,7 +1115,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // one 256-match sub-block (4 evaluations per lane) of hypothesis hh: certified count into cnt, the rest queued
 template <bool PARTIAL>
 __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &T, int s, int idx0, int hh, int lane, int m, int &cnt,
-                                              volatile uint32_t *q, int &qn, v2f &acc, int *s_unk) {
+                                              volatile uint32_t *q, int &qn, v2f &acc, int *s_unk, int &pot) {
     unsigned long long u0, u1, u2, u3;
     int c = 0;
     float ddmin = INFINITY;
@@ -1124,7 +1131,9 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &
         u3 = __builtin_amdgcn_sicmp(idx0 + 192 + lane, m, 40);
     }
     cnt += c;
+    pot += c;   // inliers this sub-block can still turn out to have: the certain ones plus the undecided ones
     if ((u0 | u1 | u2 | u3) != 0ull) {
+        pot += __popcll(u0) + __popcll(u1) + __popcll(u2) + __popcll(u3);
         if (u0) cnt_push(q, qn, u0, hh, idx0, lane);
         if (u1) cnt_push(q, qn, u1, hh, idx0 + 64, lane);
         if (u2) cnt_push(q, qn, u2, hh, idx0 + 128, lane);
@@ -1150,6 +1159,7 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     __shared__ float s_cmax[2 * kCntMaxWaves];
     __shared__ float s_part[kCntMaxWaves * kCntHyps];   // per wave and hypothesis: sum of the cheap values
     __shared__ int s_unk[kCntHyps];                     // hypothesis whose cheap sum is not certified
+    __shared__ int s_drop[kCntHyps];                    // hypothesis abandoned: it cannot reach the best count known
     extern __shared__ uint32_t s_queue[];   // kCntQueue words per wave
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
     const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
@@ -1196,6 +1206,7 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     if (tid < kCntHyps) {
         s_cnt[tid] = 0;
         s_unk[tid] = 0;
+        s_drop[tid] = 0;
         for (int w = 0; w < nw; w++) s_part[w * kCntHyps + tid] = 0.f;
     }
     __syncthreads();
@@ -1244,6 +1255,7 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     if (nsub > 0) {
         volatile uint32_t *q = s_queue + wave * kCntQueue;
         int qn = 0;
+        int bound = 0;   // a count some hypothesis of this pair is known to reach (never above the true maximum)
         for (int hh = 0; hh < nh; hh++) {
             CntRec R;
             {
@@ -1257,18 +1269,40 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
                 R.lo = v4.z;
                 R.hi = v4.w;
             }
-            int cnt = 0;
+            const int peek = hh >= 2 ? *(const volatile int *)&s_cnt[hh - 2] : 0;
+            int cnt = 0, pot = 0, seen = 0;
+            bool dropped = false;
             v2f acc;
             acc.x = 0.f;
             acc.y = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                if (s < nfull)
-                    cnt_sub_block<false>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk);
-                else if (s == nfull && part)
-                    cnt_sub_block<true>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk);
+                if (!dropped) {
+                    if (s < nfull) {
+                        cnt_sub_block<false>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
+                        seen += 256;
+                    } else if (s == nfull && part) {
+                        cnt_sub_block<true>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
+                        seen += m & 255;
+                    }
+                    // Bail-out.  Even if every match this wave has not looked at yet (the rest of its tile and all of
+                    // the other waves') were an inlier, the hypothesis would stay below a count some hypothesis of this
+                    // pair is already known to reach: it cannot be a maximum-count hypothesis, which is all the accept
+                    // rule looks at.  `bound` never exceeds the true maximum, so every hypothesis that reaches the
+                    // maximum is counted in full.
+                    dropped = pot + (m - seen) < bound;
+                }
             }
-            if (lane == 0 && cnt) atomicAdd(&s_cnt[hh], cnt);
+            if (lane == 0) {
+                if (dropped) s_drop[hh] = 1;
+                else if (cnt) atomicAdd(&s_cnt[hh], cnt);
+            }
+            // What the bound learns from: the verified inliers of the hypothesis two back (all waves of the workgroup have
+            // normally added their part by now; the read was issued at the top of the iteration, so nothing waits for it
+            // here, and a value that is late or partial is only a smaller lower bound).  Exchanging bounds between the
+            // pair's workgroups through memory was tried and cost more than the whole kernel (agent-scope loads under
+            // load); after two or three of its 64 hypotheses a workgroup's own bound is nearly as good.
+            bound = max(bound, __builtin_amdgcn_readfirstlane(peek));
             const float part_sum = wave_sum_to_lane63(acc.x + acc.y);
             if (lane == 63) s_part[wave * kCntHyps + hh] = part_sum;
             while (qn >= 64) {   // a hypothesis adds at most 1024 words to the 63 left over: kCntQueue holds them
@@ -1280,7 +1314,7 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     }
     __syncthreads();
     if (tid < nh) {
-        hyp_count[(size_t)b * hyp + hbase + tid] = s_cnt[tid];
+        hyp_count[(size_t)b * hyp + hbase + tid] = s_drop[tid] ? -1 : s_cnt[tid];   // ransac_ties keeps the maximal ones
         hyp_sum[(size_t)b * hyp + hbase + tid] = __int_as_float(0x7FC00000);   // defined by ransac_ties / tiesum where it matters
         // The cheap values' sum S~ and a bound on |S~ - (exact double sum of the e)|: per evaluation
         // |g - e| <= 12 u max(g, e) + beta (2 sqrt(g) + beta)  (the derivation above), summed with Cauchy-Schwarz
@@ -1307,7 +1341,7 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
 // tie_n[2b] = list length, tie_n[2b+1] = C*.  One workgroup per pair.
 constexpr int kTieThreads = 256;
 __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t *__restrict__ m_arr, int min_m, int hyp,
-                                                                  const int32_t *__restrict__ hyp_count,
+                                                                  int32_t *__restrict__ hyp_count,
                                                                   const float *__restrict__ approx, float *__restrict__ hyp_sum,
                                                                   int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1321,7 +1355,7 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
         }
         return;
     }
-    const int32_t *C = hyp_count + (size_t)b * hyp;
+    int32_t *C = hyp_count + (size_t)b * hyp;
     const float2 *A = reinterpret_cast<const float2 *>(approx) + (size_t)b * hyp;
     float *Sm = hyp_sum + (size_t)b * hyp;
     int32_t *TI = tie_idx + (size_t)b * hyp;
@@ -1353,6 +1387,9 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
     for (int i0 = 0; i0 < hyp; i0 += kTieThreads) {
         const int i = i0 + tid;
         bool keep = false;
+        // which hypotheses below the maximum were counted in full depends on when the counting kernel learned its
+        // bounds: the array is made canonical (and says so) — the maximum for those that reach it, -1 for the rest
+        if (i < hyp && C[i] != mx) C[i] = -1;
         if (i < hyp && C[i] == mx) {
             const float2 a = A[i];
             keep = !(a.x + a.y < cut);   // NaN or inf bounds stay
@@ -1522,8 +1559,8 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
         const int32_t *C = hyp_count + (size_t)b * hyp;
         const float *Sm = hyp_sum + (size_t)b * hyp;
         unsigned long long k = 0;
-        for (int i = tid; i < hyp; i += kSelThreads)
-            k = max(k, ((unsigned long long)(uint32_t)C[i] << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i));
+        for (int i = tid; i < hyp; i += kSelThreads)   // -1 = "below the maximum" (the counting path's canonical form): never the key
+            k = max(k, ((unsigned long long)(uint32_t)max(C[i], 0) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i));
         k = wave_max_u64(k);
         if (lane == 0) s_key[wave] = k;
         __syncthreads();
