@@ -15,6 +15,8 @@
 // checks that identity exhaustively).
 #include "ctx.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -139,6 +141,190 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
         match_knn2_body<2>(q4, t4, nq, nt, qbase, tile, sel_b, knn_b);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same knn-2 on the matrix cores (the default).  For 0/1 vectors a, b of 256 bits, Hamming(a, b) = |a| + |b| - 2 a.b,
+// and a.b over 256 positions is an int8 dot product: v_mfma_i32_32x32x32_i8 forms 32 x 32 of them per instruction at
+// 16 times the rate the vector ALUs can xor and popcount.  Everything stays integer, so the distances — and with the
+// same packed-key min-2 the indices and the tie order — are exactly those of the popcount kernel above.
+//   workgroup = 256 query rows of one pair (64 per wave: two 32-row operand tiles, expanded once to one byte per bit and
+//   kept in registers); the train rows come by in tiles of 32: the workgroup expands a tile's packed descriptors to
+//   bytes in LDS (double buffered) together with their popcounts, every wave reads it as the B operand;
+//   per tile and wave 16 MFMAs (2 row tiles x 8 k-steps of 32 bits), then 4 VALU ops per result for the running two
+//   smallest keys ((|b| - 2 a.b + 512) << 16 | train index; |a| is the same for a row and is added at the end);
+//   at the end the 32 lanes that hold different columns of a row merge their two-smallest pairs.
+// Operand layout (checked on the device with tools/mfma_probe.hip): A lane l = row l & 31, B lane l = column l & 31,
+// both carrying the 16 k-positions 16 (l >> 5) .. + 15 of the step in their 16 bytes (any order works as long as A and
+// B agree: they are built by the same bit -> byte spread); D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) +
+// 4 (lane >> 5).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int kMQ = 256;         // query rows per workgroup
+constexpr int kMT = 32;          // train rows per tile
+constexpr int kMStride = 272;    // bytes per expanded train row in LDS: 256 + 16, so 16 consecutive rows cover all banks
+constexpr uint32_t kMBias = 512; // keeps |b| - 2 a.b positive
+constexpr uint32_t kMPad = 0x4000;   // "|b|" of a train row beyond nt: never among the two smallest of a real row
+
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) {   // 4 bits -> 4 bytes holding 0 / 1
+    return (nib * 0x00204081u) & 0x01010101u;
+}
+__device__ __forceinline__ v4i spread16(uint32_t bits) {      // 16 bits -> 16 bytes
+    v4i r;
+    r.x = (int)spread4(bits & 0xFu);
+    r.y = (int)spread4((bits >> 4) & 0xFu);
+    r.z = (int)spread4((bits >> 8) & 0xFu);
+    r.w = (int)spread4((bits >> 12) & 0xFu);
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// base - (dot << 17) in one instruction (dot <= 256 and -2^17 both fit the 24-bit operands)
+__device__ __forceinline__ uint32_t mad24(int dot, int base) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(dot), "v"(-(1 << 17)), "v"(base));
+    return (uint32_t)r;
+}
+// (smallest, second smallest) of this lane's pair and the pair of the lane a DPP pattern points at
+template <int CTRL>
+__device__ __forceinline__ void merge2(uint32_t &x1, uint32_t &x2) {
+    const uint32_t o1 = dpp_u32<CTRL>(x1), o2 = dpp_u32<CTRL>(x2);
+    const uint32_t lo = min(x1, o1), hi = max(x1, o1);
+    x2 = min(hi, min(x2, o2));
+    x1 = lo;
+}
+
+__global__ __launch_bounds__(kThreads) void match_knn2_mfma_kernel(
+    const uint8_t *__restrict__ desc1, const int32_t *__restrict__ n1, const uint8_t *__restrict__ desc2,
+    const int32_t *__restrict__ n2, int kp_stride, int32_t *__restrict__ sel, int32_t *__restrict__ knn) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = n1[b], nt = n2[b];
+    const int qbase = blockIdx.x * kMQ;
+    if (qbase >= nq) return;   // uniform for the whole workgroup
+
+    __shared__ __align__(16) uint8_t s_b[2][kMT * kMStride];
+    __shared__ uint32_t s_pb[2][kMT];
+    const uint32_t *q32 = reinterpret_cast<const uint32_t *>(desc1 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
+    const uint32_t *t32 = reinterpret_cast<const uint32_t *>(desc2 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
+    int32_t *sel_b = sel + (size_t)b * kp_stride;
+    int4 *knn_b = knn ? reinterpret_cast<int4 *>(knn) + (size_t)b * kp_stride : nullptr;
+
+    const int r = lane & 31, half = lane >> 5;
+    // A operands: this lane's row of each of the wave's two 32-row tiles, bits 16 half .. + 15 of every dword
+    v4i a[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+        const int q = min(qbase + wave * 64 + rt * 32 + r, nq - 1);   // rows past the end repeat the last one (never written)
+        const uint4 lo = reinterpret_cast<const uint4 *>(q32)[2 * q], hi = reinterpret_cast<const uint4 *>(q32)[2 * q + 1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) a[rt][ks] = spread16((w[ks] >> (16 * half)) & 0xFFFFu);
+    }
+    uint32_t k1[2][16], k2[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            k1[rt][g] = 0xFFFFFFFFu;
+            k2[rt][g] = 0xFFFFFFFFu;
+        }
+
+    // Staging of train tiles: thread t owns dword t & 7 of row t >> 3 of every tile (one coalesced KiB per tile).  The
+    // dword of tile i + 2 is requested while tile i is being multiplied and tile i + 1 (already in a register) is being
+    // expanded into the other LDS buffer, so no wave ever waits for global memory inside the loop.
+    const int srow = tid >> 3, sd = tid & 7;
+    auto fetch = [&](int tile) -> uint32_t {
+        const int t = tile * kMT + srow;
+        return t < nt ? t32[(size_t)t * 8 + sd] : 0u;
+    };
+    auto expand = [&](uint32_t wv, int tile, int buf) {
+        uint8_t *dst = &s_b[buf][srow * kMStride + sd * 32];
+        *reinterpret_cast<v4i *>(dst) = spread16(wv & 0xFFFFu);
+        *reinterpret_cast<v4i *>(dst + 16) = spread16(wv >> 16);
+        uint32_t pc = (uint32_t)__popc(wv);     // |b|: sum over the row's 8 dwords = 8 neighbouring lanes
+        pc += dpp_u32<0xB1>(pc);                // quad_perm [1,0,3,2]
+        pc += dpp_u32<0x4E>(pc);                // quad_perm [2,3,0,1]
+        pc += dpp_u32<0x141>(pc);               // row_half_mirror: the other quad of the 8
+        if (sd == 0) s_pb[buf][srow] = tile * kMT + srow < nt ? pc : kMPad;
+    };
+
+    const int ntiles = (nt + kMT - 1) / kMT;
+    if (ntiles > 0) expand(fetch(0), 0, 0);
+    uint32_t w_next = ntiles > 1 ? fetch(1) : 0u;
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) expand(w_next, tile + 1, buf ^ 1);   // the other buffer was last read two barriers ago
+        if (tile + 2 < ntiles) w_next = fetch(tile + 2);
+        v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        const uint8_t *src = &s_b[buf][r * kMStride + 16 * half];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const v4i bv = *reinterpret_cast<const v4i *>(src + 32 * ks);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][ks], bv, acc1, 0, 0, 0);
+        }
+        // key = (|b| + bias - 2 a.b) << 16 | train index = base - (a.b << 17): one multiply-add per result
+        const int base = (int)(((s_pb[buf][r] + kMBias) << 16) | (uint32_t)(tile * kMT + r));
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const uint32_t key0 = mad24(acc0[g], base);
+            k2[0][g] = med3_u32(k1[0][g], k2[0][g], key0);
+            k1[0][g] = min(k1[0][g], key0);
+            const uint32_t key1 = mad24(acc1[g], base);
+            k2[1][g] = med3_u32(k1[1][g], k2[1][g], key1);
+            k1[1][g] = min(k1[1][g], key1);
+        }
+        __syncthreads();
+    }
+
+    // the 32 lanes of a half hold different columns of the same rows: merge their (smallest, second smallest)
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            uint32_t x1 = k1[rt][g], x2 = k2[rt][g];
+            merge2<0xB1>(x1, x2);    // quad_perm [1,0,3,2]
+            merge2<0x4E>(x1, x2);    // quad_perm [2,3,0,1]
+            merge2<0x141>(x1, x2);   // row_half_mirror: the other quad of the 8
+            merge2<0x140>(x1, x2);   // row_mirror: the other 8 of the 16
+            {                        // the other 16 of the 32: across DPP rows, through the LDS crossbar
+                const uint32_t o1 = __shfl_xor(x1, 16, 64), o2 = __shfl_xor(x2, 16, 64);
+                const uint32_t lo = min(x1, o1), hi = max(x1, o1);
+                x2 = min(hi, min(x2, o2));
+                x1 = lo;
+            }
+            k1[rt][g] = x1;
+            k2[rt][g] = x2;
+        }
+    // lane (g, half) of each row tile writes row (g & 3) + 8 (g >> 2) + 4 half
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            if (r != g) continue;
+            const int q = qbase + wave * 64 + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
+            if (q >= nq) continue;
+            const uint4 lo = reinterpret_cast<const uint4 *>(q32)[2 * q], hi = reinterpret_cast<const uint4 *>(q32)[2 * q + 1];
+            const int pa = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) +
+                           __popc(hi.w);
+            const int d0 = (int)(k1[rt][g] >> 16) - (int)kMBias + pa, i0 = (int)(k1[rt][g] & 0xFFFFu);
+            const int d1 = (int)(k2[rt][g] >> 16) - (int)kMBias + pa, i1 = (int)(k2[rt][g] & 0xFFFFu);
+            const bool pass = (nt >= 2) && (10 * d0 < 7 * d1);
+            sel_b[q] = pass ? i0 : -1;
+            if (knn_b) {
+                int4 o;
+                o.x = nt >= 1 ? i0 : -1;
+                o.y = nt >= 1 ? d0 : 0x7FFFFFFF;
+                o.z = nt >= 2 ? i1 : -1;
+                o.w = nt >= 2 ? d1 : 0x7FFFFFFF;
+                knn_b[q] = o;
+            }
+        }
+}
+
 // Ordered compaction of the ratio-test survivors into (queryIdx, trainIdx) pairs, query order
 // (the reference's i_matches.push_back loop, src/Frame.cpp:89-94).  One workgroup per pair.
 __global__ __launch_bounds__(kThreads) void match_compact_kernel(const int32_t *__restrict__ sel,
@@ -191,10 +377,16 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
     int32_t *sel = nullptr;
     int rc = vs_arena_get(ctx, "match.sel", sizeof(int32_t) * (size_t)batch * kp_stride, (void **)&sel);
     if (rc) return rc;
+    static const bool popcount_path = getenv("VSLAM_MATCH_POPCOUNT") != nullptr;   // the vector-ALU kernel, for A/B timing
     {
         VsProfScope ps(ctx, "match_knn2_kernel");
-        dim3 grid(vs_div_up(kp_stride, kThreads * kQueriesPerLane), batch);
-        match_knn2_kernel<<<grid, kThreads, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
+        if (popcount_path) {
+            dim3 grid(vs_div_up(kp_stride, kThreads * kQueriesPerLane), batch);
+            match_knn2_kernel<<<grid, kThreads, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
+        } else {
+            dim3 grid(vs_div_up(kp_stride, kMQ), batch);
+            match_knn2_mfma_kernel<<<grid, kThreads, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
+        }
     }
     {
         VsProfScope ps(ctx, "match_compact_kernel");
