@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
 // v_cmp writes lane masks to SGPRs, counting is s_bcnt1 on the scalar unit (north_star: ballot / popcount).
 constexpr int kCntHyps = 64;
 constexpr int kCntMaxWaves = VSLAM_MAX_KP / 1024;
-constexpr int kCntLock = 8;        // hypotheses every wave of a workgroup visits first, together (2: 0.87 ms, 4: 0.82, 8: 0.80, 16: 0.81)
+constexpr int kCntLock = 2;        // hypotheses every wave of a workgroup visits first, together
 constexpr int kCntQueue = 1088;   // words per wave: 16 evaluations x 64 lanes of one hypothesis + 63 carried over
 constexpr float kCntTinyDD = 0x1p-120f;
 // A hypothesis as the counting loop reads it from LDS: every element of F twice (so a register pair is the
@@ -1142,11 +1142,51 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &
     }
 }
 
+// A first lower bound on the pair's maximum count, so that the counting kernel can abandon hopeless hypotheses from its
+// very first one: the exact inlier counts of kPilotHyps hypotheses spread over the list (a wave each, lanes over the
+// matches), maximum kept in cbound[pair].  Any count of any hypothesis is a valid bound; a better one only prunes more.
+constexpr int kPilotHyps = 8;   // 8 .. 64 pilots and 0 .. 2 lock-step hypotheses all land within 1 % of each other
+__global__ __launch_bounds__(64) void ransac_pilot_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
+    int32_t *__restrict__ cbound) {
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int m = min(m_arr[b], kp_stride);
+    if (m < min_m) return;
+    const int h = (int)(((long long)hyp * blockIdx.x) / gridDim.x);
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    ResidualF R;
+    const float *src = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+    for (int j = 0; j < 9; j++) R.f[j] = src[j];
+    residual_prepare(R);
+    int count = 0;
+    for (int i0 = 0; i0 < m; i0 += 256) {   // four matches per lane and round: their gathers are in flight together
+        int2 pr[4];
+        float2 a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pr[u] = PR[min(i0 + u * 64 + lane, m - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] = P1[pr[u].x];
+            c[u] = P2[pr[u].y];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float e = residual_e(R, make_float4(a[u].x, a[u].y, c[u].x, c[u].y), (double)c[u].x, (double)c[u].y);
+            count += __popcll(__ballot(i0 + u * 64 + lane < m && e <= threshold));
+        }
+    }
+    if (lane == 0) atomicMax(&cbound[b], count);
+}
+
 // grid = (ceil(hyp / 64), batch), block = 64 * ceil(kp_stride / 1024) threads
 __global__ __launch_bounds__(1024) void ransac_count_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
-    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx) {
+    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx, const int32_t *__restrict__ cbound) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler may know it
     const int nw = (int)(blockDim.x >> 6);
@@ -1256,9 +1296,9 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
     if (nsub > 0) {
         volatile uint32_t *q = s_queue + wave * kCntQueue;
         int qn = 0;
-        int bound = 0;   // a count some hypothesis of this pair is known to reach (never above the true maximum)
-        // Visiting order.  The first kCntLock hypotheses are visited by all waves together: their full counts set the
-        // bound early.  After that wave w starts a w-th of the way round the rest, so that for almost every hypothesis
+        int bound = cbound[b];   // a count some hypothesis of this pair is known to reach (never above the true maximum): ransac_pilot_kernel's to begin with
+        // Visiting order.  The first kCntLock hypotheses are visited by all waves together (their full counts tighten
+        // the pilot's bound).  After that wave w starts a w-th of the way round the rest, so that for almost every hypothesis
         // one wave gets there long before the others: if it abandons the hypothesis (s_drop), the others never start it.
         const int lock = nh > 2 * kCntLock ? kCntLock : nh;
         const int ring = nh - lock;
@@ -1751,6 +1791,14 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         if ((rc = vs_arena_get(ctx, "ransac.approx", sizeof(float) * 2 * (size_t)batch * hyp, (void **)&approx))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.tie_idx", sizeof(int32_t) * (size_t)batch * hyp, (void **)&tie_idx))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.tie_n", sizeof(int32_t) * 2 * (size_t)batch, (void **)&tie_n))) return rc;
+        int32_t *cbound = nullptr;
+        if ((rc = vs_arena_get(ctx, "ransac.cbound", sizeof(int32_t) * (size_t)batch, (void **)&cbound))) return rc;
+        VS_HIP(ctx, hipMemsetAsync(cbound, 0, sizeof(int32_t) * (size_t)batch, ctx->stream));
+        {
+            VsProfScope ps(ctx, "ransac_pilot_kernel");
+            dim3 grid(min(kPilotHyps, hyp), batch);
+            ransac_pilot_kernel<<<grid, 64, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, threshold, hypF, cbound);
+        }
         {
             VsProfScope ps(ctx, "ransac_count_kernel");
             const int waves = min(kCntMaxWaves, vs_div_up(kp_stride, 1024));
@@ -1762,7 +1810,7 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
             }
             dim3 grid(vs_div_up(hyp, kCntHyps), batch);
             ransac_count_kernel<<<grid, 64 * waves, queue_bytes, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, threshold, hypF,
-                                                                     hyp_count, hyp_sum, approx);
+                                                                     hyp_count, hyp_sum, approx, cbound);
         }
         {
             VsProfScope ps(ctx, "ransac_ties_kernel");
