@@ -53,6 +53,7 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
         "ransac_solve_kernel": H * 32 + M * 24 + H * 36,
         "ransac_score_kernel": H * 36 + M * 24 + H * 8,
         "ransac_count_kernel": H * 36 + M * 24 + H * 4,
+        "ransac_pilot_kernel": 8 * (36 + M * 24),
         "ransac_ties_kernel": H * 4 + H * 4,
         "ransac_tiesum_kernel": M * 24 + 36 + 4,          # per tied hypothesis; at least one per pair
         "ransac_select_kernel": H * 8 + M * 24 + M + M * 8 + 36,
@@ -69,6 +70,7 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
 #    SIMDs x clock.  Both fractions are <= 1 by construction.
 FP32_PEAK_TFLOPS = 157.3                       # FMA counted as 2: 256 CUs x 4 SIMDs x 32 lanes x 2 x 2.4 GHz
 INT32_PEAK_TOPS = FP32_PEAK_TFLOPS / 2.0       # one 32-bit integer op per lane and clock
+INT8_MFMA_PEAK_TOPS = 5000.0                   # dense int8 MFMA (MI355X_MICROARCH.md: about 2x the 2.5 PFLOP/s bf16 rate)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
 ALG_OPS = {
     # kernel: (what one unit is, algorithmic ops per unit, kind, peak in Tops/s)
@@ -76,7 +78,8 @@ ALG_OPS = {
     "ransac_score_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop", FP32_PEAK_TFLOPS),
     "ransac_solve_kernel": ("hypotheses (two SVDs, about 3000 flop each: SURVEY.md 8d)", 3000.0, "flop", FP32_PEAK_TFLOPS),
     "min_eigen_kernel": ("pixels (stencil work, about 60 int/flop per pixel: SURVEY.md 8d)", 60.0, "flop", FP32_PEAK_TFLOPS),
-    "match_knn2_kernel": ("(query, train) descriptor pairs", 16.0, "int op (8 x 32-bit xor + 8 x popcount)", INT32_PEAK_TOPS),
+    # the matcher forms each 256-bit Hamming distance as an int8 dot product on the matrix cores: 256 multiply-adds
+    "match_knn2_kernel": ("(query, train) descriptor pairs", 512.0, "int8 op (256 multiply-adds on MFMA)", INT8_MFMA_PEAK_TOPS),
 }
 SQ_PROFILE = os.path.join(ROOT, "profiles", "r02_sq_counters.csv")
 
@@ -89,7 +92,7 @@ def sq_counters(kernel):
         return None
     with open(SQ_PROFILE) as f:
         for r in csv.DictReader(f):
-            if re.sub(r"_(v4|stream|lds)_kernel$", "_kernel", r["kernel"]) == kernel:
+            if re.sub(r"_(v4|stream|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
                 return float(r["waves_per_launch"]), float(r["valu_insts_per_wave"])
     return None
 
@@ -124,7 +127,7 @@ def pmc_traffic(kernel):
         return None
     with open(path) as f:
         for r in csv.DictReader(f):
-            if re.sub(r"_(v4|stream|lds)_kernel$", "_kernel", r["kernel"]) == kernel:
+            if re.sub(r"_(v4|stream|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
                 return (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
     return None
 
@@ -454,12 +457,13 @@ def main():
                                           "against the vector ALU peak and its issued VALU instructions against the chip's issue rate")
         if "match_knn2_kernel" in by_name:   # north_star names the match kernel: always report it
             mk = by_name["match_knn2_kernel"]
-            result["roofline_match"] = {"kernel": "match_knn2_kernel", "bound": "hbm", "achieved": mk["alg_GBps"], "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": mk["alg_GBps"] / HBM_PEAK_GBS,
+            mv = arithmetic_view("match_knn2_kernel", units_of("match_knn2_kernel"), mk["ms_per_launch"], full_batch)
+            result["roofline_match"] = {"kernel": "match_knn2_kernel", "bound": "mfma", "achieved": mv["achieved"], "peak": mv["peak"],
+                                        "unit": "TOP/s (int8, dense)", "frac": mv["frac"],
                                         "traffic": pmc_traffic("match_knn2_kernel") if full_batch else None,
                                         "avg_launch_ms": mk["ms_per_launch"],
-                                        "arithmetic": arithmetic_view("match_knn2_kernel", units_of("match_knn2_kernel"),
-                                                                      mk["ms_per_launch"], full_batch)}
+                                        "hbm": {"achieved": mk["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mk["alg_GBps"] / HBM_PEAK_GBS},
+                                        "arithmetic": mv}
         # the HBM-class (stencil) kernel that moves the most bytes, for the bandwidth view of the step
         stencil = [k for k in kernels if k["kernel"] in ("min_eigen_kernel", "gaussian7_kernel", "bgr2gray_kernel")]
         if stencil:
