@@ -52,8 +52,10 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
         "ransac_sets_kernel": 2 * H * 32,              # raw outputs in, sets out
         "ransac_solve_kernel": H * 32 + M * 24 + H * 36,
         "ransac_score_kernel": H * 36 + M * 24 + H * 8,
-        "ransac_count_kernel": H * 36 + M * 24 + H * 4,
-        "ransac_pilot_kernel": 8 * (36 + M * 24),
+        "ransac_count_kernel": H * 36 + M * 16 + H * 4 + H * 16,
+        "ransac_rank_kernel": 8 * 36 + M * 24 + M * 16,
+        "ransac_screen_kernel": H * 36 + 128 * 16 + H * 4,
+        "ransac_cand_kernel": H * 4 + 8 * (36 + M * 16),
         "ransac_ties_kernel": H * 4 + H * 4,
         "ransac_tiesum_kernel": M * 24 + 36 + 4,          # per tied hypothesis; at least one per pair
         "ransac_select_kernel": H * 8 + M * 24 + M + M * 8 + 36,

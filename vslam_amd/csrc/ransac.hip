@@ -977,12 +977,18 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
 // compute_fundamental_residual, counts first (the default scoring path)
 // ------------------------------------------------------------------------------------------
 // find_fundamental consults a hypothesis' residual SUM only to break ties among hypotheses whose inlier COUNT
-// equals the running maximum (RansacFilter.cpp:59); every other sum is computed by the reference and thrown away.
-// So the scoring is split:
-//   ransac_count_kernel   exact inlier count of every hypothesis that can matter (those reaching the pair's maximum
-//                         count are always counted in full), from a cheap evaluation of e with a certified error
-//                         band; the few evaluations that land inside the band are re-done with the exact sequence
-//                         (residual_e) -> these counts are the reference's counts, bit for bit;
+// equals the running maximum (RansacFilter.cpp:59); every other sum is computed by the reference and thrown away,
+// and a COUNT below the pair's maximum never reaches the accept rule either.  So the scoring is split:
+//   ransac_rank_kernel    exact counts of 8 pilot hypotheses (a first lower bound on the maximum) and, from their
+//                         inlier masks, the matches ordered by how many pilots miss them (most-missed first), laid
+//                         out as four coordinate arrays;
+//   ransac_screen_kernel  every hypothesis on the 128 most-missed matches: how many of those it can have as inliers;
+//   ransac_cand_kernel    exact full counts of the (up to 8) hypotheses that do best there -> the bound is now the
+//                         pair's maximum count on almost every pair;
+//   ransac_count_kernel   exact inlier count of every hypothesis that can reach the maximum (those that do are always
+//                         counted in full), from a cheap evaluation of e with a certified error band; the few
+//                         evaluations that land inside the band are re-done with the exact sequence (residual_e)
+//                         -> these counts are the reference's counts, bit for bit;
 //   ransac_ties_kernel    C* = max count per pair; of the hypotheses that reach it, those whose sum can still be
 //                         the largest after rounding (the count kernel's cheap sums bound every exact sum);
 //   ransac_tiesum_kernel  the exact, index-ordered double sum (cv::sum, :138) for those hypotheses only;
@@ -1010,69 +1016,103 @@ __global__ __launch_bounds__(kScoreThreads) void ransac_score_kernel(
 // in a thousand, so uncertain evaluations are not handled in place (a wave would leave the fast path for 6 % of its
 // evaluations) but queued per wave in LDS as (hypothesis, match) words and evaluated 64 at a time with full lanes.
 //
-// Bail-out: a hypothesis matters to the accept rule only if its count is the pair's maximum, so a wave stops working
-// on a hypothesis once the matches it has looked at contain more certain outliers than ANY maximum-count hypothesis
-// can have: potential inliers seen + all matches not seen < a count some hypothesis of the pair verifiably reaches.
-// Such hypotheses report -1 (ransac_ties_kernel then writes -1 for every hypothesis below the maximum, so the array
-// does not depend on timing).  On the bench data 60 % of the (hypothesis, wave) units stop after their first 256 matches.
+// Bail-out: a hypothesis matters to the accept rule only if its count is the pair's maximum, so work on a hypothesis
+// stops once the matches looked at contain more certain outliers than ANY maximum-count hypothesis can have:
+// potential inliers seen + all matches not seen < a count some hypothesis of the pair verifiably reaches (`bound`,
+// never above the true maximum).  Such hypotheses report -1 (ransac_ties_kernel then writes -1 for every hypothesis
+// below the maximum, so the array does not depend on timing).  How soon that happens depends on two things the three
+// small kernels in front are there for.  (1) The bound: on clean data a third to two thirds of the hypotheses share one
+// count (every true correspondence an inlier) and a handful reach one more; with a bound one short of the maximum that
+// whole plateau has to be counted in full, with the maximum itself none of it (tools/bail_sim.py: 54 % -> 29 % of all
+// evaluations).  (2) The order: the matches every decent hypothesis misses are looked at first, so the allowance of
+// outliers is used up at once and the first real difference decides.  Counts do not depend on the order of the
+// matches, the cheap sums only within their certified bound, and ransac_tiesum_kernel sums in list order.
 //
-// Mapping: one workgroup = 64 hypotheses x all matches of a pair; a wave owns up to 1024 matches, 16 per lane, held
-// in registers for the 64 hypotheses; the hypothesis' record (F, lo, hi) is a broadcast read from LDS;
-// v_cmp writes lane masks to SGPRs, counting is s_bcnt1 on the scalar unit (north_star: ballot / popcount).
-constexpr int kCntHyps = 64;
-constexpr int kCntMaxWaves = VSLAM_MAX_KP / 1024;
-constexpr int kCntLock = 2;        // hypotheses every wave of a workgroup visits first, together
-constexpr int kCntQueue = 1088;   // words per wave: 16 evaluations x 64 lanes of one hypothesis + 63 carried over
+// Mapping of the count kernel: a workgroup = 128 hypotheses of a pair; those the screen has not already ruled out are
+// handed to its 8 waves one at a time; a wave walks the ranked matches 256 at a time (4 per lane, coordinates staged in
+// LDS as four arrays so that a lane's two neighbouring matches are the halves of a packed operand); the hypothesis'
+// record (F twice, lo, hi) is a broadcast read from LDS; v_cmp writes lane masks to SGPRs, counting is s_bcnt1 on the
+// scalar unit (north_star: ballot / popcount).
+constexpr int kCntHyps = 128;
+constexpr int kCntWaves = 8;
+constexpr int kCntQueue = 320;          // words per wave: the 256 evaluations of one sub-block + 63 carried over
+constexpr int kCntLdsMatches = 4096;    // ranked coordinates are staged in LDS up to this many matches (64 KiB); read from memory beyond
+constexpr int kScreenMatches = 128;
+constexpr int kScreenHyps = 128;        // per workgroup: 4 waves x 32
+constexpr int kRankThreads = 512;
+constexpr int kPilotHyps = kRankThreads / 64;
+constexpr int kCandMax = 8;
 constexpr float kCntTinyDD = 0x1p-120f;
 // A hypothesis as the counting loop reads it from LDS: every element of F twice (so a register pair is the
 // (f, f) operand of a packed instruction with no v_mov), then lo, hi.  kCntRec floats per hypothesis.
 constexpr int kCntRec = 20;
-static_assert(kCntMaxWaves * 64 <= 1024, "one workgroup must be able to hold VSLAM_MAX_KP matches");
+// a wave's queue: volatile (lanes read what other lanes wrote) and typed as LDS so that the accesses are ds_ instructions
+typedef __attribute__((address_space(3))) volatile uint32_t cnt_queue_t;
+static_assert(VSLAM_MAX_KP <= 65536, "queue words keep the match index in 16 bits");
 
-struct CntCoords {
-    v2f x1[8], y1[8], x2[8], y2[8];   // [j] = the lane's matches 2j and 2j+1
+__host__ __device__ constexpr int cnt_pad(int n) { return (n + 255) & ~255; }
+
+struct CntBand {
+    float lo, hi;
+    double beta;
+    bool ok;
 };
-
-// exact evaluation of up to 64 queued (hypothesis, match) words, one per lane
-__device__ __forceinline__ void cnt_drain(const volatile uint32_t *q, int from, int count, int lane, const float *s_rec,
-                                          int *s_cnt, const float2 *P1, const float2 *P2, const int2 *PR, float threshold) {
-    if (lane < count) {
-        const uint32_t en = q[from + lane];
-        const int hh = (int)(en >> 16), i = (int)(en & 0xFFFFu);
-        ResidualF R;
+// the certified band of one hypothesis (see above); C1 / C2 = the pair's largest |coordinate| in frame 1 / 2
+__device__ __forceinline__ CntBand cnt_band(const float *f, float C1, float C2, float threshold) {
+    CntBand B;
+    bool ok = threshold >= 0x1p-20f && threshold <= 0x1p20f && C1 <= 0x1p20f && C2 <= 0x1p20f;
 #pragma unroll
-        for (int k = 0; k < 9; k++) R.f[k] = s_rec[hh * kCntRec + 2 * k];
-        residual_prepare(R);
-        const int2 pr = PR[i];
-        const float2 a = P1[pr.x], c = P2[pr.y];
-        const float e = residual_e(R, make_float4(a.x, a.y, c.x, c.y), (double)c.x, (double)c.y);
-        if (e <= threshold) atomicAdd(&s_cnt[hh], 1);
+    for (int k = 0; k < 9; k++) ok = ok && fabsf(f[k]) <= 1024.f;   // false for NaN
+    const double S = ((double)fabsf(f[0]) + (double)fabsf(f[3]) + (double)fabsf(f[1]) + (double)fabsf(f[4])) * (double)C2 +
+                     (double)fabsf(f[6]) + (double)fabsf(f[7]);
+    const double beta = 4.04 * 0x1p-24 * S + 1e-30;
+    const double sq = sqrt((double)threshold);
+    const double lo_r = sq * (1.0 - 0x1p-20) - 1.01 * beta;
+    const double hi_r = sq * (1.0 + 0x1p-20) + 2.5 * beta;
+    B.lo = lo_r > 0 ? (float)(lo_r * lo_r * (1.0 - 0x1p-22)) : -1.f;
+    B.hi = (float)(hi_r * hi_r * (1.0 + 0x1p-20) * (1.0 + 0x1p-22));
+    if (!ok) {
+        B.lo = -1.f;       // g >= 0 or NaN: never below lo
+        B.hi = INFINITY;   // never above hi: every evaluation takes the exact sequence
     }
+    B.beta = beta;
+    B.ok = ok;
+    return B;
 }
-
-// append the lanes of mask U (evaluation `idx0 + lane` of hypothesis hh) to the wave's queue
-__device__ __forceinline__ void cnt_push(volatile uint32_t *q, int &qn, unsigned long long U, int hh, int idx0, int lane) {
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(U >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)U, 0u));
-    if ((U >> lane) & 1ull) q[qn + rank] = ((uint32_t)hh << 16) | (uint32_t)(idx0 + lane);
-    qn += __popcll(U);
+__device__ __forceinline__ void cnt_store_record(float *d, const float *f, const CntBand &B) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        d[2 * k] = f[k];
+        d[2 * k + 1] = f[k];
+    }
+    d[18] = B.lo;
+    d[19] = B.hi;
 }
 
 struct CntRec {
     v2f f[9];
     float lo, hi;
 };
+__device__ __forceinline__ void cnt_load_record(CntRec &R, const float *s_rec, int hh) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(s_rec + hh * kCntRec);
+    const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3], v4 = r4[4];
+    R.f[0].x = v0.x; R.f[0].y = v0.y; R.f[1].x = v0.z; R.f[1].y = v0.w;
+    R.f[2].x = v1.x; R.f[2].y = v1.y; R.f[3].x = v1.z; R.f[3].y = v1.w;
+    R.f[4].x = v2.x; R.f[4].y = v2.y; R.f[5].x = v2.z; R.f[5].y = v2.w;
+    R.f[6].x = v3.x; R.f[6].y = v3.y; R.f[7].x = v3.z; R.f[7].y = v3.w;
+    R.f[8].x = v4.x; R.f[8].y = v4.y;
+    R.lo = v4.z;
+    R.hi = v4.w;
+}
 
-// two matches per lane under one hypothesis: count of the certain inliers and masks of the undecided lanes
-template <bool PARTIAL>
-__device__ __forceinline__ void cnt_eval_pair(const CntRec &R, const v2f X1, const v2f Y1, const v2f X2, const v2f Y2, int idx0,
-                                              int lane, int m, int &cnt, unsigned long long &ua, unsigned long long &ub,
-                                              float &ddmin, v2f &acc) {
+// the cheap value g for two matches per lane; dd returned for the caller's denormal check
+__device__ __forceinline__ v2f cnt_cheap(const CntRec &R, const v2f X1, const v2f Y1, const v2f X2, const v2f Y2, v2f &dd) {
     const v2f a0 = (R.f[0] * X1 + R.f[1] * Y1) + R.f[2];
     const v2f a1 = (R.f[3] * X1 + R.f[4] * Y1) + R.f[5];
     const v2f a2 = (R.f[6] * X1 + R.f[7] * Y1) + R.f[8];
     const v2f n = (X2 * a0 + Y2 * a1) + a2;
-    const v2f nn = n * n, dd = a0 * a0;
-    ddmin = fminf(ddmin, fminf(dd.x, dd.y));
+    const v2f nn = n * n;
+    dd = a0 * a0;
     v2f r;
     r.x = __builtin_amdgcn_rcpf(dd.x);
     r.y = __builtin_amdgcn_rcpf(dd.y);
@@ -1081,11 +1121,47 @@ __device__ __forceinline__ void cnt_eval_pair(const CntRec &R, const v2f X1, con
     const v2f t1 = __builtin_elementwise_fma(R.f[4], Y2, __builtin_elementwise_fma(R.f[1], X2, R.f[7]));
     g = __builtin_elementwise_fma(t0, t0, g);
     g = __builtin_elementwise_fma(t1, t1, g);
+    return g;
+}
+
+// exact evaluation of up to 64 queued (hypothesis, ranked match) words, one per lane
+__device__ __forceinline__ void cnt_drain(const cnt_queue_t *q, int from, int count, int lane, const float *s_rec,
+                                          int *s_cnt, const float *cx1, const float *cy1, const float *cx2, const float *cy2,
+                                          float threshold) {
+    if (lane < count) {
+        const uint32_t en = q[from + lane];
+        const int hh = (int)(en >> 16), i = (int)(en & 0xFFFFu);
+        ResidualF R;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.f[k] = s_rec[hh * kCntRec + 2 * k];
+        residual_prepare(R);
+        const float x2 = cx2[i], y2 = cy2[i];
+        const float e = residual_e(R, make_float4(cx1[i], cy1[i], x2, y2), (double)x2, (double)y2);
+        if (e <= threshold) atomicAdd(&s_cnt[hh], 1);
+    }
+}
+
+// append the lanes of mask U (evaluation `idx` of hypothesis hh, idx per lane) to the wave's queue
+__device__ __forceinline__ void cnt_push(cnt_queue_t *q, int &qn, unsigned long long U, int hh, int idx, int lane) {
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(U >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)U, 0u));
+    if ((U >> lane) & 1ull) q[qn + rank] = ((uint32_t)hh << 16) | (uint32_t)idx;
+    qn += __popcll(U);
+}
+
+// two matches per lane (ranked positions ix, ix + 1) under one hypothesis: count of the certain inliers and masks of
+// the undecided lanes
+template <bool PARTIAL>
+__device__ __forceinline__ void cnt_eval_pair(const CntRec &R, const v2f X1, const v2f Y1, const v2f X2, const v2f Y2, int ix,
+                                              int m, int &cnt, unsigned long long &ua, unsigned long long &ub,
+                                              float &ddmin, v2f &acc) {
+    v2f dd;
+    v2f g = cnt_cheap(R, X1, Y1, X2, Y2, dd);
+    ddmin = fminf(ddmin, fminf(dd.x, dd.y));
     // v_cmp straight into a lane mask (llvm::CmpInst predicates: 4 = ordered <, 2 = ordered >)
     unsigned long long ia = __builtin_amdgcn_fcmpf(g.x, R.lo, 4), oa = __builtin_amdgcn_fcmpf(g.x, R.hi, 2);
     unsigned long long ib = __builtin_amdgcn_fcmpf(g.y, R.lo, 4), ob = __builtin_amdgcn_fcmpf(g.y, R.hi, 2);
     if (PARTIAL) {
-        const bool in_a = idx0 + lane < m, in_b = idx0 + 64 + lane < m;
+        const bool in_a = ix < m, in_b = ix + 1 < m;
         const unsigned long long va = __ballot(in_a), vb = __ballot(in_b);
         ia &= va;
         ib &= vb;
@@ -1113,83 +1189,311 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-// one 256-match sub-block (4 evaluations per lane) of hypothesis hh: certified count into cnt, the rest queued
+// one 256-match sub-block (the lane's ranked matches ix .. ix + 3) of hypothesis hh: certified count into cnt, the rest queued
 template <bool PARTIAL>
-__device__ __forceinline__ void cnt_sub_block(const CntRec &R, const CntCoords &T, int s, int idx0, int hh, int lane, int m, int &cnt,
-                                              volatile uint32_t *q, int &qn, v2f &acc, int *s_unk, int &pot) {
+__device__ __forceinline__ void cnt_sub_block(const CntRec &R, const float4 X1, const float4 Y1, const float4 X2, const float4 Y2,
+                                              int ix, int hh, int lane, int m, int &cnt, cnt_queue_t *q, int &qn, v2f &acc,
+                                              int *s_unk, int &pot) {
     unsigned long long u0, u1, u2, u3;
     int c = 0;
     float ddmin = INFINITY;
-    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s], T.y1[2 * s], T.x2[2 * s], T.y2[2 * s], idx0, lane, m, c, u0, u1, ddmin, acc);
-    cnt_eval_pair<PARTIAL>(R, T.x1[2 * s + 1], T.y1[2 * s + 1], T.x2[2 * s + 1], T.y2[2 * s + 1], idx0 + 128, lane, m, c, u2, u3, ddmin, acc);
+    v2f x1a, y1a, x2a, y2a, x1b, y1b, x2b, y2b;
+    x1a.x = X1.x; x1a.y = X1.y; x1b.x = X1.z; x1b.y = X1.w;
+    y1a.x = Y1.x; y1a.y = Y1.y; y1b.x = Y1.z; y1b.y = Y1.w;
+    x2a.x = X2.x; x2a.y = X2.y; x2b.x = X2.z; x2b.y = X2.w;
+    y2a.x = Y2.x; y2a.y = Y2.y; y2b.x = Y2.z; y2b.y = Y2.w;
+    cnt_eval_pair<PARTIAL>(R, x1a, y1a, x2a, y2a, ix, m, c, u0, u1, ddmin, acc);
+    cnt_eval_pair<PARTIAL>(R, x1b, y1b, x2b, y2b, ix + 2, m, c, u2, u3, ddmin, acc);
     if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, 9) != 0ull) {   // 9 = unordered or <: some dd is zero / denormal (or NaN)
         // nothing of this sub-block is certified: all of it is queued, and the hypothesis' cheap sum means nothing
         if (lane == 0) s_unk[hh] = 1;
         c = 0;
-        u0 = __builtin_amdgcn_sicmp(idx0 + lane, m, 40);
-        u1 = __builtin_amdgcn_sicmp(idx0 + 64 + lane, m, 40);
-        u2 = __builtin_amdgcn_sicmp(idx0 + 128 + lane, m, 40);
-        u3 = __builtin_amdgcn_sicmp(idx0 + 192 + lane, m, 40);
+        u0 = __builtin_amdgcn_sicmp(ix, m, 40);   // 40 = signed <
+        u1 = __builtin_amdgcn_sicmp(ix + 1, m, 40);
+        u2 = __builtin_amdgcn_sicmp(ix + 2, m, 40);
+        u3 = __builtin_amdgcn_sicmp(ix + 3, m, 40);
     }
     cnt += c;
     pot += c;   // inliers this sub-block can still turn out to have: the certain ones plus the undecided ones
     if ((u0 | u1 | u2 | u3) != 0ull) {
         pot += __popcll(u0) + __popcll(u1) + __popcll(u2) + __popcll(u3);
-        if (u0) cnt_push(q, qn, u0, hh, idx0, lane);
-        if (u1) cnt_push(q, qn, u1, hh, idx0 + 64, lane);
-        if (u2) cnt_push(q, qn, u2, hh, idx0 + 128, lane);
-        if (u3) cnt_push(q, qn, u3, hh, idx0 + 192, lane);
+        if (u0) cnt_push(q, qn, u0, hh, ix, lane);
+        if (u1) cnt_push(q, qn, u1, hh, ix + 1, lane);
+        if (u2) cnt_push(q, qn, u2, hh, ix + 2, lane);
+        if (u3) cnt_push(q, qn, u3, hh, ix + 3, lane);
     }
 }
 
-// A first lower bound on the pair's maximum count, so that the counting kernel can abandon hopeless hypotheses from its
-// very first one: the exact inlier counts of kPilotHyps hypotheses spread over the list (a wave each, lanes over the
-// matches), maximum kept in cbound[pair].  Any count of any hypothesis is a valid bound; a better one only prunes more.
-constexpr int kPilotHyps = 8;   // 8 .. 64 pilots and 0 .. 2 lock-step hypotheses all land within 1 % of each other
-__global__ __launch_bounds__(64) void ransac_pilot_kernel(
-    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
-    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
-    int32_t *__restrict__ cbound) {
-    const int b = blockIdx.y, lane = threadIdx.x;
-    const int m = min(m_arr[b], kp_stride);
-    if (m < min_m) return;
-    const int h = (int)(((long long)hyp * blockIdx.x) / gridDim.x);
-    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
-    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
-    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+// exact inlier count of one hypothesis over the ranked coordinate arrays (one wave, lanes over the matches)
+__device__ __forceinline__ int cnt_exact_ranked(const float *F9, const float *r, int kp_pad, int m, float threshold, int lane) {
     ResidualF R;
-    const float *src = hypF + ((size_t)b * hyp + h) * 9;
 #pragma unroll
-    for (int j = 0; j < 9; j++) R.f[j] = src[j];
+    for (int j = 0; j < 9; j++) R.f[j] = F9[j];
     residual_prepare(R);
     int count = 0;
-    for (int i0 = 0; i0 < m; i0 += 256) {   // four matches per lane and round: their gathers are in flight together
-        int2 pr[4];
-        float2 a[4], c[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) pr[u] = PR[min(i0 + u * 64 + lane, m - 1)];
+    for (int i0 = 0; i0 < m; i0 += 256) {   // the arrays are padded to a multiple of 256
+        float4 c[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            a[u] = P1[pr[u].x];
-            c[u] = P2[pr[u].y];
+            const int i = i0 + u * 64 + lane;
+            c[u] = make_float4(r[i], r[kp_pad + i], r[2 * kp_pad + i], r[3 * kp_pad + i]);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const float e = residual_e(R, make_float4(a[u].x, a[u].y, c[u].x, c[u].y), (double)c[u].x, (double)c[u].y);
+            const float e = residual_e(R, c[u], (double)c[u].z, (double)c[u].w);
             count += __popcll(__ballot(i0 + u * 64 + lane < m && e <= threshold));
         }
     }
-    if (lane == 0) atomicMax(&cbound[b], count);
+    return count;
 }
 
-// grid = (ceil(hyp / 64), batch), block = 64 * ceil(kp_stride / 1024) threads
-__global__ __launch_bounds__(1024) void ransac_count_kernel(
+// One workgroup per pair.  Wave w counts pilot hypothesis w exactly (lanes over the matches) and leaves its inlier mask in
+// LDS; cbound[pair] = the best of those counts: a first lower bound on the pair's maximum count (any count of any
+// hypothesis is a valid bound; a better one only prunes more).  Then the matches are ordered by the number of pilots that
+// miss them, most-missed first, original order among equals (a counting sort over 9 keys), and written as four arrays
+// rk[pair][0..3][kp_pad] = x1, y1, x2, y2, padded with a real match up to the next multiple of 256.
+// cmax[pair] = the largest |coordinate| per frame (the error bands need it).
+__global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
-    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold, const float *__restrict__ hypF,
-    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx, const int32_t *__restrict__ cbound) {
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int kp_pad, int hyp, float threshold,
+    const float *__restrict__ hypF, int32_t *__restrict__ cbound, float *__restrict__ rk, float *__restrict__ cmax) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = min(m_arr[b], kp_stride);
+    if (m < min_m) return;
+    __shared__ unsigned long long s_bits[kPilotHyps][VSLAM_MAX_KP / 64];
+    __shared__ int s_hist[kPilotHyps][kPilotHyps + 1], s_off[kPilotHyps][kPilotHyps + 1];
+    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
+    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
+    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    const int npil = min(kPilotHyps, hyp);
+    const int G = (m + 63) >> 6;
+
+    if (wave < npil) {
+        const int h = (int)(((long long)hyp * wave) / npil);
+        ResidualF R;
+        const float *src = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; j++) R.f[j] = src[j];
+        residual_prepare(R);
+        int count = 0;
+        float c1 = 0.f, c2 = 0.f;
+        for (int g0 = 0; g0 < G; g0 += 4) {   // four matches per lane and round: their gathers are in flight together
+            int2 pr[4];
+            float2 a[4], c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pr[u] = PR[min((g0 + u) * 64 + lane, m - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = P1[pr[u].x];
+                c[u] = P2[pr[u].y];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float e = residual_e(R, make_float4(a[u].x, a[u].y, c[u].x, c[u].y), (double)c[u].x, (double)c[u].y);
+                const unsigned long long in = __ballot((g0 + u) * 64 + lane < m && e <= threshold);
+                count += __popcll(in);
+                if (lane == 0 && g0 + u < G) s_bits[wave][g0 + u] = in;
+                c1 = fmaxf(c1, fmaxf(fabsf(a[u].x), fabsf(a[u].y)));
+                c2 = fmaxf(c2, fmaxf(fabsf(c[u].x), fabsf(c[u].y)));
+            }
+        }
+        if (lane == 0) atomicMax(&cbound[b], count);
+        if (wave == 0) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                c1 = fmaxf(c1, __shfl_xor(c1, off, 64));
+                c2 = fmaxf(c2, __shfl_xor(c2, off, 64));
+            }
+            if (lane == 0) {
+                cmax[2 * b] = c1;
+                cmax[2 * b + 1] = c2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // this wave's share of the 64-match groups; key of a match = number of pilots that miss it
+    const int gpw = (G + kPilotHyps - 1) / kPilotHyps;
+    const int g_lo = min(G, wave * gpw), g_hi = min(G, g_lo + gpw);
+    int hist[kPilotHyps + 1];
+#pragma unroll
+    for (int v = 0; v <= kPilotHyps; v++) hist[v] = 0;
+    for (int g = g_lo; g < g_hi; g++) {
+        const bool valid = g * 64 + lane < m;
+        int key = 0;
+        for (int w = 0; w < npil; w++) key += (int)((~s_bits[w][g] >> lane) & 1ull);
+#pragma unroll
+        for (int v = 0; v <= kPilotHyps; v++) hist[v] += __popcll(__ballot(valid && key == v));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int v = 0; v <= kPilotHyps; v++) s_hist[wave][v] = hist[v];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int v = kPilotHyps; v >= 0; v--)
+            for (int w = 0; w < kPilotHyps; w++) {
+                s_off[w][v] = run;
+                run += s_hist[w][v];
+            }
+    }
+    __syncthreads();
+    int off[kPilotHyps + 1];
+#pragma unroll
+    for (int v = 0; v <= kPilotHyps; v++) off[v] = s_off[wave][v];
+    float *r = rk + (size_t)b * 4 * kp_pad;
+    for (int g = g_lo; g < g_hi; g++) {
+        const int i = g * 64 + lane;
+        const bool valid = i < m;
+        int key = 0;
+        for (int w = 0; w < npil; w++) key += (int)((~s_bits[w][g] >> lane) & 1ull);
+        int pos = 0;
+#pragma unroll
+        for (int v = 0; v <= kPilotHyps; v++) {
+            const unsigned long long bal = __ballot(valid && key == v);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (key == v) pos = off[v] + rank;
+            off[v] += __popcll(bal);
+        }
+        if (valid) {
+            const int2 pr = PR[i];
+            const float2 a = P1[pr.x], c = P2[pr.y];
+            r[pos] = a.x;
+            r[kp_pad + pos] = a.y;
+            r[2 * kp_pad + pos] = c.x;
+            r[3 * kp_pad + pos] = c.y;
+        }
+    }
+    const int mpad = cnt_pad(m);
+    if (m + tid < mpad) {   // at most 255 slots: lanes beyond m in the last sub-block read a real match (and are masked)
+        const int2 pr = PR[m - 1];
+        const float2 a = P1[pr.x], c = P2[pr.y];
+        r[m + tid] = a.x;
+        r[kp_pad + m + tid] = a.y;
+        r[2 * kp_pad + m + tid] = c.x;
+        r[3 * kp_pad + m + tid] = c.y;
+    }
+}
+
+// pot0[pair][h] = how many of the kScreenMatches most-missed matches hypothesis h can have as inliers (everything the
+// cheap evaluation does not certify as an outlier).  Workgroup = 128 hypotheses, a wave walks 32 of them with two of the
+// ranked matches per lane.  grid = (ceil(hyp / 128), batch).
+__global__ __launch_bounds__(256) void ransac_screen_kernel(
+    const float *__restrict__ rk, int kp_pad, const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp,
+    float threshold, const float *__restrict__ hypF, const float *__restrict__ cmax, int32_t *__restrict__ pot0) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hbase = blockIdx.x * kScreenHyps;
+    const int m = min(m_arr[b], kp_stride);
+    if (m < min_m) return;
+    __shared__ __align__(16) float s_rec[kScreenHyps * kCntRec];
+    if (tid < kScreenHyps) {
+        const float *src = hypF + ((size_t)b * hyp + min(hbase + tid, hyp - 1)) * 9;
+        float f[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = src[k];
+        const CntBand B = cnt_band(f, cmax[2 * b], cmax[2 * b + 1], threshold);
+        cnt_store_record(s_rec + tid * kCntRec, f, B);
+    }
+    const int n0 = min(m, kScreenMatches);
+    const float *r = rk + (size_t)b * 4 * kp_pad;
+    const float2 x1 = *reinterpret_cast<const float2 *>(r + 2 * lane);
+    const float2 y1 = *reinterpret_cast<const float2 *>(r + kp_pad + 2 * lane);
+    const float2 x2 = *reinterpret_cast<const float2 *>(r + 2 * kp_pad + 2 * lane);
+    const float2 y2 = *reinterpret_cast<const float2 *>(r + 3 * kp_pad + 2 * lane);
+    v2f X1, Y1, X2, Y2;
+    X1.x = x1.x; X1.y = x1.y; Y1.x = y1.x; Y1.y = y1.y;
+    X2.x = x2.x; X2.y = x2.y; Y2.x = y2.x; Y2.y = y2.y;
+    const unsigned long long va = __ballot(2 * lane < n0), vb = __ballot(2 * lane + 1 < n0);
+    __syncthreads();
+    int mine = 0;
+    for (int j = 0; j < 32; j += 2) {   // two hypotheses in flight
+        CntRec R0, R1;
+        cnt_load_record(R0, s_rec, wave * 32 + j);
+        cnt_load_record(R1, s_rec, wave * 32 + j + 1);
+        v2f dd0, dd1;
+        const v2f g0 = cnt_cheap(R0, X1, Y1, X2, Y2, dd0);
+        const v2f g1 = cnt_cheap(R1, X1, Y1, X2, Y2, dd1);
+        const unsigned long long oa0 = __builtin_amdgcn_fcmpf(g0.x, R0.hi, 2), ob0 = __builtin_amdgcn_fcmpf(g0.y, R0.hi, 2);
+        const unsigned long long oa1 = __builtin_amdgcn_fcmpf(g1.x, R1.hi, 2), ob1 = __builtin_amdgcn_fcmpf(g1.y, R1.hi, 2);
+        int p0 = __popcll(va & ~oa0) + __popcll(vb & ~ob0);
+        int p1 = __popcll(va & ~oa1) + __popcll(vb & ~ob1);
+        // a zero / denormal (or NaN) dd: v_rcp_f32 is not a 1-ulp reciprocal there, nothing is certified
+        if (__builtin_amdgcn_fcmpf(fminf(dd0.x, dd0.y), kCntTinyDD, 9) != 0ull) p0 = n0;
+        if (__builtin_amdgcn_fcmpf(fminf(dd1.x, dd1.y), kCntTinyDD, 9) != 0ull) p1 = n0;
+        mine = lane == j ? p0 : mine;
+        mine = lane == j + 1 ? p1 : mine;
+    }
+    const int h = hbase + wave * 32 + lane;
+    if (lane < 32 && h < hyp) pot0[(size_t)b * hyp + h] = mine;
+}
+
+// The hypotheses that do best on the screen (largest pot0, then one less, first indices, at most kCandMax) are counted in
+// full, exactly: cbound[pair] = max(cbound[pair], those counts).  One workgroup of 8 waves per pair.
+__global__ __launch_bounds__(64 * kCandMax) void ransac_cand_kernel(
+    const float *__restrict__ rk, int kp_pad, const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp,
+    float threshold, const float *__restrict__ hypF, const int32_t *__restrict__ pot0, int32_t *__restrict__ cbound) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = min(m_arr[b], kp_stride);
+    if (m < min_m) return;
+    __shared__ int s_max[kCandMax], s_l0[kCandMax][kCandMax], s_l1[kCandMax][kCandMax], s_n0[kCandMax], s_n1[kCandMax];
+    __shared__ int s_cand[kCandMax], s_nc;
+    const int32_t *P = pot0 + (size_t)b * hyp;
+    int mx = -1;
+    for (int i = tid; i < hyp; i += 64 * kCandMax) mx = max(mx, P[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = s_max[0];
+    for (int w = 1; w < kCandMax; w++) mx = max(mx, s_max[w]);
+    // wave w scans its contiguous share in index order
+    const int per = (hyp + kCandMax - 1) / kCandMax;
+    const int lo = min(hyp, wave * per), hi = min(hyp, lo + per);
+    int n0 = 0, n1 = 0;
+    for (int i0 = lo; i0 < hi && (n0 < kCandMax || n1 < kCandMax); i0 += 64) {
+        const int i = i0 + lane;
+        const int v = i < hi ? P[i] : -2;
+        unsigned long long b0 = __ballot(v == mx), b1 = __ballot(v == mx - 1);
+        const int r0 = n0 + __popcll(b0 & ((1ull << lane) - 1ull)), r1 = n1 + __popcll(b1 & ((1ull << lane) - 1ull));
+        if (v == mx && r0 < kCandMax) s_l0[wave][r0] = i;
+        if (v == mx - 1 && r1 < kCandMax) s_l1[wave][r1] = i;
+        n0 = min(kCandMax, n0 + __popcll(b0));
+        n1 = min(kCandMax, n1 + __popcll(b1));
+    }
+    if (lane == 0) {
+        s_n0[wave] = n0;
+        s_n1[wave] = n1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int w = 0; w < kCandMax && n < kCandMax; w++)
+            for (int k = 0; k < s_n0[w] && n < kCandMax; k++) s_cand[n++] = s_l0[w][k];
+        for (int w = 0; w < kCandMax && n < kCandMax; w++)
+            for (int k = 0; k < s_n1[w] && n < kCandMax; k++) s_cand[n++] = s_l1[w][k];
+        s_nc = n;
+    }
+    __syncthreads();
+    if (wave < s_nc) {
+        const int h = s_cand[wave];
+        const int count = cnt_exact_ranked(hypF + ((size_t)b * hyp + h) * 9, rk + (size_t)b * 4 * kp_pad, kp_pad, m, threshold, lane);
+        if (lane == 0) atomicMax(&cbound[b], count);
+    }
+}
+
+// grid = (ceil(hyp / 128), batch), block = 512; dynamic LDS = (LDS ? 16 B x cnt_pad(kp_stride) : 0) + 8 queues.
+// LDS = false (more than kCntLdsMatches slots per pair): the ranked coordinates are read from memory instead.
+template <bool LDS>
+__global__ __launch_bounds__(64 * kCntWaves) void ransac_count_kernel(
+    const float *__restrict__ rk, int kp_pad, const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
+    const float *__restrict__ hypF, const int32_t *__restrict__ pot0, const float *__restrict__ cmax,
+    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx, int32_t *__restrict__ cbound) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler may know it
-    const int nw = (int)(blockDim.x >> 6);
     const int hbase = blockIdx.x * kCntHyps;
     const int nh = min(kCntHyps, hyp - hbase);
     const int m = min(m_arr[b], kp_stride);
@@ -1197,197 +1501,154 @@ __global__ __launch_bounds__(1024) void ransac_count_kernel(
 
     __shared__ __align__(16) float s_rec[kCntHyps * kCntRec];
     __shared__ int s_cnt[kCntHyps];
-    __shared__ float s_cmax[2 * kCntMaxWaves];
-    __shared__ float s_part[kCntMaxWaves * kCntHyps];   // per wave and hypothesis: sum of the cheap values
-    __shared__ int s_unk[kCntHyps];                     // hypothesis whose cheap sum is not certified
-    __shared__ int s_drop[kCntHyps];                    // hypothesis abandoned: it cannot reach the best count known
-    extern __shared__ uint32_t s_queue[];   // kCntQueue words per wave
-    const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
-    const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
-    const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
+    __shared__ float s_part[kCntHyps];   // sum of the cheap values
+    __shared__ int s_unk[kCntHyps];      // hypothesis whose cheap sum is not certified
+    __shared__ int s_state[kCntHyps];    // 0 = ruled out by the screen, 1 = counted in full, 2 = abandoned on the way
+    __shared__ int s_list[kCntHyps];     // survivors of the screen: [0, 64) found by wave 0, [64, 128) by wave 1
+    __shared__ int s_nlist[2], s_next, s_bound;
+    extern __shared__ __align__(16) uint32_t s_dyn[];
 
-    // this wave's matches: the pair's 256-match sub-blocks dealt evenly over the waves (at most 4 each)
-    const int total_sub = (m + 255) >> 8;
-    const int sub_lo = (total_sub * wave) / nw, sub_hi = (total_sub * (wave + 1)) / nw;
-    const int nsub = sub_hi - sub_lo;
-    const int base = sub_lo * 256;
-    const bool part = sub_hi == total_sub && (m & 255) != 0;   // this wave's last sub-block has lanes beyond m
-    const int nfull = part ? nsub - 1 : nsub;
-
-    CntCoords T;
-    float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        float2 a[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, c[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-        if ((j >> 1) < nsub) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int i = min(base + (2 * j + k) * 64 + lane, m - 1);   // lanes beyond m repeat the last match (masked later)
-                const int2 pr = PR[i];
-                a[k] = P1[pr.x];
-                c[k] = P2[pr.y];
-                c1 = fmaxf(c1, fmaxf(fabsf(a[k].x), fabsf(a[k].y)));
-                c2 = fmaxf(c2, fmaxf(fabsf(c[k].x), fabsf(c[k].y)));
-            }
-        }
-        T.x1[j].x = a[0].x; T.x1[j].y = a[1].x;
-        T.y1[j].x = a[0].y; T.y1[j].y = a[1].y;
-        T.x2[j].x = c[0].x; T.x2[j].y = c[1].x;
-        T.y2[j].x = c[0].y; T.y2[j].y = c[1].y;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        c1 = fmaxf(c1, __shfl_xor(c1, off, 64));
-        c2 = fmaxf(c2, __shfl_xor(c2, off, 64));
-    }
-    if (lane == 0) {
-        s_cmax[2 * wave] = c1;
-        s_cmax[2 * wave + 1] = c2;
-    }
-    if (tid < kCntHyps) {
+    const int n0 = min(m, kScreenMatches);
+    const int bound0 = cbound[b];   // a count some hypothesis of this pair is known to reach (never above the true maximum)
+    if (tid < kCntHyps) {           // waves 0 and 1, whole
+        const bool alive = tid < nh && pot0[(size_t)b * hyp + hbase + tid] + (m - n0) >= bound0;
         s_cnt[tid] = 0;
         s_unk[tid] = 0;
-        s_drop[tid] = 0;
-        for (int w = 0; w < nw; w++) s_part[w * kCntHyps + tid] = 0.f;
+        s_part[tid] = 0.f;
+        s_state[tid] = alive ? 1 : 0;
+        const unsigned long long bal = __ballot(alive);
+        if (alive) s_list[wave * 64 + __popcll(bal & ((1ull << lane) - 1ull))] = tid;
+        if (lane == 0) s_nlist[wave] = __popcll(bal);
+    }
+    if (tid == 0) {
+        s_next = 0;
+        s_bound = bound0;
     }
     __syncthreads();
+    const int n_a = s_nlist[0], n_alive = n_a + s_nlist[1];
+    const size_t out = (size_t)b * hyp + hbase + tid;
+    if (n_alive == 0) {   // the usual case on a pair whose maximum only a few hypotheses reach
+        if (tid < nh) {
+            hyp_count[out] = -1;
+            hyp_sum[out] = __int_as_float(0x7FC00000);
+            reinterpret_cast<float2 *>(approx)[out] = make_float2(0.f, INFINITY);
+        }
+        return;
+    }
 
-    double my_beta = 0;     // thread t < 64 keeps hypothesis t's beta for the bound on its cheap sum
+    double my_beta = 0;     // thread t < 128 keeps hypothesis t's beta for the bound on its cheap sum
     bool my_ok = false;
-    if (tid < kCntHyps) {   // the hypothesis records: F, lo, hi
-        float C1 = 0.f, C2 = 0.f;
-        for (int w = 0; w < nw; w++) {
-            C1 = fmaxf(C1, s_cmax[2 * w]);
-            C2 = fmaxf(C2, s_cmax[2 * w + 1]);
-        }
-        const float *src = hypF + ((size_t)b * hyp + min(hbase + tid, hyp - 1)) * 9;
+    if (tid < kCntHyps && s_state[tid]) {   // the survivors' records: F, lo, hi
+        const float *src = hypF + ((size_t)b * hyp + hbase + tid) * 9;
         float f[9];
-        bool ok = threshold >= 0x1p-20f && threshold <= 0x1p20f && C1 <= 0x1p20f && C2 <= 0x1p20f;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            f[k] = src[k];
-            ok = ok && fabsf(f[k]) <= 1024.f;   // false for NaN
-        }
-        const double S = ((double)fabsf(f[0]) + (double)fabsf(f[3]) + (double)fabsf(f[1]) + (double)fabsf(f[4])) * (double)C2 +
-                         (double)fabsf(f[6]) + (double)fabsf(f[7]);
-        const double beta = 4.04 * 0x1p-24 * S + 1e-30;
-        const double sq = sqrt((double)threshold);
-        const double lo_r = sq * (1.0 - 0x1p-20) - 1.01 * beta;
-        const double hi_r = sq * (1.0 + 0x1p-20) + 2.5 * beta;
-        float lo = lo_r > 0 ? (float)(lo_r * lo_r * (1.0 - 0x1p-22)) : -1.f;
-        float hi = (float)(hi_r * hi_r * (1.0 + 0x1p-20) * (1.0 + 0x1p-22));
-        if (!ok) {
-            lo = -1.f;       // g >= 0 or NaN: never below lo
-            hi = INFINITY;   // never above hi: every evaluation takes the exact sequence
-        }
-        my_beta = beta;
-        my_ok = ok;
-        float *d = s_rec + tid * kCntRec;
+        for (int k = 0; k < 9; k++) f[k] = src[k];
+        const CntBand B = cnt_band(f, cmax[2 * b], cmax[2 * b + 1], threshold);
+        my_beta = B.beta;
+        my_ok = B.ok;
+        cnt_store_record(s_rec + tid * kCntRec, f, B);
+    }
+    const int mpad = cnt_pad(m);
+    const float *rg = rk + (size_t)b * 4 * kp_pad;
+    float *s_co = reinterpret_cast<float *>(s_dyn);
+    if (LDS) {
+        for (int k = tid * 4; k < mpad; k += 64 * kCntWaves * 4) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            d[2 * k] = f[k];
-            d[2 * k + 1] = f[k];
+            for (int a = 0; a < 4; a++)
+                *reinterpret_cast<float4 *>(s_co + a * mpad + k) = *reinterpret_cast<const float4 *>(rg + (size_t)a * kp_pad + k);
         }
-        d[18] = lo;
-        d[19] = hi;
     }
     __syncthreads();
+    const int cstride = LDS ? mpad : kp_pad;
+    const float *cx1 = LDS ? s_co : rg;
+    const float *cy1 = cx1 + cstride, *cx2 = cx1 + 2 * cstride, *cy2 = cx1 + 3 * cstride;
 
-    if (nsub > 0) {
-        volatile uint32_t *q = s_queue + wave * kCntQueue;
+    {
+        cnt_queue_t *q = (cnt_queue_t *)(s_dyn + (LDS ? 4 * mpad : 0) + wave * kCntQueue);
         int qn = 0;
-        int bound = cbound[b];   // a count some hypothesis of this pair is known to reach (never above the true maximum): ransac_pilot_kernel's to begin with
-        // Visiting order.  The first kCntLock hypotheses are visited by all waves together (their full counts tighten
-        // the pilot's bound).  After that wave w starts a w-th of the way round the rest, so that for almost every hypothesis
-        // one wave gets there long before the others: if it abandons the hypothesis (s_drop), the others never start it.
-        const int lock = nh > 2 * kCntLock ? kCntLock : nh;
-        const int ring = nh - lock;
-        int cur = ring > 0 ? lock + (int)(((long long)ring * wave) / nw) : 0;   // next hypothesis once the lock-step ones are done
-        int hh_prev1 = -1, hh_prev2 = -1;
-        int drop_flag = 0;   // s_drop of the hypothesis about to be visited, read one iteration ahead
-        for (int t = 0; t < nh; t++) {
-            const int hh = t < lock ? t : cur;
-            if (t >= lock) cur = cur + 1 == nh ? lock : cur + 1;
-            const int hh_next = t + 1 < lock ? t + 1 : cur;
-            const bool skip = __builtin_amdgcn_readfirstlane(drop_flag) != 0;
-            drop_flag = t + 1 < nh ? *(const volatile int *)&s_drop[hh_next] : 0;
-            const int peek = hh_prev2 >= 0 ? *(const volatile int *)&s_cnt[hh_prev2] : 0;
-            hh_prev2 = hh_prev1;
-            hh_prev1 = hh;
-            if (skip) {   // another wave has already shown that this hypothesis cannot reach the maximum
-                bound = max(bound, __builtin_amdgcn_readfirstlane(peek));
-                continue;
-            }
+        int bound = bound0;
+        const int nsub = mpad >> 8;
+        const bool part = (m & 255) != 0;
+        // the survivors are handed out one at a time: what a hypothesis costs (256 evaluations or all of them) is not known beforehand
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&s_next, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        while (k < n_alive) {
+            int knext = 0;
+            if (lane == 0) knext = atomicAdd(&s_next, 1);   // consumed at the bottom: the round trip hides behind the work
+            const int hh = k < n_a ? s_list[k] : s_list[64 + k - n_a];
+            bound = max(bound, *(__attribute__((address_space(3))) const volatile int *)&s_bound);
             CntRec R;
-            {
-                const float4 *r4 = reinterpret_cast<const float4 *>(s_rec + hh * kCntRec);
-                const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3], v4 = r4[4];
-                R.f[0].x = v0.x; R.f[0].y = v0.y; R.f[1].x = v0.z; R.f[1].y = v0.w;
-                R.f[2].x = v1.x; R.f[2].y = v1.y; R.f[3].x = v1.z; R.f[3].y = v1.w;
-                R.f[4].x = v2.x; R.f[4].y = v2.y; R.f[5].x = v2.z; R.f[5].y = v2.w;
-                R.f[6].x = v3.x; R.f[6].y = v3.y; R.f[7].x = v3.z; R.f[7].y = v3.w;
-                R.f[8].x = v4.x; R.f[8].y = v4.y;
-                R.lo = v4.z;
-                R.hi = v4.w;
-            }
+            cnt_load_record(R, s_rec, hh);
             int cnt = 0, pot = 0, seen = 0;
             bool dropped = false;
             v2f acc;
             acc.x = 0.f;
             acc.y = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                if (!dropped) {
-                    if (s < nfull) {
-                        cnt_sub_block<false>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
-                        seen += 256;
-                    } else if (s == nfull && part) {
-                        cnt_sub_block<true>(R, T, s, base + s * 256, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
-                        seen += m & 255;
-                    }
-                    // Bail-out.  Even if every match this wave has not looked at yet (the rest of its tile and all of
-                    // the other waves') were an inlier, the hypothesis would stay below a count some hypothesis of this
-                    // pair is already known to reach: it cannot be a maximum-count hypothesis, which is all the accept
-                    // rule looks at.  `bound` never exceeds the true maximum, so every hypothesis that reaches the
-                    // maximum is counted in full.
-                    dropped = pot + (m - seen) < bound;
+            float4 nx1 = *reinterpret_cast<const float4 *>(cx1 + 4 * lane), ny1 = *reinterpret_cast<const float4 *>(cy1 + 4 * lane);
+            float4 nx2 = *reinterpret_cast<const float4 *>(cx2 + 4 * lane), ny2 = *reinterpret_cast<const float4 *>(cy2 + 4 * lane);
+            for (int s = 0; s < nsub; s++) {
+                const float4 X1 = nx1, Y1 = ny1, X2 = nx2, Y2 = ny2;
+                const int ix = s * 256 + 4 * lane;
+                if (s + 1 < nsub) {
+                    nx1 = *reinterpret_cast<const float4 *>(cx1 + ix + 256);
+                    ny1 = *reinterpret_cast<const float4 *>(cy1 + ix + 256);
+                    nx2 = *reinterpret_cast<const float4 *>(cx2 + ix + 256);
+                    ny2 = *reinterpret_cast<const float4 *>(cy2 + ix + 256);
+                }
+                if (s == nsub - 1 && part) {
+                    cnt_sub_block<true>(R, X1, Y1, X2, Y2, ix, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
+                    seen += m & 255;
+                } else {
+                    cnt_sub_block<false>(R, X1, Y1, X2, Y2, ix, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
+                    seen += 256;
+                }
+                while (qn >= 64) {   // a sub-block adds at most 256 words to the 63 left over: kCntQueue holds them
+                    cnt_drain(q, qn - 64, 64, lane, s_rec, s_cnt, cx1, cy1, cx2, cy2, threshold);
+                    qn -= 64;
+                }
+                // Bail-out.  Even if every match not looked at yet were an inlier, the hypothesis would stay below a
+                // count some hypothesis of this pair is already known to reach: it cannot be a maximum-count hypothesis,
+                // which is all the accept rule looks at.  `bound` never exceeds the true maximum, so every hypothesis
+                // that reaches the maximum is counted in full.
+                if (pot + (m - seen) < bound) {
+                    dropped = true;
+                    break;
                 }
             }
-            if (lane == 0) {
-                if (dropped) s_drop[hh] = 1;
-                else if (cnt) atomicAdd(&s_cnt[hh], cnt);
+            if (dropped) {
+                if (lane == 0) s_state[hh] = 2;
+            } else {
+                const float part_sum = wave_sum_to_lane63(acc.x + acc.y);
+                if (lane == 63) s_part[hh] = part_sum;
+                if (lane == 0) {
+                    if (cnt) atomicAdd(&s_cnt[hh], cnt);
+                    if (cnt > bound) {   // the certain inliers alone are a count this hypothesis verifiably reaches
+                        atomicMax(&s_bound, cnt);
+                        atomicMax(&cbound[b], cnt);   // fire and forget: workgroups of this pair that start later begin with it
+                    }
+                }
+                bound = max(bound, cnt);
             }
-            // What the bound learns from: the verified inliers of the hypothesis two back (all waves of the workgroup have
-            // normally added their part by now; the read was issued at the top of the iteration, so nothing waits for it
-            // here, and a value that is late or partial is only a smaller lower bound).  Exchanging bounds between the
-            // pair's workgroups through memory was tried and cost more than the whole kernel (agent-scope loads under
-            // load); after two or three of its 64 hypotheses a workgroup's own bound is nearly as good.
-            bound = max(bound, __builtin_amdgcn_readfirstlane(peek));
-            const float part_sum = wave_sum_to_lane63(acc.x + acc.y);
-            if (lane == 63) s_part[wave * kCntHyps + hh] = part_sum;
-            while (qn >= 64) {   // a hypothesis adds at most 1024 words to the 63 left over: kCntQueue holds them
-                cnt_drain(q, qn - 64, 64, lane, s_rec, s_cnt, P1, P2, PR, threshold);
-                qn -= 64;
-            }
+            k = __builtin_amdgcn_readfirstlane(knext);
         }
-        if (qn > 0) cnt_drain(q, 0, qn, lane, s_rec, s_cnt, P1, P2, PR, threshold);
+        if (qn > 0) cnt_drain(q, 0, qn, lane, s_rec, s_cnt, cx1, cy1, cx2, cy2, threshold);
     }
     __syncthreads();
     if (tid < nh) {
-        hyp_count[(size_t)b * hyp + hbase + tid] = s_drop[tid] ? -1 : s_cnt[tid];   // ransac_ties keeps the maximal ones
-        hyp_sum[(size_t)b * hyp + hbase + tid] = __int_as_float(0x7FC00000);   // defined by ransac_ties / tiesum where it matters
+        const int st = s_state[tid];
+        hyp_count[out] = st == 1 ? s_cnt[tid] : -1;     // ransac_ties keeps the maximal ones
+        hyp_sum[out] = __int_as_float(0x7FC00000);      // defined by ransac_ties / tiesum where it matters
         // The cheap values' sum S~ and a bound on |S~ - (exact double sum of the e)|: per evaluation
         // |g - e| <= 12 u max(g, e) + beta (2 sqrt(g) + beta)  (the derivation above), summed with Cauchy-Schwarz
         // (sum sqrt(g_i) <= sqrt(M sum g_i)), plus 2^-20 S~ for the float additions that formed S~.
-        float S = 0.f;
-        for (int w = 0; w < nw; w++) S += s_part[w * kCntHyps + tid];
+        const float S = s_part[tid];
         float err = INFINITY;
-        if (my_ok && !s_unk[tid]) {
+        if (st == 1 && my_ok && !s_unk[tid]) {
             const double Sd = (double)S;
             err = (float)((2.02 * my_beta * sqrt((double)m * Sd) + (double)m * my_beta * my_beta + 0x1p-18 * Sd) * (1.0 + 0x1p-20));
         }
-        float2 *ap = reinterpret_cast<float2 *>(approx) + (size_t)b * hyp + hbase + tid;
-        *ap = make_float2(S, err);
+        reinterpret_cast<float2 *>(approx)[out] = make_float2(S, err);
     }
 }
 
@@ -1791,26 +2052,45 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         if ((rc = vs_arena_get(ctx, "ransac.approx", sizeof(float) * 2 * (size_t)batch * hyp, (void **)&approx))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.tie_idx", sizeof(int32_t) * (size_t)batch * hyp, (void **)&tie_idx))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.tie_n", sizeof(int32_t) * 2 * (size_t)batch, (void **)&tie_n))) return rc;
-        int32_t *cbound = nullptr;
+        int32_t *cbound = nullptr, *pot0 = nullptr;
+        float *rk = nullptr, *cmax = nullptr;
+        const int kp_pad = cnt_pad(kp_stride);
         if ((rc = vs_arena_get(ctx, "ransac.cbound", sizeof(int32_t) * (size_t)batch, (void **)&cbound))) return rc;
+        if ((rc = vs_arena_get(ctx, "ransac.pot0", sizeof(int32_t) * (size_t)batch * hyp, (void **)&pot0))) return rc;
+        if ((rc = vs_arena_get(ctx, "ransac.rk", sizeof(float) * 4 * (size_t)kp_pad * batch, (void **)&rk))) return rc;
+        if ((rc = vs_arena_get(ctx, "ransac.cmax", sizeof(float) * 2 * (size_t)batch, (void **)&cmax))) return rc;
         VS_HIP(ctx, hipMemsetAsync(cbound, 0, sizeof(int32_t) * (size_t)batch, ctx->stream));
         {
-            VsProfScope ps(ctx, "ransac_pilot_kernel");
-            dim3 grid(min(kPilotHyps, hyp), batch);
-            ransac_pilot_kernel<<<grid, 64, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, threshold, hypF, cbound);
+            VsProfScope ps(ctx, "ransac_rank_kernel");
+            ransac_rank_kernel<<<batch, kRankThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, kp_pad, hyp, threshold, hypF,
+                                                                        cbound, rk, cmax);
+        }
+        {
+            VsProfScope ps(ctx, "ransac_screen_kernel");
+            dim3 grid(vs_div_up(hyp, kScreenHyps), batch);
+            ransac_screen_kernel<<<grid, 256, 0, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, cmax, pot0);
+        }
+        {
+            VsProfScope ps(ctx, "ransac_cand_kernel");
+            ransac_cand_kernel<<<batch, 64 * kCandMax, 0, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0, cbound);
         }
         {
             VsProfScope ps(ctx, "ransac_count_kernel");
-            const int waves = min(kCntMaxWaves, vs_div_up(kp_stride, 1024));
-            const size_t queue_bytes = sizeof(uint32_t) * kCntQueue * waves;
-            if (queue_bytes > 40 * 1024 && !ctx->attr_done["ransac_count"]) {   // beyond the default static + dynamic LDS limit
-                VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_count_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * kCntQueue * kCntMaxWaves)));
+            const bool lds = kp_pad <= kCntLdsMatches;
+            const size_t dyn = (lds ? sizeof(float) * 4 * (size_t)kp_pad : 0) + sizeof(uint32_t) * kCntQueue * kCntWaves;
+            if (dyn > 32 * 1024 && !ctx->attr_done["ransac_count"]) {   // beyond the default static + dynamic LDS limit
+                VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_count_kernel<true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)(sizeof(float) * 4 * kCntLdsMatches + sizeof(uint32_t) * kCntQueue * kCntWaves)));
                 ctx->attr_done["ransac_count"] = true;
             }
             dim3 grid(vs_div_up(hyp, kCntHyps), batch);
-            ransac_count_kernel<<<grid, 64 * waves, queue_bytes, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, threshold, hypF,
-                                                                     hyp_count, hyp_sum, approx, cbound);
+            if (lds)
+                ransac_count_kernel<true><<<grid, 64 * kCntWaves, dyn, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0,
+                                                                                      cmax, hyp_count, hyp_sum, approx, cbound);
+            else
+                ransac_count_kernel<false><<<grid, 64 * kCntWaves, dyn, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0,
+                                                                                       cmax, hyp_count, hyp_sum, approx, cbound);
         }
         {
             VsProfScope ps(ctx, "ransac_ties_kernel");
