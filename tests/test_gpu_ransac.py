@@ -221,9 +221,9 @@ def _compare(out, ref, b, n, mode):
 
 
 def test_counts_first_path_at_scale(ctx, oracle, sums_mode):
-    """The shapes the counting kernel is built around: more than one wave of matches per workgroup (1024 / wave), a
-    partial last sub-block, hypothesis counts that are not a multiple of 64, and thresholds that put many
-    evaluations next to the decision boundary."""
+    """The shapes the counting kernel is built around: several 256-match sub-blocks per hypothesis, a partial last
+    sub-block, hypothesis counts that are not a multiple of a workgroup's 128, thresholds that put many evaluations next
+    to the decision boundary, and more matches than the LDS staging holds (4096: coordinates read from memory)."""
     for K, sizes, Hy, thr in ((2304, [2304, 1500, 1025, 257, 256, 64], 200, 10.0), (2304, [1800, 700], 130, 3.0),
                               (2304, [1200, 2000], 64, 40.0), (16384, [16384, 9000, 4097], 70, 10.0)):
         xy1, xy2, pairs, m = _batch(900 + Hy, sizes, K, 1280, 720)
@@ -231,6 +231,21 @@ def test_counts_first_path_at_scale(ctx, oracle, sums_mode):
         out = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
         for b, n in enumerate(sizes):
             ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], thr)
+            _compare(out, ref, b, n, sums_mode)
+
+
+def test_screen_and_rank_edge_shapes(ctx, oracle, sums_mode):
+    """Shapes around the edges of the ranking / screening stages in front of the counting kernel: fewer hypotheses than
+    pilots (8) or candidates, hypothesis counts around a workgroup's 128, match counts around the screen's 128 and the
+    256-match sub-blocks (the ranked arrays are padded to a multiple of 256)."""
+    for Hy, sizes in ((1, [8, 200]), (3, [127, 128, 129]), (7, [255, 256, 257]), (9, [383, 384, 385]),
+                      (127, [130, 511]), (129, [64, 512, 513]), (257, [100, 300])):
+        K = 520
+        xy1, xy2, pairs, m = _batch(4000 + Hy, sizes, K, 1280, 720)
+        sets = np.stack([oracle.ransac_sets(11 + b, n, Hy) for b, n in enumerate(sizes)])
+        out = _find(ctx, oracle, xy1, xy2, pairs, m, sets, 10.0)
+        for b, n in enumerate(sizes):
+            ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], 10.0)
             _compare(out, ref, b, n, sums_mode)
 
 

@@ -119,12 +119,18 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return VSLAM_ERR_HIP;
     vslam_ctx *ctx = new vslam_ctx();
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    // The auxiliary stream carries work that fills holes beside the main chain (blur, k-d build, generator): the main
+    // stream's workgroups go first whenever both have some ready (VSLAM_STREAM_PRIORITY=0: both at the default priority).
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (const char *e = getenv("VSLAM_STREAM_PRIORITY"))
+        if (e[0] == '0') prio_least = prio_greatest = 0;
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
     ctx->own_stream = true;
-    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete ctx;

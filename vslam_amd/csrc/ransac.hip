@@ -1504,13 +1504,15 @@ __global__ __launch_bounds__(64 * kCntWaves) void ransac_count_kernel(
     __shared__ float s_part[kCntHyps];   // sum of the cheap values
     __shared__ int s_unk[kCntHyps];      // hypothesis whose cheap sum is not certified
     __shared__ int s_state[kCntHyps];    // 0 = ruled out by the screen, 1 = counted in full, 2 = abandoned on the way
-    __shared__ int s_list[kCntHyps];     // survivors of the screen: [0, 64) found by wave 0, [64, 128) by wave 1
-    __shared__ int s_nlist[2], s_next, s_bound;
+    __shared__ int s_list[kCntHyps];     // survivors of the screen: [64 w, 64 w + s_nlist[w]) found by wave w
+    constexpr int kListWaves = kCntHyps / 64;
+    static_assert(kCntHyps % 64 == 0 && kListWaves <= kCntWaves, "whole waves find the survivors");
+    __shared__ int s_nlist[kListWaves], s_next, s_bound;
     extern __shared__ __align__(16) uint32_t s_dyn[];
 
     const int n0 = min(m, kScreenMatches);
     const int bound0 = cbound[b];   // a count some hypothesis of this pair is known to reach (never above the true maximum)
-    if (tid < kCntHyps) {           // waves 0 and 1, whole
+    if (tid < kCntHyps) {           // whole waves
         const bool alive = tid < nh && pot0[(size_t)b * hyp + hbase + tid] + (m - n0) >= bound0;
         s_cnt[tid] = 0;
         s_unk[tid] = 0;
@@ -1525,7 +1527,9 @@ __global__ __launch_bounds__(64 * kCntWaves) void ransac_count_kernel(
         s_bound = bound0;
     }
     __syncthreads();
-    const int n_a = s_nlist[0], n_alive = n_a + s_nlist[1];
+    int n_alive = 0;
+#pragma unroll
+    for (int w = 0; w < kListWaves; w++) n_alive += s_nlist[w];
     const size_t out = (size_t)b * hyp + hbase + tid;
     if (n_alive == 0) {   // the usual case on a pair whose maximum only a few hypotheses reach
         if (tid < nh) {
@@ -1576,7 +1580,12 @@ __global__ __launch_bounds__(64 * kCntWaves) void ransac_count_kernel(
         while (k < n_alive) {
             int knext = 0;
             if (lane == 0) knext = atomicAdd(&s_next, 1);   // consumed at the bottom: the round trip hides behind the work
-            const int hh = k < n_a ? s_list[k] : s_list[64 + k - n_a];
+            int hh;
+            {
+                int kk = k, w = 0;
+                while (w + 1 < kListWaves && kk >= s_nlist[w]) kk -= s_nlist[w++];
+                hh = s_list[w * 64 + kk];
+            }
             bound = max(bound, *(__attribute__((address_space(3))) const volatile int *)&s_bound);
             CntRec R;
             cnt_load_record(R, s_rec, hh);
