@@ -62,6 +62,12 @@ struct BlurArgs {
     bool edge, left_fix, right_fix, own_lane;
 };
 
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int K>   // K = t % 7: ring slot of both the filtered row and the prefetched gray row
 __device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int t) {
     constexpr uint32_t W0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // taps 0..3
@@ -69,13 +75,20 @@ __device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int 
     uint32_t d0 = st.raw[K][0];
     const uint32_t d1 = st.raw[K][1];
     uint32_t d2 = st.raw[K][2];
-    if (t + 7 < a.steps) {   // the row seven steps ahead goes into the slot just consumed
-        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + t + 7, a.h) * a.w;
-        st.raw[K][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
-        st.raw[K][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
-        st.raw[K][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+    {   // The row seven steps ahead goes into the slot just consumed (past the segment's last step the index is clamped:
+        // a redundant load costs less than the register copies a conditional one brings).  The lane offsets are made
+        // opaque so that their zero-extension is not hoisted into 64-bit register pairs: base in SGPRs + 32-bit lane
+        // offset is an addressing mode, a 64-bit vector add is an instruction per load.
+        const int tn = t + 7 < a.steps ? t + 7 : a.steps - 1;
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.w;
+        uint32_t ol = a.voff_l, oc = a.voff_c, orr = a.voff_r;
+        asm volatile("" : "+v"(ol), "+v"(oc), "+v"(orr));
+        st.raw[K][0] = *reinterpret_cast<const uint32_t *>(rowp + ol);
+        st.raw[K][1] = *reinterpret_cast<const uint32_t *>(rowp + oc);
+        st.raw[K][2] = *reinterpret_cast<const uint32_t *>(rowp + orr);
     }
     if (a.edge) {   // BORDER_REFLECT_101: columns -3..-1 are 3..1, columns w..w+2 are w-2..w-4
+        asm volatile("" ::: "memory");   // keep this a branch (uniform per wave): as selects it would cost every strip
         if (a.left_fix) d0 = __builtin_amdgcn_perm(d1, d1, 0x01020300u);
         if (a.right_fix) d2 = __builtin_amdgcn_perm(d1, d1, 0x00000102u);
     }
@@ -88,14 +101,25 @@ __device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int 
     st.rp[K][3] = __builtin_amdgcn_udot4(d1, W0, __builtin_amdgcn_udot4(d2, W1, 0u, false), false);
     if (t < 6) return;
     const int y = a.ys - 6 + t;
-    uint32_t packed = 0;
+    // column pass: v_mad_u32_u24 chains (every operand is below 2^24), the rounding constant rides in as the first
+    // addend, and the result byte (bits 16..23 of the sum, which is below 2^24) is picked with v_perm_b32
+    uint32_t sum[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const uint32_t sum = 18u * (st.rp[(K + 1) % 7][i] + st.rp[K][i]) + 34u * (st.rp[(K + 2) % 7][i] + st.rp[(K + 6) % 7][i]) +
-                             48u * (st.rp[(K + 3) % 7][i] + st.rp[(K + 5) % 7][i]) + 56u * st.rp[(K + 4) % 7][i];
-        packed |= ((sum + (1u << 15)) >> 16) << (8 * i);
+        uint32_t acc = mad_u24(st.rp[(K + 1) % 7][i] + st.rp[K][i], 18u, 1u << 15);
+        acc = mad_u24(st.rp[(K + 2) % 7][i] + st.rp[(K + 6) % 7][i], 34u, acc);
+        acc = mad_u24(st.rp[(K + 3) % 7][i] + st.rp[(K + 5) % 7][i], 48u, acc);
+        sum[i] = mad_u24(st.rp[(K + 4) % 7][i], 56u, acc);
     }
-    if (a.own_lane) *reinterpret_cast<uint32_t *>(a.dst + (size_t)y * a.w + a.x) = packed;
+    const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);   // bytes: sum0[2], sum1[2], 0, 0
+    const uint32_t hi = __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);   // bytes: 0, 0, sum2[2], sum3[2]
+    const uint32_t packed = lo | hi;
+    if (a.own_lane) {
+        uint8_t *rowd = a.dst + (size_t)y * a.w;   // uniform base + 32-bit lane offset, as for the loads
+        uint32_t ox = (uint32_t)a.x;
+        asm volatile("" : "+v"(ox));
+        *reinterpret_cast<uint32_t *>(rowd + ox) = packed;
+    }
 }
 
 __global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
