@@ -14,27 +14,44 @@ LIB = os.path.join(HERE, "libvslam_amd.so")
 SOURCES = ["capi.hip", "match.hip", "ransac.hip", "kdtree.hip", "gray.hip", "response.hip", "select.hip", "blur.hip",
            "brief.hip", "orb_grid.hip", "pose.hip", "assoc.hip"]
 HEADERS = ["ctx.h", "introselect.h", "image_common.h", os.path.join("..", "..", "include", "vslam_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
+# Per-file additions.  response.hip: the SLP vectoriser pairs the stencil's float operations into v_pk_* forms whose
+# operands it then has to assemble with v_mov (a packed op issues for two slots, so the copies are a net loss: min_eigen
+# 1.131 -> 1.116 ms without it); the RANSAC kernels, whose packed math is written out by hand, are faster with it on.
+EXTRA_FLAGS = {"response.hip": ["-fno-slp-vectorize"]}
+OBJDIR = os.path.join(HERE, "_obj")
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+def _compile(hipcc, src, verbose):
+    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+        return obj, None
+    cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", "-o", obj, src]
+    if verbose:
+        print(" ".join(cmd))
+    return obj, subprocess.Popen(cmd, cwd=CSRC)
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+    """Every source is its own translation unit (no device code crosses files), compiled in parallel, then linked."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    os.makedirs(OBJDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJDIR):
+            os.remove(os.path.join(OBJDIR, f))
+    jobs = [_compile(hipcc, src, verbose) for src in SOURCES]
+    failed = [obj for obj, proc in jobs if proc is not None and proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c (" + ", ".join(os.path.basename(f) for f in failed) + ")")
+    objs = [obj for obj, _ in jobs]
+    if os.path.exists(LIB) and all(proc is None for _, proc in jobs) and all(
+            os.path.getmtime(o) <= os.path.getmtime(LIB) for o in objs):
+        return LIB
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, cwd=CSRC, check=True)
+    subprocess.run(cmd, check=True)
     return LIB
 
 

@@ -308,11 +308,17 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
     uint32_t d0 = st.raw[K][0];
     const uint32_t d1 = st.raw[K][1];
     uint32_t d2 = st.raw[K][2];
-    if (t + 3 < a.steps) {   // prefetch the row three steps ahead into the slot just consumed
-        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + t + 3, a.h) * a.w;
-        st.raw[K][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
-        st.raw[K][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
-        st.raw[K][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+    {   // Prefetch the row three steps ahead into the slot just consumed (past the segment's last step the index is
+        // clamped: a redundant load costs less than the register copies a conditional one brings).  The lane offsets
+        // are made opaque so that their zero-extension is not hoisted into 64-bit register pairs: base in SGPRs +
+        // 32-bit lane offset is an addressing mode, a 64-bit vector add is an instruction per load.
+        const int tn = t + 3 < a.steps ? t + 3 : a.steps - 1;
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.w;
+        uint32_t ol = a.voff_l, oc = a.voff_c, orr = a.voff_r;
+        asm volatile("" : "+v"(ol), "+v"(oc), "+v"(orr));
+        st.raw[K][0] = *reinterpret_cast<const uint32_t *>(rowp + ol);
+        st.raw[K][1] = *reinterpret_cast<const uint32_t *>(rowp + oc);
+        st.raw[K][2] = *reinterpret_cast<const uint32_t *>(rowp + orr);
     }
     if (a.edge) {   // BORDER_REFLECT_101 in x: columns -2, -1 are columns 2, 1; columns w, w+1 are w-2, w-3
         if (a.left_fix) d0 = (d1 & 0x00FF0000u) | ((d1 & 0x0000FF00u) << 16);
