@@ -323,19 +323,26 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
             // mask) and goes back to LDS once per i.  Same operations on the same values as reading both rows per
             // pair, so the bits do not change; the LDS traffic halves (1.03 -> 0.97 ms at C3).  Fetching row j + 1
             // ahead of time on top of that was slower (1.06 ms), and the 3x3 instance is faster with the plain form.
+            // So do its double conversions and its squared norm W[i]: both are functions of the current row only, and are
+            // redone (same operations, same order) where a rotation changes it.
             float ai[M];
+            double dai[M];
+            double a = 0;   // W[i]
 #pragma unroll
-            for (int k = 0; k < M; k++) ai[k] = VS_A(i, k);
+            for (int k = 0; k < M; k++) {
+                ai[k] = VS_A(i, k);
+                dai[k] = (double)ai[k];
+                a = __builtin_fma(dai[k], dai[k], a);
+            }
             for (int j = i + 1; j < N; j++) {
                 float aj[M];
 #pragma unroll
                 for (int k = 0; k < M; k++) aj[k] = VS_A(j, k);
-                double a = 0, p = 0, b = 0;
+                double p = 0, b = 0;
 #pragma unroll
                 for (int k = 0; k < M; k++) {
-                    const double di = (double)ai[k], dj = (double)aj[k];
-                    p = __builtin_fma(di, dj, p);
-                    a = __builtin_fma(di, di, a);   // W[i]
+                    const double dj = (double)aj[k];
+                    p = __builtin_fma(dai[k], dj, p);
                     b = __builtin_fma(dj, dj, b);   // W[j]
                 }
                 if (jacobi_converged(p, a, b)) continue;
@@ -367,12 +374,15 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
                         s = (float)(p / (gamma * (double)c * 2));
                     }
                 }
+                a = 0;
 #pragma unroll
                 for (int k = 0; k < M; k++) {
                     const float t0 = c * ai[k] + s * aj[k];
                     const float t1 = (-s) * ai[k] + c * aj[k];
                     ai[k] = t0;
                     VS_A(j, k) = t1;
+                    dai[k] = (double)t0;
+                    a = __builtin_fma(dai[k], dai[k], a);
                 }
                 changed = true;
                 if (HASV) {
