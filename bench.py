@@ -76,7 +76,8 @@ INT8_MFMA_PEAK_TOPS = 5000.0                   # dense int8 MFMA (MI355X_MICROAR
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
 ALG_OPS = {
     # kernel: (what one unit is, algorithmic ops per unit, kind, peak in Tops/s)
-    "ransac_count_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop", FP32_PEAK_TFLOPS),
+    # ransac_count_kernel has no entry: it decides most (hypothesis, match) pairs without evaluating them (bail-out),
+    # so SURVEY's H x M x 40 flop is not work it performs and a flop fraction of it would mean nothing
     "ransac_score_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop", FP32_PEAK_TFLOPS),
     "ransac_solve_kernel": ("hypotheses (two SVDs, about 3000 flop each: SURVEY.md 8d)", 3000.0, "flop", FP32_PEAK_TFLOPS),
     "min_eigen_kernel": ("pixels (stencil work, about 60 int/flop per pixel: SURVEY.md 8d)", 60.0, "flop", FP32_PEAK_TFLOPS),
