@@ -271,7 +271,11 @@ constexpr int kSW = 256;     // pixels per strip (64 lanes x 4), all owned
 constexpr int kSQ = 512;     // candidate queue entries per wave
 struct StreamState {
     float hx[3][6], rr[3][6];      // per gray row: x-derivative parts and smoothed values, columns x-1 .. x+4
-    double S[3][12];               // per product row: horizontal 3-sums of xx, xy, yy for the lane's 4 pixels
+    double T[12], Rp[12];          // horizontal 3-sums of xx, xy, yy for the lane's 4 pixels: Rp = those of the previous
+                                   // product row, T = (row before that) + Rp.  Two rows' worth of state instead of
+                                   // three (24 registers: the difference between 2 and 3 waves per SIMD) for a
+                                   // register copy per value and step; the additions and their order are unchanged:
+                                   // S(y) = (r(y-1) + r(y)) + r(y+1) = T + r(y+1)
     float ctr[3][4], hm[3][4];     // per response row: the values and their horizontal 3-maxima
     uint32_t raw[3][3];            // prefetched gray dwords (x-4, x, x+4) of the next three rows
     float emax;
@@ -358,26 +362,39 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
         if (a.left_fix) cxy[0] = -cxy[0];
         if (a.right_fix) cxy[5] = -cxy[5];
     }
+    double r[12];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        st.S[K][i] = ((double)cxx[i] + (double)cxx[i + 1]) + (double)cxx[i + 2];
-        st.S[K][4 + i] = ((double)cxy[i] + (double)cxy[i + 1]) + (double)cxy[i + 2];
-        st.S[K][8 + i] = ((double)cyy[i] + (double)cyy[i + 1]) + (double)cyy[i + 2];
+        r[i] = ((double)cxx[i] + (double)cxx[i + 1]) + (double)cxx[i + 2];
+        r[4 + i] = ((double)cxy[i] + (double)cxy[i + 1]) + (double)cxy[i + 2];
+        r[8 + i] = ((double)cyy[i] + (double)cyy[i + 1]) + (double)cyy[i + 2];
     }
     if (rowflip) {   // mirrored row (two per frame): same rule; negating the sums equals summing the negated products
         asm volatile("" ::: "memory");   // keep this a branch: as selects it would cost every row
 #pragma unroll
-        for (int i = 0; i < 4; i++) st.S[K][4 + i] = -st.S[K][4 + i];
+        for (int i = 0; i < 4; i++) r[4 + i] = -r[4 + i];
+    }
+    float sx[4], sxy4[4], sy[4];
+    if (t >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // column sums S(y) = (r(y-1) + r(y)) + r(y+1)
+            sx[i] = (float)(st.T[i] + r[i]);
+            sxy4[i] = (float)(st.T[4 + i] + r[4 + i]);
+            sy[i] = (float)(st.T[8 + i] + r[8 + i]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; e++) {
+        st.T[e] = st.Rp[e] + r[e];
+        st.Rp[e] = r[e];
     }
     if (t >= 4) {
         const int y = a.ys - 5 + t;
         float apc[4], tt[4], rt[4], e4[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            // column sums S(y) = (r(y-1) + r(y)) + r(y+1), rows in slots K2, K1, K
-            const float sxx = (float)((st.S[K2][i] + st.S[K1][i]) + st.S[K][i]);
-            const float sxy = (float)((st.S[K2][4 + i] + st.S[K1][4 + i]) + st.S[K][4 + i]);
-            const float syy = (float)((st.S[K2][8 + i] + st.S[K1][8 + i]) + st.S[K][8 + i]);
+            const float sxx = sx[i], sxy = sxy4[i], syy = sy[i];
             const float ea = sxx * 0.5f, eb = sxy, ec = syy * 0.5f;
             const float amc = ea - ec;
             tt[i] = amc * amc + eb * eb;
@@ -427,7 +444,7 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
     }
 }
 
-__global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void min_eigen_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
                                                                float *__restrict__ edge, uint32_t *__restrict__ frame_max,
                                                                double quality, unsigned long long *__restrict__ keys,
                                                                uint32_t *__restrict__ counts, size_t key_cap, int seg_rows,
@@ -473,9 +490,7 @@ __global__ __launch_bounds__(256) void min_eigen_stream_kernel(const uint8_t *__
     StreamState st;
     st.emax = ninf;
 #pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int i = 0; i < 12; i++) st.S[k][i] = 0.0;
+    for (int i = 0; i < 12; i++) st.T[i] = st.Rp[i] = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
