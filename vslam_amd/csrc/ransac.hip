@@ -232,11 +232,155 @@ __device__ __forceinline__ double div_inrange(double x, double y) {
     return __builtin_fma(e, r, q);
 }
 
+// Everything after the sweeps: W, the descending sort (rows travel with W), normalisation / regeneration of the rows,
+// the row beyond the rank.  The matrix is reached through pA / pV with element stride SA, so the same code runs on a
+// lane's LDS columns (SA = kSolveThreads) and on a private copy (SA = 1).
+#define FA(r, k) pA[((r) * M + (k)) * SA]
+#define FV(r, k) pV[((r) * N + (k)) * SA]
+template <int M, int N, int N1, bool HASV, int SA>
+__device__ __forceinline__ void jacobi_finish(float *pA, float *pV, float *wout, float *extra_row) {
+    const double minval = FLT_MIN;
+    const float eps = FLT_EPSILON * 2;
+    double W[N];   // singular values: registers, every index below is compile-time
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            const float t = FA(i, k);
+            sd = __builtin_fma((double)t, (double)t, sd);
+        }
+        W[i] = sqrt(sd);
+    }
+
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {   // selection sort, descending, rows travel with W
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+            if (wj < W[k]) {
+                j = k;
+                wj = W[k];
+            }
+        if (i != j) {
+#pragma unroll
+            for (int jj = i + 1; jj < N; jj++)
+                if (jj == j) W[jj] = W[i];
+            W[i] = wj;
+#pragma unroll
+            for (int k = 0; k < M; k++) {
+                const float x = FA(i, k), y = FA(j, k);
+                FA(i, k) = y;
+                FA(j, k) = x;
+            }
+            if (HASV) {
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const float x = FV(i, k), y = FV(j, k);
+                    FV(i, k) = y;
+                    FV(j, k) = x;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < N; i++) wout[i] = (float)W[i];
+
+    uint64_t rng = 0x12345678ull;
+    for (int i = 0; i < N; i++) {
+        double sd = 0;   // W[i] again: the sorted row's norm
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            const float t = FA(i, k);
+            sd = __builtin_fma((double)t, (double)t, sd);
+        }
+        sd = sqrt(sd);
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const float val0 = (float)(1. / M);
+#pragma unroll
+            for (int k = 0; k < M; k++) FA(i, k) = (cvrng_next(rng) & 256) != 0 ? val0 : -val0;
+            for (int iter = 0; iter < 2; iter++) {
+                for (int j = 0; j < i; j++) {
+                    float vi[M], vj[M];
+                    sd = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        vi[k] = FA(i, k);
+                        vj[k] = FA(j, k);
+                        sd += (double)(vi[k] * vj[k]);   // float product, double running sum
+                    }
+                    float asum = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        const float t = (float)((double)vi[k] - sd * (double)vj[k]);
+                        vi[k] = t;
+                        asum += fabsf(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) FA(i, k) = vi[k] * asum;
+                }
+            }
+            sd = 0;
+#pragma unroll
+            for (int k = 0; k < M; k++) {
+                const float t = FA(i, k);
+                sd = __builtin_fma((double)t, (double)t, sd);
+            }
+            sd = sqrt(sd);
+        }
+        const float s = (float)(sd > minval ? 1 / sd : 0.);
+#pragma unroll
+        for (int k = 0; k < M; k++) FA(i, k) = FA(i, k) * s;
+    }
+    if (N1 > N) {
+        // the row beyond the rank (FULL_UV): same procedure with i = N, W = 0; it lives in registers,
+        // which keeps the per-lane LDS footprint at N rows
+        float v[M];
+        double sd = 0;
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const float val0 = (float)(1. / M);
+#pragma unroll
+            for (int k = 0; k < M; k++) v[k] = (cvrng_next(rng) & 256) != 0 ? val0 : -val0;
+            for (int iter = 0; iter < 2; iter++) {
+                for (int j = 0; j < N; j++) {
+                    float vj[M];
+                    sd = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        vj[k] = FA(j, k);
+                        sd += (double)(v[k] * vj[k]);
+                    }
+                    float asum = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        const float t = (float)((double)v[k] - sd * (double)vj[k]);
+                        v[k] = t;
+                        asum += fabsf(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) v[k] = v[k] * asum;
+                }
+            }
+            sd = 0;
+#pragma unroll
+            for (int k = 0; k < M; k++) sd = __builtin_fma((double)v[k], (double)v[k], sd);
+            sd = sqrt(sd);
+        }
+        const float s = (float)(sd > minval ? 1 / sd : 0.);
+#pragma unroll
+        for (int k = 0; k < M; k++) extra_row[k] = v[k] * s;
+    }
+}
+#undef FA
+#undef FV
+
 template <int M, int N, int N1, bool HASV, bool ROWREG = false>
 __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, float *extra_row) {
     static_assert(N1 == N || N1 == N + 1, "FULL_UV asks for at most one row beyond the rank here");
-    const double minval = FLT_MIN;
-    const float eps = FLT_EPSILON * 2;
     constexpr int max_iter = M > 30 ? M : 30;
 
     if (HASV) {
@@ -403,139 +547,7 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
     }
 
     }
-    double W[N];   // singular values: registers, every index below is compile-time
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        double sd = 0;
-#pragma unroll
-        for (int k = 0; k < M; k++) {
-            const float t = VS_A(i, k);
-            sd = __builtin_fma((double)t, (double)t, sd);
-        }
-        W[i] = sqrt(sd);
-    }
-
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) {   // selection sort, descending, rows travel with W
-        int j = i;
-        double wj = W[i];
-#pragma unroll
-        for (int k = i + 1; k < N; k++)
-            if (wj < W[k]) {
-                j = k;
-                wj = W[k];
-            }
-        if (i != j) {
-#pragma unroll
-            for (int jj = i + 1; jj < N; jj++)
-                if (jj == j) W[jj] = W[i];
-            W[i] = wj;
-#pragma unroll
-            for (int k = 0; k < M; k++) {
-                const float x = VS_A(i, k), y = VS_A(j, k);
-                VS_A(i, k) = y;
-                VS_A(j, k) = x;
-            }
-            if (HASV) {
-#pragma unroll
-                for (int k = 0; k < N; k++) {
-                    const float x = VS_V(i, k), y = VS_V(j, k);
-                    VS_V(i, k) = y;
-                    VS_V(j, k) = x;
-                }
-            }
-        }
-    }
-
-#pragma unroll
-    for (int i = 0; i < N; i++) wout[i] = (float)W[i];
-
-    uint64_t rng = 0x12345678ull;
-    for (int i = 0; i < N; i++) {
-        double sd = 0;   // W[i] again: the sorted row's norm
-#pragma unroll
-        for (int k = 0; k < M; k++) {
-            const float t = VS_A(i, k);
-            sd = __builtin_fma((double)t, (double)t, sd);
-        }
-        sd = sqrt(sd);
-        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-            const float val0 = (float)(1. / M);
-#pragma unroll
-            for (int k = 0; k < M; k++) VS_A(i, k) = (cvrng_next(rng) & 256) != 0 ? val0 : -val0;
-            for (int iter = 0; iter < 2; iter++) {
-                for (int j = 0; j < i; j++) {
-                    float vi[M], vj[M];
-                    sd = 0;
-#pragma unroll
-                    for (int k = 0; k < M; k++) {
-                        vi[k] = VS_A(i, k);
-                        vj[k] = VS_A(j, k);
-                        sd += (double)(vi[k] * vj[k]);   // float product, double running sum
-                    }
-                    float asum = 0;
-#pragma unroll
-                    for (int k = 0; k < M; k++) {
-                        const float t = (float)((double)vi[k] - sd * (double)vj[k]);
-                        vi[k] = t;
-                        asum += fabsf(t);
-                    }
-                    asum = asum > eps * 100 ? 1 / asum : 0;
-#pragma unroll
-                    for (int k = 0; k < M; k++) VS_A(i, k) = vi[k] * asum;
-                }
-            }
-            sd = 0;
-#pragma unroll
-            for (int k = 0; k < M; k++) {
-                const float t = VS_A(i, k);
-                sd = __builtin_fma((double)t, (double)t, sd);
-            }
-            sd = sqrt(sd);
-        }
-        const float s = (float)(sd > minval ? 1 / sd : 0.);
-#pragma unroll
-        for (int k = 0; k < M; k++) VS_A(i, k) = VS_A(i, k) * s;
-    }
-    if (N1 > N) {
-        // the row beyond the rank (FULL_UV): same procedure with i = N, W = 0; it lives in registers,
-        // which keeps the per-lane LDS footprint at N rows
-        float v[M];
-        double sd = 0;
-        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-            const float val0 = (float)(1. / M);
-#pragma unroll
-            for (int k = 0; k < M; k++) v[k] = (cvrng_next(rng) & 256) != 0 ? val0 : -val0;
-            for (int iter = 0; iter < 2; iter++) {
-                for (int j = 0; j < N; j++) {
-                    float vj[M];
-                    sd = 0;
-#pragma unroll
-                    for (int k = 0; k < M; k++) {
-                        vj[k] = VS_A(j, k);
-                        sd += (double)(v[k] * vj[k]);
-                    }
-                    float asum = 0;
-#pragma unroll
-                    for (int k = 0; k < M; k++) {
-                        const float t = (float)((double)v[k] - sd * (double)vj[k]);
-                        v[k] = t;
-                        asum += fabsf(t);
-                    }
-                    asum = asum > eps * 100 ? 1 / asum : 0;
-#pragma unroll
-                    for (int k = 0; k < M; k++) v[k] = v[k] * asum;
-                }
-            }
-            sd = 0;
-#pragma unroll
-            for (int k = 0; k < M; k++) sd = __builtin_fma((double)v[k], (double)v[k], sd);
-            sd = sqrt(sd);
-        }
-        const float s = (float)(sd > minval ? 1 / sd : 0.);
-#pragma unroll
-        for (int k = 0; k < M; k++) extra_row[k] = v[k] * s;
-    }
+    jacobi_finish<M, N, N1, HASV, kSolveThreads>(sA + tid, HASV ? sV + tid : nullptr, wout, extra_row);
 }
 
 // One lane per hypothesis, one wave per workgroup.  grid = (ceil(hyp / 64), batch).
