@@ -173,7 +173,6 @@ __global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *
 // compute_fundamental: OpenCV JacobiSVDImpl_<float> on per-lane matrices held in LDS
 // ------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 64;
-constexpr int kSolveFloats = 72;    // 8 rows x 9 (the FULL_UV null-space row stays in registers)
 
 __device__ __forceinline__ uint32_t cvrng_next(uint64_t &state) {   // cv::RNG (MWC)
     state = (uint64_t)(uint32_t)state * 4164903690ull + (uint32_t)(state >> 32);
@@ -550,8 +549,212 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
     jacobi_finish<M, N, N1, HASV, kSolveThreads>(sA + tid, HASV ? sV + tid : nullptr, wout, extra_row);
 }
 
+// ------------------------------------------------------------------------------------------
+// The 8 x 9 instance as ransac_solve_kernel runs it: rows 0..4 of a lane's matrix in LDS, rows 5..7 in registers.
+// ------------------------------------------------------------------------------------------
+// 72 floats per lane in LDS hold the kernel at 8 waves per CU (2 per SIMD) and it is VALU-bound with dependent f64
+// chains, where a third wave pays (min_eigen: 2 -> 3 waves per SIMD was worth 18 %).  45 floats per lane fit 12 waves.
+// Every operation on every value is the one jacobi_svd_lanes<9, 8, 9, false, true> performs, in the same order.
+constexpr int kSolveLdsRows = 5;
+constexpr int kSolveSplitFloats = kSolveLdsRows * 9;
+
+// one (i, j) step on two rows held in registers.  Returns whether this lane rotated (the rows are then the rotated ones).
+// (Keeping row i's double conversions and norm across the j's, as the LDS form does, costs 20 registers here: with three
+// rows resident the registers are worth more than the 18 instructions a step without rotation would save.)
+__device__ __forceinline__ bool jacobi_pair_9(float (&ai)[9], float (&aj)[9]) {
+    double a = 0, p = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const double di = (double)ai[k], dj = (double)aj[k];
+        p = __builtin_fma(di, dj, p);
+        a = __builtin_fma(di, di, a);   // W[i]
+        b = __builtin_fma(dj, dj, b);   // W[j]
+    }
+    if (jacobi_converged(p, a, b)) return false;
+    p *= 2;
+    const double beta = a - b;
+    const double g2 = p * p + beta * beta;
+    float c, s;
+    // see jacobi_svd_lanes for the range argument
+    const bool safe = g2 > 0x1p-400 && g2 < 0x1p400 && fabs(p) > 0x1p-300;
+    if (!__any(!safe)) {
+        const double gamma = sqrt_inrange(g2);   // pinned hypot
+        if (beta < 0) {
+            const double delta = (gamma - beta) * 0.5;
+            s = (float)sqrt_inrange(div_inrange(delta, gamma));
+            c = (float)div_inrange(p, gamma * (double)s * 2);
+        } else {
+            c = (float)sqrt_inrange(div_inrange(gamma + beta, gamma * 2));
+            s = (float)div_inrange(p, gamma * (double)c * 2);
+        }
+    } else {
+        const double gamma = sqrt(g2);   // pinned hypot
+        if (beta < 0) {
+            const double delta = (gamma - beta) * 0.5;
+            s = (float)sqrt(delta / gamma);
+            c = (float)(p / (gamma * (double)s * 2));
+        } else {
+            c = (float)sqrt((gamma + beta) / (gamma * 2));
+            s = (float)(p / (gamma * (double)c * 2));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const float t0 = c * ai[k] + s * aj[k];
+        const float t1 = (-s) * ai[k] + c * aj[k];
+        ai[k] = t0;
+        aj[k] = t1;
+    }
+    return true;
+}
+
+// one sweep over all pairs in OpenCV's order; pA = this lane's LDS column (element (r, k) at pA[(9 r + k) * 64])
+__device__ __forceinline__ bool jacobi_sweep_8x9_split(float *pA, float (&R5)[9], float (&R6)[9], float (&R7)[9]) {
+    bool changed = false;
+    for (int i = 0; i < kSolveLdsRows; i++) {
+        float ai[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) ai[k] = pA[(i * 9 + k) * kSolveThreads];
+        for (int j = i + 1; j < kSolveLdsRows; j++) {
+            float aj[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) aj[k] = pA[(j * 9 + k) * kSolveThreads];
+            if (jacobi_pair_9(ai, aj)) {
+                changed = true;
+#pragma unroll
+                for (int k = 0; k < 9; k++) pA[(j * 9 + k) * kSolveThreads] = aj[k];
+            }
+        }
+        changed |= jacobi_pair_9(ai, R5);
+        changed |= jacobi_pair_9(ai, R6);
+        changed |= jacobi_pair_9(ai, R7);
+#pragma unroll
+        for (int k = 0; k < 9; k++) pA[(i * 9 + k) * kSolveThreads] = ai[k];
+    }
+    changed |= jacobi_pair_9(R5, R6);
+    changed |= jacobi_pair_9(R5, R7);
+    changed |= jacobi_pair_9(R6, R7);
+    return changed;
+}
+
+// After the sweeps: V_t.row(8) of SVDecomp(A 8x9, FULL_UV) = the row beyond the rank, orthogonalised against the sorted,
+// normalised rows (jacobi_finish<9, 8, 9, false, .> with only extra_row kept).  If a row's norm does not exceed FLT_MIN
+// OpenCV regenerates that row from its RNG stream first (degenerate samples): any lane in that case sends the wave
+// through jacobi_finish itself on a private copy.  Otherwise a row's normalisation factor is a function of that row alone
+// and the sort only fixes the ORDER in which the rows are visited, so nothing has to move: rowid[ii] = the row at sorted
+// position ii.
+__device__ __forceinline__ void jacobi_null_row_8x9_split(float *pA, float (&R5)[9], float (&R6)[9], float (&R7)[9], float *f0) {
+    constexpr int M = 9, N = 8;
+    const double minval = FLT_MIN;
+    const float eps = FLT_EPSILON * 2;
+    double W[N];
+    bool tiny = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            const float t = i < kSolveLdsRows ? pA[(i * 9 + k) * kSolveThreads] : (i == 5 ? R5[k] : (i == 6 ? R6[k] : R7[k]));
+            sd = __builtin_fma((double)t, (double)t, sd);
+        }
+        W[i] = sqrt(sd);
+        tiny = tiny || W[i] <= minval;
+    }
+    if (__any(tiny)) {
+        float rows[N * M], w8[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int k = 0; k < M; k++)
+                rows[i * M + k] = i < kSolveLdsRows ? pA[(i * 9 + k) * kSolveThreads] : (i == 5 ? R5[k] : (i == 6 ? R6[k] : R7[k]));
+        jacobi_finish<9, 8, 9, false, 1>(rows, nullptr, w8, f0);
+        return;
+    }
+    // normalise (RansacFilter's rows are OpenCV's: row *= (float)(1 / W), W = the row's norm)
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float s = (float)(1 / W[i]);
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            if (i < kSolveLdsRows) pA[(i * 9 + k) * kSolveThreads] = pA[(i * 9 + k) * kSolveThreads] * s;
+            else if (i == 5) R5[k] = R5[k] * s;
+            else if (i == 6) R6[k] = R6[k] * s;
+            else R7[k] = R7[k] * s;
+        }
+    }
+    // the descending selection sort, on (W, row id) pairs
+    int rowid[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) rowid[i] = i;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+            if (wj < W[k]) {
+                j = k;
+                wj = W[k];
+            }
+        if (i != j) {
+            const int ri = rowid[i];
+            int rj = ri;
+#pragma unroll
+            for (int jj = i + 1; jj < N; jj++)
+                if (jj == j) {
+                    W[jj] = W[i];
+                    rj = rowid[jj];
+                    rowid[jj] = ri;
+                }
+            W[i] = wj;
+            rowid[i] = rj;
+        }
+    }
+    // the row beyond the rank: jacobi_finish's N1 > N block, rows visited in sorted order
+    uint64_t rng = 0x12345678ull;
+    float v[M];
+    double sd = 0;
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+        const float val0 = (float)(1. / M);
+#pragma unroll
+        for (int k = 0; k < M; k++) v[k] = (cvrng_next(rng) & 256) != 0 ? val0 : -val0;
+        for (int iter = 0; iter < 2; iter++) {
+#pragma unroll
+            for (int jj = 0; jj < N; jj++) {
+                const int r = rowid[jj];
+                const int rl = r < kSolveLdsRows ? r : 0;
+                float vj[M];
+                sd = 0;
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    const float l = pA[(rl * 9 + k) * kSolveThreads];
+                    vj[k] = r == 5 ? R5[k] : (r == 6 ? R6[k] : (r == 7 ? R7[k] : l));
+                    sd += (double)(v[k] * vj[k]);   // float product, double running sum
+                }
+                float asum = 0;
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    const float t = (float)((double)v[k] - sd * (double)vj[k]);
+                    v[k] = t;
+                    asum += fabsf(t);
+                }
+                asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+                for (int k = 0; k < M; k++) v[k] = v[k] * asum;
+            }
+        }
+        sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) sd = __builtin_fma((double)v[k], (double)v[k], sd);
+        sd = sqrt(sd);
+    }
+    const float s = (float)(sd > minval ? 1 / sd : 0.);
+#pragma unroll
+    for (int k = 0; k < M; k++) f0[k] = v[k] * s;
+}
+
 // One lane per hypothesis, one wave per workgroup.  grid = (ceil(hyp / 64), batch).
-__global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
+__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void ransac_solve_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, const int32_t *__restrict__ sets, int kp_stride, int hyp,
     float *__restrict__ hypF) {
@@ -559,7 +762,7 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
     const int h = blockIdx.x * kSolveThreads + tid;
     if (m_arr[b] < VSLAM_SET_SIZE) return;   // uniform per workgroup
 
-    __shared__ float sA[kSolveFloats * kSolveThreads];
+    __shared__ float sA[kSolveSplitFloats * kSolveThreads];
 
     const bool live = h < hyp;
     const int hc = live ? h : hyp - 1;   // idle lanes redo the last hypothesis; no divergence in barriers
@@ -568,6 +771,7 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
     const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
     const int32_t *S = sets + ((size_t)b * hyp + hc) * VSLAM_SET_SIZE;
 
+    float R5[9], R6[9], R7[9];
     {   // design matrix, RansacFilter.cpp:75-90
         constexpr int M = 9;
 #pragma unroll
@@ -575,20 +779,24 @@ __global__ __launch_bounds__(kSolveThreads) void ransac_solve_kernel(
             const int2 pr = PR[S[r]];
             const float2 a = P1[pr.x], c = P2[pr.y];
             const float u1 = a.x, v1 = a.y, u2 = c.x, v2 = c.y;
-            VS_A(r, 0) = u2 * u1;
-            VS_A(r, 1) = u2 * v1;
-            VS_A(r, 2) = u2;
-            VS_A(r, 3) = v2 * u1;
-            VS_A(r, 4) = v2 * v1;
-            VS_A(r, 5) = v2;
-            VS_A(r, 6) = u1;
-            VS_A(r, 7) = v1;
-            VS_A(r, 8) = 1.f;
+            const float row[9] = {u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, 1.f};
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                if (r < kSolveLdsRows) VS_A(r, k) = row[k];
+                else if (r == 5) R5[k] = row[k];
+                else if (r == 6) R6[k] = row[k];
+                else R7[k] = row[k];
+            }
         }
     }
 
-    float w8[8], f0[9];
-    jacobi_svd_lanes<9, 8, 9, false, true>(sA, nullptr, tid, w8, f0);   // SVDecomp(A 8x9), :94; f0 = V_t.row(8), :95
+    float f0[9];
+    {   // SVDecomp(A 8x9), :94; f0 = V_t.row(8), :95
+        constexpr int max_iter = 30;
+        for (int iter = 0; iter < max_iter; iter++)
+            if (!jacobi_sweep_8x9_split(sA + tid, R5, R6, R7)) break;
+        jacobi_null_row_8x9_split(sA + tid, R5, R6, R7, f0);
+    }
 
     // second SVD on the 3x3 (:98): working rows are the COLUMNS of F0 (m == n -> transpose)
     float *sV = sA + 9 * kSolveThreads;
