@@ -69,10 +69,14 @@ const char *vslam_version(void);
  *       operation by operation; bit-exact with the oracle).  1: opt-in APPROXIMATE solver for throughput experiments
  *       (BASELINE.json configs[4]): conditioned 9x9 normal matrix on the matrix cores (v_mfma_f32_16x16x4_f32) +
  *       inverse iteration.  NOT bit-exact: F equals the exact solver's up to sign and about 1e-4 (unit-norm F) on
- *       well-conditioned samples; inlier masks may differ.  Never used unless set.                              */
+ *       well-conditioned samples; inlier masks may differ.  Never used unless set.
+ *   VSLAM_OPT_MATCH_SHAPE  0 (default): the matcher picks its workgroup shape from kp_stride.  1: 8 waves x 32 query
+ *       rows, 2: 4 waves x 64 query rows.  Same results bit for bit; a tuning / test knob (the two differ in how much
+ *       room they leave the k-d build that runs beside the matcher).                                            */
 #define VSLAM_OPT_RANSAC_ALL_SUMS 1
 #define VSLAM_OPT_RANSAC_MIN_MATCHES 2
 #define VSLAM_OPT_RANSAC_SOLVER 3
+#define VSLAM_OPT_MATCH_SHAPE 4
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

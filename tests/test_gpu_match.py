@@ -18,7 +18,15 @@ def _pack(items, K):
     return torch.from_numpy(d).cuda(), torch.from_numpy(n).cuda()
 
 
-def test_knn2_and_ratio_bit_exact_ragged_batch(ctx, oracle):
+@pytest.fixture(params=[1, 2], ids=["8x32", "4x64"])
+def shape(ctx, request):
+    """Both workgroup shapes of the MFMA matcher (VSLAM_OPT_MATCH_SHAPE; the default picks one by kp_stride)."""
+    ctx.set_option(ctx.OPT_MATCH_SHAPE, request.param)
+    yield request.param
+    ctx.set_option(ctx.OPT_MATCH_SHAPE, 0)
+
+
+def test_knn2_and_ratio_bit_exact_ragged_batch(ctx, oracle, shape):
     K = 700
     sizes = [(500, 500), (700, 650), (1, 2), (513, 257), (256, 512), (0, 10), (10, 1), (10, 0), (3, 2)]
     items = [synth.descriptors_pair(100 + i, a, b) for i, (a, b) in enumerate(sizes)]
@@ -44,7 +52,7 @@ def test_knn2_and_ratio_bit_exact_ragged_batch(ctx, oracle):
             assert m[b] == 0      # reference reads m[1] of a 1-row result: undefined; we emit nothing
 
 
-def test_full_size_property_self_match(ctx):
+def test_full_size_property_self_match(ctx, shape):
     """At the headline size (K = 2000, B = 8 of the 256) every row's best match against a
     shuffled copy of itself is its own image at distance 0, and a copy is its own 2nd-NN-ratio
     survivor: checks index packing over the whole range without the oracle."""

@@ -103,6 +103,7 @@ class Context:
     OPT_RANSAC_ALL_SUMS = 1
     OPT_RANSAC_MIN_MATCHES = 2
     OPT_RANSAC_SOLVER = 3
+    OPT_MATCH_SHAPE = 4
 
     def set_option(self, option, value):
         self._check(self.lib.vslam_ctx_set_option(self.handle, C.c_int(option), C.c_int(int(value))))

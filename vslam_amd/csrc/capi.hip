@@ -226,6 +226,11 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
         ctx->ransac_solver = value;
         return VSLAM_OK;
     }
+    if (option == VSLAM_OPT_MATCH_SHAPE) {
+        VS_REQUIRE(ctx, value >= 0 && value <= 2, VSLAM_ERR_INVALID);
+        ctx->match_shape = value;
+        return VSLAM_OK;
+    }
     VS_REQUIRE(ctx, false && "unknown option", VSLAM_ERR_INVALID);
     return VSLAM_OK;
 }

@@ -180,11 +180,11 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
 }
 
-// base - (dot << 17) in one instruction (dot <= 256 and -2^17 both fit the 24-bit operands)
-__device__ __forceinline__ uint32_t mad24(int dot, int base) {
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(dot), "v"(-(1 << 17)), "v"(base));
-    return (uint32_t)r;
+// base - (dot << 17) in one instruction (dot <= 256 and -2^17 both fit the 24-bit operands: the compiler folds the
+// 24-bit multiply and the add into v_mad_i32_i24).  Not inline assembly: the operand comes straight out of an MFMA, and
+// the wait states a vector instruction needs after one are only inserted for instructions the compiler knows.
+__device__ __forceinline__ uint32_t mad24(int dot, int base, int neg_two_17) {
+    return (uint32_t)(__mul24(dot, neg_two_17) + base);
 }
 // (smallest, second smallest) of this lane's pair and the pair of the lane a DPP pattern points at
 template <int CTRL>
@@ -195,7 +195,9 @@ __device__ __forceinline__ void merge2(uint32_t &x1, uint32_t &x2) {
     x1 = lo;
 }
 
-__global__ __launch_bounds__(kThreads) void match_knn2_mfma_kernel(
+// RT = 32-row query tiles per wave; a workgroup is kMQ / (32 RT) waves.
+template <int RT>
+__global__ __launch_bounds__(64 * kMQ / (32 * RT)) void match_knn2_mfma_kernel(
     const uint8_t *__restrict__ desc1, const int32_t *__restrict__ n1, const uint8_t *__restrict__ desc2,
     const int32_t *__restrict__ n2, int kp_stride, int32_t *__restrict__ sel, int32_t *__restrict__ knn) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -213,18 +215,18 @@ __global__ __launch_bounds__(kThreads) void match_knn2_mfma_kernel(
 
     const int r = lane & 31, half = lane >> 5;
     // A operands: this lane's row of each of the wave's two 32-row tiles, bits 16 half .. + 15 of every dword
-    v4i a[2][8];
+    v4i a[RT][8];
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++) {
-        const int q = min(qbase + wave * 64 + rt * 32 + r, nq - 1);   // rows past the end repeat the last one (never written)
+    for (int rt = 0; rt < RT; rt++) {
+        const int q = min(qbase + wave * (32 * RT) + rt * 32 + r, nq - 1);   // rows past the end repeat the last one (never written)
         const uint4 lo = reinterpret_cast<const uint4 *>(q32)[2 * q], hi = reinterpret_cast<const uint4 *>(q32)[2 * q + 1];
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) a[rt][ks] = spread16((w[ks] >> (16 * half)) & 0xFFFFu);
     }
-    uint32_t k1[2][16], k2[2][16];
+    uint32_t k1[RT][16], k2[RT][16];
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             k1[rt][g] = 0xFFFFFFFFu;
@@ -234,22 +236,34 @@ __global__ __launch_bounds__(kThreads) void match_knn2_mfma_kernel(
     // Staging of train tiles: thread t owns dword t & 7 of row t >> 3 of every tile (one coalesced KiB per tile).  The
     // dword of tile i + 2 is requested while tile i is being multiplied and tile i + 1 (already in a register) is being
     // expanded into the other LDS buffer, so no wave ever waits for global memory inside the loop.
-    const int srow = tid >> 3, sd = tid & 7;
+    // With 8 waves (RT = 1) the two halves of the workgroup share a dword: threads 0..255 expand its low 16 bits (and
+    // sum the popcounts), threads 256..511 its high 16 bits.
+    constexpr bool kSplit = RT == 1;
+    const int st = kSplit ? (tid & 255) : tid, shalf = kSplit ? (tid >> 8) : 0;
+    const int srow = st >> 3, sd = st & 7;
     auto fetch = [&](int tile) -> uint32_t {
         const int t = tile * kMT + srow;
         return t < nt ? t32[(size_t)t * 8 + sd] : 0u;
     };
     auto expand = [&](uint32_t wv, int tile, int buf) {
         uint8_t *dst = &s_b[buf][srow * kMStride + sd * 32];
-        *reinterpret_cast<v4i *>(dst) = spread16(wv & 0xFFFFu);
-        *reinterpret_cast<v4i *>(dst + 16) = spread16(wv >> 16);
-        uint32_t pc = (uint32_t)__popc(wv);     // |b|: sum over the row's 8 dwords = 8 neighbouring lanes
-        pc += dpp_u32<0xB1>(pc);                // quad_perm [1,0,3,2]
-        pc += dpp_u32<0x4E>(pc);                // quad_perm [2,3,0,1]
-        pc += dpp_u32<0x141>(pc);               // row_half_mirror: the other quad of the 8
-        if (sd == 0) s_pb[buf][srow] = tile * kMT + srow < nt ? pc : kMPad;
+        if (kSplit) {
+            *reinterpret_cast<v4i *>(dst + 16 * shalf) = spread16((wv >> (16 * shalf)) & 0xFFFFu);
+        } else {
+            *reinterpret_cast<v4i *>(dst) = spread16(wv & 0xFFFFu);
+            *reinterpret_cast<v4i *>(dst + 16) = spread16(wv >> 16);
+        }
+        if (!kSplit || shalf == 0) {                // whole waves: threads 0..255
+            uint32_t pc = (uint32_t)__popc(wv);     // |b|: sum over the row's 8 dwords = 8 neighbouring lanes
+            pc += dpp_u32<0xB1>(pc);                // quad_perm [1,0,3,2]
+            pc += dpp_u32<0x4E>(pc);                // quad_perm [2,3,0,1]
+            pc += dpp_u32<0x141>(pc);               // row_half_mirror: the other quad of the 8
+            if (sd == 0) s_pb[buf][srow] = tile * kMT + srow < nt ? pc : kMPad;
+        }
     };
 
+    int neg_two_17 = -(1 << 17);
+    asm volatile("" : "+s"(neg_two_17));   // opaque, or the multiply becomes a shift and the add a second instruction
     const int ntiles = (nt + kMT - 1) / kMT;
     if (ntiles > 0) expand(fetch(0), 0, 0);
     uint32_t w_next = ntiles > 1 ? fetch(1) : 0u;
@@ -258,31 +272,33 @@ __global__ __launch_bounds__(kThreads) void match_knn2_mfma_kernel(
         const int buf = tile & 1;
         if (tile + 1 < ntiles) expand(w_next, tile + 1, buf ^ 1);   // the other buffer was last read two barriers ago
         if (tile + 2 < ntiles) w_next = fetch(tile + 2);
-        v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        v16i acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) acc[rt] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const uint8_t *src = &s_b[buf][r * kMStride + 16 * half];
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             const v4i bv = *reinterpret_cast<const v4i *>(src + 32 * ks);
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], bv, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][ks], bv, acc1, 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt][ks], bv, acc[rt], 0, 0, 0);
         }
         // key = (|b| + bias - 2 a.b) << 16 | train index = base - (a.b << 17): one multiply-add per result
         const int base = (int)(((s_pb[buf][r] + kMBias) << 16) | (uint32_t)(tile * kMT + r));
 #pragma unroll
         for (int g = 0; g < 16; g++) {
-            const uint32_t key0 = mad24(acc0[g], base);
-            k2[0][g] = med3_u32(k1[0][g], k2[0][g], key0);
-            k1[0][g] = min(k1[0][g], key0);
-            const uint32_t key1 = mad24(acc1[g], base);
-            k2[1][g] = med3_u32(k1[1][g], k2[1][g], key1);
-            k1[1][g] = min(k1[1][g], key1);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const uint32_t key = mad24(acc[rt][g], base, neg_two_17);
+                k2[rt][g] = med3_u32(k1[rt][g], k2[rt][g], key);
+                k1[rt][g] = min(k1[rt][g], key);
+            }
         }
         __syncthreads();
     }
 
     // the 32 lanes of a half hold different columns of the same rows: merge their (smallest, second smallest)
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             uint32_t x1 = k1[rt][g], x2 = k2[rt][g];
@@ -301,11 +317,11 @@ __global__ __launch_bounds__(kThreads) void match_knn2_mfma_kernel(
         }
     // lane (g, half) of each row tile writes row (g & 3) + 8 (g >> 2) + 4 half
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             if (r != g) continue;
-            const int q = qbase + wave * 64 + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
+            const int q = qbase + wave * (32 * RT) + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
             if (q >= nq) continue;
             const uint4 lo = reinterpret_cast<const uint4 *>(q32)[2 * q], hi = reinterpret_cast<const uint4 *>(q32)[2 * q + 1];
             const int pa = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) +
@@ -384,8 +400,18 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
             dim3 grid(vs_div_up(kp_stride, kThreads * kQueriesPerLane), batch);
             match_knn2_kernel<<<grid, kThreads, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
         } else {
+            // Two shapes of the same kernel.  8 waves x 32 rows (106 VGPRs, 4 waves / SIMD, results straight out of
+            // the MFMA's vector registers: 3 vector ops per result instead of 4) is the faster kernel on its own
+            // (0.254 vs 0.268 ms at C3, 1.89 vs 2.02 at C5); 4 waves x 64 rows (196 VGPRs, 2 waves / SIMD) leaves the
+            // k-d build, which the front end runs beside the matcher, the wave slots it needs, and the STEP is faster
+            // with it while the two take about equally long (C3: 3.70 vs 3.76 ms).  With more keypoints the matcher
+            // dominates (quadratic against n log n) and the first shape wins the step too (C5: 18.1 vs 18.3 ms).
+            static const char *shape = getenv("VSLAM_MATCH_SHAPE");   // "8x32" / "4x64" force one (A/B timing)
+            const int pick = ctx->match_shape ? ctx->match_shape : (shape ? (shape[0] == '4' ? 2 : 1) : 0);
+            const bool wide = pick ? pick == 2 : kp_stride <= 2048;
             dim3 grid(vs_div_up(kp_stride, kMQ), batch);
-            match_knn2_mfma_kernel<<<grid, kThreads, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
+            if (wide) match_knn2_mfma_kernel<2><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
+            else match_knn2_mfma_kernel<1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
         }
     }
     {
