@@ -1639,22 +1639,22 @@ __global__ __launch_bounds__(256) void ransac_screen_kernel(
     const unsigned long long va = __ballot(2 * lane < n0), vb = __ballot(2 * lane + 1 < n0);
     __syncthreads();
     int mine = 0;
-    for (int j = 0; j < 32; j += 2) {   // two hypotheses in flight
-        CntRec R0, R1;
-        cnt_load_record(R0, s_rec, wave * 32 + j);
-        cnt_load_record(R1, s_rec, wave * 32 + j + 1);
-        v2f dd0, dd1;
-        const v2f g0 = cnt_cheap(R0, X1, Y1, X2, Y2, dd0);
-        const v2f g1 = cnt_cheap(R1, X1, Y1, X2, Y2, dd1);
-        const unsigned long long oa0 = __builtin_amdgcn_fcmpf(g0.x, R0.hi, 2), ob0 = __builtin_amdgcn_fcmpf(g0.y, R0.hi, 2);
-        const unsigned long long oa1 = __builtin_amdgcn_fcmpf(g1.x, R1.hi, 2), ob1 = __builtin_amdgcn_fcmpf(g1.y, R1.hi, 2);
-        int p0 = __popcll(va & ~oa0) + __popcll(vb & ~ob0);
-        int p1 = __popcll(va & ~oa1) + __popcll(vb & ~ob1);
-        // a zero / denormal (or NaN) dd: v_rcp_f32 is not a 1-ulp reciprocal there, nothing is certified
-        if (__builtin_amdgcn_fcmpf(fminf(dd0.x, dd0.y), kCntTinyDD, 9) != 0ull) p0 = n0;
-        if (__builtin_amdgcn_fcmpf(fminf(dd1.x, dd1.y), kCntTinyDD, 9) != 0ull) p1 = n0;
-        mine = lane == j ? p0 : mine;
-        mine = lane == j + 1 ? p1 : mine;
+    constexpr int kU = 4;   // hypotheses in flight: the record reads and the dependent chain of one hide behind the others
+    for (int j = 0; j < 32; j += kU) {
+        CntRec R[kU];
+        v2f dd[kU], g[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) cnt_load_record(R[u], s_rec, wave * 32 + j + u);
+#pragma unroll
+        for (int u = 0; u < kU; u++) g[u] = cnt_cheap(R[u], X1, Y1, X2, Y2, dd[u]);
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const unsigned long long oa = __builtin_amdgcn_fcmpf(g[u].x, R[u].hi, 2), ob = __builtin_amdgcn_fcmpf(g[u].y, R[u].hi, 2);
+            int p = __popcll(va & ~oa) + __popcll(vb & ~ob);
+            // a zero / denormal (or NaN) dd: v_rcp_f32 is not a 1-ulp reciprocal there, nothing is certified
+            if (__builtin_amdgcn_fcmpf(fminf(dd[u].x, dd[u].y), kCntTinyDD, 9) != 0ull) p = n0;
+            mine = lane == j + u ? p : mine;
+        }
     }
     const int h = hbase + wave * 32 + lane;
     if (lane < 32 && h < hyp) pot0[(size_t)b * hyp + h] = mine;
