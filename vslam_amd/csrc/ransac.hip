@@ -550,17 +550,36 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
 }
 
 // ------------------------------------------------------------------------------------------
-// The 8 x 9 instance as ransac_solve_kernel runs it: rows 0..4 of a lane's matrix in LDS, rows 5..7 in registers.
+// The 8 x 9 instance as ransac_solve_kernel runs it: the lane's whole matrix in registers during the sweeps.
 // ------------------------------------------------------------------------------------------
-// 72 floats per lane in LDS hold the kernel at 8 waves per CU (2 per SIMD) and it is VALU-bound with dependent f64
-// chains, where a third wave pays (min_eigen: 2 -> 3 waves per SIMD was worth 18 %).  45 floats per lane fit 12 waves.
-// Every operation on every value is the one jacobi_svd_lanes<9, 8, 9, false, true> performs, in the same order.
-constexpr int kSolveLdsRows = 5;
+// 72 floats per lane in LDS held the kernel at 8 waves per CU (2 per SIMD); it is bound by dependent f64 chains on the
+// vector pipe, where more waves pay (2 -> 3 per SIMD: 0.96 -> 0.88 ms with three of the rows in registers).  With all
+// eight rows in registers (72 VGPRs; every (i, j) step written out, the row indices compile-time) the sweeps touch no
+// LDS at all, 128 VGPRs suffice and 4 waves fit.  Only the part after the sweeps wants rows by run-time index: rows
+// 0..3 go to LDS for it (36 floats per lane).  Every operation on every value is the one
+// jacobi_svd_lanes<9, 8, 9, false, true> performs, in the same order.
+constexpr int kSolveLdsRows = 4;
 constexpr int kSolveSplitFloats = kSolveLdsRows * 9;
 
+// c, s of a rotation for operands outside the range the short sqrt / division sequences cover (see jacobi_svd_lanes).
+// Deliberately a real call: it is reached by a wave-wide vote that practically never passes, and 28 inlined copies of the
+// IEEE sqrt and division expansions would double the size of the sweep loop.
+__device__ __attribute__((noinline)) void jacobi_cs_full(double p, double beta, double g2, float *c_out, float *s_out) {
+    float c, s;
+    const double gamma = sqrt(g2);   // pinned hypot
+    if (beta < 0) {
+        const double delta = (gamma - beta) * 0.5;
+        s = (float)sqrt(delta / gamma);
+        c = (float)(p / (gamma * (double)s * 2));
+    } else {
+        c = (float)sqrt((gamma + beta) / (gamma * 2));
+        s = (float)(p / (gamma * (double)c * 2));
+    }
+    *c_out = c;
+    *s_out = s;
+}
+
 // one (i, j) step on two rows held in registers.  Returns whether this lane rotated (the rows are then the rotated ones).
-// (Keeping row i's double conversions and norm across the j's, as the LDS form does, costs 20 registers here: with three
-// rows resident the registers are worth more than the 18 instructions a step without rotation would save.)
 __device__ __forceinline__ bool jacobi_pair_9(float (&ai)[9], float (&aj)[9]) {
     double a = 0, p = 0, b = 0;
 #pragma unroll
@@ -588,15 +607,7 @@ __device__ __forceinline__ bool jacobi_pair_9(float (&ai)[9], float (&aj)[9]) {
             s = (float)div_inrange(p, gamma * (double)c * 2);
         }
     } else {
-        const double gamma = sqrt(g2);   // pinned hypot
-        if (beta < 0) {
-            const double delta = (gamma - beta) * 0.5;
-            s = (float)sqrt(delta / gamma);
-            c = (float)(p / (gamma * (double)s * 2));
-        } else {
-            c = (float)sqrt((gamma + beta) / (gamma * 2));
-            s = (float)(p / (gamma * (double)c * 2));
-        }
+        jacobi_cs_full(p, beta, g2, &c, &s);
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -608,32 +619,13 @@ __device__ __forceinline__ bool jacobi_pair_9(float (&ai)[9], float (&aj)[9]) {
     return true;
 }
 
-// one sweep over all pairs in OpenCV's order; pA = this lane's LDS column (element (r, k) at pA[(9 r + k) * 64])
-__device__ __forceinline__ bool jacobi_sweep_8x9_split(float *pA, float (&R5)[9], float (&R6)[9], float (&R7)[9]) {
+// one sweep over all pairs in OpenCV's order
+__device__ __forceinline__ bool jacobi_sweep_8x9_regs(float (&R)[8][9]) {
     bool changed = false;
-    for (int i = 0; i < kSolveLdsRows; i++) {
-        float ai[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) ai[k] = pA[(i * 9 + k) * kSolveThreads];
-        for (int j = i + 1; j < kSolveLdsRows; j++) {
-            float aj[9];
+    for (int i = 0; i < 7; i++)
 #pragma unroll
-            for (int k = 0; k < 9; k++) aj[k] = pA[(j * 9 + k) * kSolveThreads];
-            if (jacobi_pair_9(ai, aj)) {
-                changed = true;
-#pragma unroll
-                for (int k = 0; k < 9; k++) pA[(j * 9 + k) * kSolveThreads] = aj[k];
-            }
-        }
-        changed |= jacobi_pair_9(ai, R5);
-        changed |= jacobi_pair_9(ai, R6);
-        changed |= jacobi_pair_9(ai, R7);
-#pragma unroll
-        for (int k = 0; k < 9; k++) pA[(i * 9 + k) * kSolveThreads] = ai[k];
-    }
-    changed |= jacobi_pair_9(R5, R6);
-    changed |= jacobi_pair_9(R5, R7);
-    changed |= jacobi_pair_9(R6, R7);
+        for (int j = i + 1; j < 8; j++) changed |= jacobi_pair_9(R[i], R[j]);
     return changed;
 }
 
@@ -642,9 +634,10 @@ __device__ __forceinline__ bool jacobi_sweep_8x9_split(float *pA, float (&R5)[9]
 // OpenCV regenerates that row from its RNG stream first (degenerate samples): any lane in that case sends the wave
 // through jacobi_finish itself on a private copy.  Otherwise a row's normalisation factor is a function of that row alone
 // and the sort only fixes the ORDER in which the rows are visited, so nothing has to move: rowid[ii] = the row at sorted
-// position ii.
-__device__ __forceinline__ void jacobi_null_row_8x9_split(float *pA, float (&R5)[9], float (&R6)[9], float (&R7)[9], float *f0) {
-    constexpr int M = 9, N = 8;
+// position ii.  Rows below kSolveLdsRows are parked in LDS (pA = this lane's column, element (r, k) at
+// pA[(9 r + k) * 64]) so that a run-time row id is an address; the others are picked with selects.
+__device__ __forceinline__ void jacobi_null_row_8x9(float *pA, float (&R)[8][9], float *f0) {
+    constexpr int M = 9, N = 8, L = kSolveLdsRows;
     const double minval = FLT_MIN;
     const float eps = FLT_EPSILON * 2;
     double W[N];
@@ -653,10 +646,7 @@ __device__ __forceinline__ void jacobi_null_row_8x9_split(float *pA, float (&R5)
     for (int i = 0; i < N; i++) {
         double sd = 0;
 #pragma unroll
-        for (int k = 0; k < M; k++) {
-            const float t = i < kSolveLdsRows ? pA[(i * 9 + k) * kSolveThreads] : (i == 5 ? R5[k] : (i == 6 ? R6[k] : R7[k]));
-            sd = __builtin_fma((double)t, (double)t, sd);
-        }
+        for (int k = 0; k < M; k++) sd = __builtin_fma((double)R[i][k], (double)R[i][k], sd);
         W[i] = sqrt(sd);
         tiny = tiny || W[i] <= minval;
     }
@@ -665,21 +655,18 @@ __device__ __forceinline__ void jacobi_null_row_8x9_split(float *pA, float (&R5)
 #pragma unroll
         for (int i = 0; i < N; i++)
 #pragma unroll
-            for (int k = 0; k < M; k++)
-                rows[i * M + k] = i < kSolveLdsRows ? pA[(i * 9 + k) * kSolveThreads] : (i == 5 ? R5[k] : (i == 6 ? R6[k] : R7[k]));
+            for (int k = 0; k < M; k++) rows[i * M + k] = R[i][k];
         jacobi_finish<9, 8, 9, false, 1>(rows, nullptr, w8, f0);
         return;
     }
-    // normalise (RansacFilter's rows are OpenCV's: row *= (float)(1 / W), W = the row's norm)
+    // normalise (row *= (float)(1 / W), W = the row's norm), park the first rows
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const float s = (float)(1 / W[i]);
 #pragma unroll
         for (int k = 0; k < M; k++) {
-            if (i < kSolveLdsRows) pA[(i * 9 + k) * kSolveThreads] = pA[(i * 9 + k) * kSolveThreads] * s;
-            else if (i == 5) R5[k] = R5[k] * s;
-            else if (i == 6) R6[k] = R6[k] * s;
-            else R7[k] = R7[k] * s;
+            R[i][k] = R[i][k] * s;
+            if (i < L) pA[(i * 9 + k) * kSolveThreads] = R[i][k];
         }
     }
     // the descending selection sort, on (W, row id) pairs
@@ -722,13 +709,15 @@ __device__ __forceinline__ void jacobi_null_row_8x9_split(float *pA, float (&R5)
 #pragma unroll
             for (int jj = 0; jj < N; jj++) {
                 const int r = rowid[jj];
-                const int rl = r < kSolveLdsRows ? r : 0;
+                const int rl = r < L ? r : 0;
                 float vj[M];
                 sd = 0;
 #pragma unroll
                 for (int k = 0; k < M; k++) {
-                    const float l = pA[(rl * 9 + k) * kSolveThreads];
-                    vj[k] = r == 5 ? R5[k] : (r == 6 ? R6[k] : (r == 7 ? R7[k] : l));
+                    float t = pA[(rl * 9 + k) * kSolveThreads];
+#pragma unroll
+                    for (int q = L; q < N; q++) t = r == q ? R[q][k] : t;
+                    vj[k] = t;
                     sd += (double)(v[k] * vj[k]);   // float product, double running sum
                 }
                 float asum = 0;
@@ -754,7 +743,7 @@ __device__ __forceinline__ void jacobi_null_row_8x9_split(float *pA, float (&R5)
 }
 
 // One lane per hypothesis, one wave per workgroup.  grid = (ceil(hyp / 64), batch).
-__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void ransac_solve_kernel(
+__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_solve_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, const int32_t *__restrict__ sets, int kp_stride, int hyp,
     float *__restrict__ hypF) {
@@ -771,31 +760,29 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(3
     const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
     const int32_t *S = sets + ((size_t)b * hyp + hc) * VSLAM_SET_SIZE;
 
-    float R5[9], R6[9], R7[9];
-    {   // design matrix, RansacFilter.cpp:75-90
-        constexpr int M = 9;
+    float R[8][9];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int2 pr = PR[S[r]];
-            const float2 a = P1[pr.x], c = P2[pr.y];
-            const float u1 = a.x, v1 = a.y, u2 = c.x, v2 = c.y;
-            const float row[9] = {u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, 1.f};
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                if (r < kSolveLdsRows) VS_A(r, k) = row[k];
-                else if (r == 5) R5[k] = row[k];
-                else if (r == 6) R6[k] = row[k];
-                else R7[k] = row[k];
-            }
-        }
+    for (int r = 0; r < 8; r++) {   // design matrix, RansacFilter.cpp:75-90
+        const int2 pr = PR[S[r]];
+        const float2 a = P1[pr.x], c = P2[pr.y];
+        const float u1 = a.x, v1 = a.y, u2 = c.x, v2 = c.y;
+        R[r][0] = u2 * u1;
+        R[r][1] = u2 * v1;
+        R[r][2] = u2;
+        R[r][3] = v2 * u1;
+        R[r][4] = v2 * v1;
+        R[r][5] = v2;
+        R[r][6] = u1;
+        R[r][7] = v1;
+        R[r][8] = 1.f;
     }
 
     float f0[9];
     {   // SVDecomp(A 8x9), :94; f0 = V_t.row(8), :95
         constexpr int max_iter = 30;
         for (int iter = 0; iter < max_iter; iter++)
-            if (!jacobi_sweep_8x9_split(sA + tid, R5, R6, R7)) break;
-        jacobi_null_row_8x9_split(sA + tid, R5, R6, R7, f0);
+            if (!jacobi_sweep_8x9_regs(R)) break;
+        jacobi_null_row_8x9(sA + tid, R, f0);
     }
 
     // second SVD on the 3x3 (:98): working rows are the COLUMNS of F0 (m == n -> transpose)
