@@ -1260,9 +1260,10 @@ constexpr int kRankThreads = 512;
 constexpr int kPilotHyps = kRankThreads / 64;
 constexpr int kCandMax = 8;
 constexpr float kCntTinyDD = 0x1p-120f;
-// A hypothesis as the counting loop reads it from LDS: every element of F twice (so a register pair is the
-// (f, f) operand of a packed instruction with no v_mov), then lo, hi.  kCntRec floats per hypothesis.
-constexpr int kCntRec = 20;
+// A hypothesis as the counting loop reads it from LDS: F, lo, hi (+ 1 pad): kCntRec floats per hypothesis.  (Storing every
+// element of F twice spares the loop nine v_movs per hypothesis — the (f, f) operands of the packed instructions — but
+// costs 4 KiB per workgroup, which is the difference between two and three workgroups per CU.)
+constexpr int kCntRec = 12;
 // a wave's queue: volatile (lanes read what other lanes wrote) and typed as LDS so that the accesses are ds_ instructions
 typedef __attribute__((address_space(3))) volatile uint32_t cnt_queue_t;
 static_assert(VSLAM_MAX_KP <= 65536, "queue words keep the match index in 16 bits");
@@ -1298,12 +1299,10 @@ __device__ __forceinline__ CntBand cnt_band(const float *f, float C1, float C2, 
 }
 __device__ __forceinline__ void cnt_store_record(float *d, const float *f, const CntBand &B) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        d[2 * k] = f[k];
-        d[2 * k + 1] = f[k];
-    }
-    d[18] = B.lo;
-    d[19] = B.hi;
+    for (int k = 0; k < 9; k++) d[k] = f[k];
+    d[9] = B.lo;
+    d[10] = B.hi;
+    d[11] = 0.f;
 }
 
 struct CntRec {
@@ -1312,14 +1311,15 @@ struct CntRec {
 };
 __device__ __forceinline__ void cnt_load_record(CntRec &R, const float *s_rec, int hh) {
     const float4 *r4 = reinterpret_cast<const float4 *>(s_rec + hh * kCntRec);
-    const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3], v4 = r4[4];
-    R.f[0].x = v0.x; R.f[0].y = v0.y; R.f[1].x = v0.z; R.f[1].y = v0.w;
-    R.f[2].x = v1.x; R.f[2].y = v1.y; R.f[3].x = v1.z; R.f[3].y = v1.w;
-    R.f[4].x = v2.x; R.f[4].y = v2.y; R.f[5].x = v2.z; R.f[5].y = v2.w;
-    R.f[6].x = v3.x; R.f[6].y = v3.y; R.f[7].x = v3.z; R.f[7].y = v3.w;
-    R.f[8].x = v4.x; R.f[8].y = v4.y;
-    R.lo = v4.z;
-    R.hi = v4.w;
+    const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2];
+    const float f[9] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x};
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        R.f[k].x = f[k];
+        R.f[k].y = f[k];
+    }
+    R.lo = v2.y;
+    R.hi = v2.z;
 }
 
 // the cheap value g for two matches per lane; dd returned for the caller's denormal check
@@ -1350,7 +1350,7 @@ __device__ __forceinline__ void cnt_drain(const cnt_queue_t *q, int from, int co
         const int hh = (int)(en >> 16), i = (int)(en & 0xFFFFu);
         ResidualF R;
 #pragma unroll
-        for (int k = 0; k < 9; k++) R.f[k] = s_rec[hh * kCntRec + 2 * k];
+        for (int k = 0; k < 9; k++) R.f[k] = s_rec[hh * kCntRec + k];
         residual_prepare(R);
         const float x2 = cx2[i], y2 = cy2[i];
         const float e = residual_e(R, make_float4(cx1[i], cy1[i], x2, y2), (double)x2, (double)y2);
@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(64 * kCandMax) void ransac_cand_kernel(
 // grid = (ceil(hyp / 128), batch), block = 512; dynamic LDS = (LDS ? 16 B x cnt_pad(kp_stride) : 0) + 8 queues.
 // LDS = false (more than kCntLdsMatches slots per pair): the ranked coordinates are read from memory instead.
 template <bool LDS>
-__global__ __launch_bounds__(64 * kCntWaves) void ransac_count_kernel(
+__global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(6, 6))) void ransac_count_kernel(
     const float *__restrict__ rk, int kp_pad, const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
     const float *__restrict__ hypF, const int32_t *__restrict__ pot0, const float *__restrict__ cmax,
     int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx, int32_t *__restrict__ cbound) {
