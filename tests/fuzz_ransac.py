@@ -23,7 +23,7 @@ def run(ctx, o, seed, cases=None, seconds=None):
     t0, done = time.time(), 0
     while (cases is None or done < cases) and (seconds is None or time.time() - t0 < seconds):
         B = int(rng.integers(1, 5))
-        K = int(rng.choice([16, 64, 200]))
+        K = int(rng.choice([16, 64, 200, 200, 700, 1600]))   # up to several 256-match sub-blocks of the counting kernel
         Hy = int(rng.choice([8, 64, 130]))
         thr = float(10.0 ** rng.uniform(-6, 6)) if rng.random() < 0.5 else 10.0
         xy1 = np.zeros((B, K, 2), np.float32)
