@@ -597,15 +597,17 @@ __device__ __forceinline__ bool jacobi_pair_9(float (&ai)[9], float (&aj)[9]) {
     // see jacobi_svd_lanes for the range argument
     const bool safe = g2 > 0x1p-400 && g2 < 0x1p400 && fabs(p) > 0x1p-300;
     if (!__any(!safe)) {
+        // One instruction stream for both signs of beta (lanes of a wave differ in it, so as two branches both would run):
+        // the first of (c, s) is a square root of a quotient, the second a quotient by it; which is which, and the operands
+        // of the first quotient, are selected.  The operations on every lane are the ones its branch would perform.
         const double gamma = sqrt_inrange(g2);   // pinned hypot
-        if (beta < 0) {
-            const double delta = (gamma - beta) * 0.5;
-            s = (float)sqrt_inrange(div_inrange(delta, gamma));
-            c = (float)div_inrange(p, gamma * (double)s * 2);
-        } else {
-            c = (float)sqrt_inrange(div_inrange(gamma + beta, gamma * 2));
-            s = (float)div_inrange(p, gamma * (double)c * 2);
-        }
+        const bool neg = beta < 0;
+        const double num = neg ? (gamma - beta) * 0.5 : gamma + beta;
+        const double den = neg ? gamma : gamma * 2;
+        const float first = (float)sqrt_inrange(div_inrange(num, den));
+        const float second = (float)div_inrange(p, gamma * (double)first * 2);
+        s = neg ? first : second;
+        c = neg ? second : first;
     } else {
         jacobi_cs_full(p, beta, g2, &c, &s);
     }
