@@ -271,11 +271,13 @@ constexpr int kSW = 256;     // pixels per strip (64 lanes x 4), all owned
 constexpr int kSQ = 512;     // candidate queue entries per wave
 struct StreamState {
     float hx[3][6], rr[3][6];      // per gray row: x-derivative parts and smoothed values, columns x-1 .. x+4
-    double T[12], Rp[12];          // horizontal 3-sums of xx, xy, yy for the lane's 4 pixels: Rp = those of the previous
-                                   // product row, T = (row before that) + Rp.  Two rows' worth of state instead of
-                                   // three (24 registers: the difference between 2 and 3 waves per SIMD) for a
-                                   // register copy per value and step; the additions and their order are unchanged:
-                                   // S(y) = (r(y-1) + r(y)) + r(y+1) = T + r(y+1)
+    double T[12], X[2][12];        // horizontal 3-sums of xx, xy, yy for the lane's 4 pixels: X[t & 1] = those of the
+                                   // product row of step t, X[~t & 1] of the row before, T = the sum of the two rows
+                                   // before this step's.  The column sum S(y) = (r(y-1) + r(y)) + r(y+1) is T + r(y+1)
+                                   // — the same two additions in the same order as three stored rows would give —
+                                   // and neither a third row of state nor a register copy per value is needed: the
+                                   // new row is computed straight into the slot of the row that just left the window
+                                   // (the difference between 2 and 3 waves per SIMD)
     float ctr[3][4], hm[3][4];     // per response row: the values and their horizontal 3-maxima
     uint32_t raw[3][3];            // prefetched gray dwords (x-4, x, x+4) of the next three rows
     float emax;
@@ -291,6 +293,7 @@ struct StreamArgs {
     int w, h, ys, ye, x, steps;
     uint32_t voff_l, voff_c, voff_r;
     bool edge, left_fix, right_fix, own_lane;
+    unsigned long long col_ok[4];   // lanes whose pixel i is an owned, testable column (1 <= x < w - 1)
     float k0, k1, thr_p;
 };
 
@@ -306,7 +309,7 @@ __device__ __forceinline__ void stream_flush(const StreamArgs &a, int &qn, int l
     qn = 0;
 }
 
-template <int K>
+template <int K, int P>   // K = t % 3 (three-row rings), P = t % 2 (X)
 __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a, int t, int &qn, int lane) {
     constexpr int K1 = (K + 2) % 3, K2 = (K + 1) % 3;   // slots of the previous row and the one before
     uint32_t d0 = st.raw[K][0];
@@ -362,7 +365,8 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
         if (a.left_fix) cxy[0] = -cxy[0];
         if (a.right_fix) cxy[5] = -cxy[5];
     }
-    double r[12];
+    double (&r)[12] = st.X[P];
+    const double (&rp)[12] = st.X[P ^ 1];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         r[i] = ((double)cxx[i] + (double)cxx[i + 1]) + (double)cxx[i + 2];
@@ -385,10 +389,7 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
         }
     }
 #pragma unroll
-    for (int e = 0; e < 12; e++) {
-        st.T[e] = st.Rp[e] + r[e];
-        st.Rp[e] = r[e];
-    }
+    for (int e = 0; e < 12; e++) st.T[e] = rp[e] + r[e];
     if (t >= 4) {
         const int y = a.ys - 5 + t;
         float apc[4], tt[4], rt[4], e4[4];
@@ -423,14 +424,16 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
         if (t >= 6) {
             const int ty = y - 1;   // ys <= ty < ye by construction
             if (qn > kSQ - 256) stream_flush(a, qn, lane);
-            const bool row_ok = ty >= 1 && ty < a.h - 1 && a.own_lane;
+            const bool row_ok = ty >= 1 && ty < a.h - 1;   // uniform; the lane's part of the test is in a.col_ok
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float v = st.ctr[K1][i];
                 const float m = max3_nonan(st.hm[K2][i], st.hm[K1][i], st.hm[K][i]);
                 const int xx = a.x + i;
-                const bool cand = row_ok && xx >= 1 && xx < a.w - 1 && v > a.thr_p && !(m > v);
-                const unsigned long long bal = __ballot(cand);
+                // candidate: v > thr && !(m > v), in the columns and rows that can be tested — formed from compare masks
+                // (as a bool the compiler materialises it per lane and compares it again to get the ballot)
+                const unsigned long long bal = row_ok ? (__builtin_amdgcn_fcmpf(v, a.thr_p, 2) & ~__builtin_amdgcn_fcmpf(m, v, 2) & a.col_ok[i]) : 0ull;
+                const bool cand = (bal >> lane) & 1ull;
                 if (bal) {
                     const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     uint32_t lo = (uint32_t)(ty * a.w + xx);
@@ -475,6 +478,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int x0 = strip * kSW;
     a.x = x0 + 4 * lane;
     a.own_lane = a.x < w;
+#pragma unroll
+    for (int i = 0; i < 4; i++) a.col_ok[i] = __ballot(a.own_lane && a.x + i >= 1 && a.x + i < w - 1);
     a.edge = x0 == 0 || x0 + kSW + 4 > w;
     a.left_fix = a.x == 0;
     a.right_fix = a.x + 4 == w;
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     StreamState st;
     st.emax = ninf;
 #pragma unroll
-    for (int i = 0; i < 12; i++) st.T[i] = st.Rp[i] = 0.0;
+    for (int i = 0; i < 12; i++) st.T[i] = st.X[0][i] = st.X[1][i] = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
@@ -504,11 +509,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     a.thr_p = (float)((double)ord2f(run_max) * quality);
     if (run_max == 0u) a.thr_p = ninf;   // nothing published yet
     int qn = 0;
-    for (int t0 = 0; t0 < a.steps; t0 += 3) {
-        stream_step<0>(st, a, t0, qn, lane);
-        if (t0 + 1 < a.steps) stream_step<1>(st, a, t0 + 1, qn, lane);
-        if (t0 + 2 < a.steps) stream_step<2>(st, a, t0 + 2, qn, lane);
-        if ((t0 % 12) == 9) {   // every 12 rows: tighten the prefilter with this wave's own maximum and publish it
+    for (int t0 = 0; t0 < a.steps; t0 += 6) {   // six steps per trip: every ring index (t % 3, t % 2) is a compile-time constant
+        stream_step<0, 0>(st, a, t0, qn, lane);
+        if (t0 + 1 < a.steps) stream_step<1, 1>(st, a, t0 + 1, qn, lane);
+        if (t0 + 2 < a.steps) stream_step<2, 0>(st, a, t0 + 2, qn, lane);
+        if (t0 + 3 < a.steps) stream_step<0, 1>(st, a, t0 + 3, qn, lane);
+        if (t0 + 4 < a.steps) stream_step<1, 0>(st, a, t0 + 4, qn, lane);
+        if (t0 + 5 < a.steps) stream_step<2, 1>(st, a, t0 + 5, qn, lane);
+        if ((t0 % 12) == 6) {   // every 12 rows: tighten the prefilter with this wave's own maximum and publish it
             uint32_t k = st.emax == ninf ? 0u : f2ord(st.emax);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
