@@ -378,24 +378,15 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
 #pragma unroll
         for (int i = 0; i < 4; i++) r[4 + i] = -r[4 + i];
     }
-    float sx[4], sxy4[4], sy[4];
-    if (t >= 4) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            // column sums S(y) = (r(y-1) + r(y)) + r(y+1)
-            sx[i] = (float)(st.T[i] + r[i]);
-            sxy4[i] = (float)(st.T[4 + i] + r[4 + i]);
-            sy[i] = (float)(st.T[8 + i] + r[8 + i]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 12; e++) st.T[e] = rp[e] + r[e];
     if (t >= 4) {
         const int y = a.ys - 5 + t;
         float apc[4], tt[4], rt[4], e4[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float sxx = sx[i], sxy = sxy4[i], syy = sy[i];
+            // column sums S(y) = (r(y-1) + r(y)) + r(y+1)
+            const float sxx = (float)(st.T[i] + r[i]);
+            const float sxy = (float)(st.T[4 + i] + r[4 + i]);
+            const float syy = (float)(st.T[8 + i] + r[8 + i]);
             const float ea = sxx * 0.5f, eb = sxy, ec = syy * 0.5f;
             const float amc = ea - ec;
             tt[i] = amc * amc + eb * eb;
@@ -445,6 +436,9 @@ __device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a
             }
         }
     }
+    // the two-row sum moves on only now: the block above read the old one
+#pragma unroll
+    for (int e = 0; e < 12; e++) st.T[e] = rp[e] + r[e];
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void min_eigen_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
