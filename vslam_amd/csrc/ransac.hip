@@ -1813,17 +1813,12 @@ __global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(
             v2f acc;
             acc.x = 0.f;
             acc.y = 0.f;
-            float4 nx1 = *reinterpret_cast<const float4 *>(cx1 + 4 * lane), ny1 = *reinterpret_cast<const float4 *>(cy1 + 4 * lane);
-            float4 nx2 = *reinterpret_cast<const float4 *>(cx2 + 4 * lane), ny2 = *reinterpret_cast<const float4 *>(cy2 + 4 * lane);
             for (int s = 0; s < nsub; s++) {
-                const float4 X1 = nx1, Y1 = ny1, X2 = nx2, Y2 = ny2;
+                // the lane's four matches of this sub-block: straight from LDS (six waves per SIMD hide the round trip;
+                // fetching a sub-block ahead cost 16 registers and a copy per value)
                 const int ix = s * 256 + 4 * lane;
-                if (s + 1 < nsub) {
-                    nx1 = *reinterpret_cast<const float4 *>(cx1 + ix + 256);
-                    ny1 = *reinterpret_cast<const float4 *>(cy1 + ix + 256);
-                    nx2 = *reinterpret_cast<const float4 *>(cx2 + ix + 256);
-                    ny2 = *reinterpret_cast<const float4 *>(cy2 + ix + 256);
-                }
+                const float4 X1 = *reinterpret_cast<const float4 *>(cx1 + ix), Y1 = *reinterpret_cast<const float4 *>(cy1 + ix);
+                const float4 X2 = *reinterpret_cast<const float4 *>(cx2 + ix), Y2 = *reinterpret_cast<const float4 *>(cy2 + ix);
                 if (s == nsub - 1 && part) {
                     cnt_sub_block<true>(R, X1, Y1, X2, Y2, ix, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
                     seen += m & 255;
