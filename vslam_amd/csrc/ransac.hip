@@ -1308,7 +1308,7 @@ __device__ __forceinline__ void cnt_store_record(float *d, const float *f, const
 }
 
 struct CntRec {
-    v2f f[9];
+    float f[9];   // the packed instructions take (f, f) operands: a splat of one register is an operand modifier (op_sel_hi)
     float lo, hi;
 };
 __device__ __forceinline__ void cnt_load_record(CntRec &R, const float *s_rec, int hh) {
@@ -1316,19 +1316,24 @@ __device__ __forceinline__ void cnt_load_record(CntRec &R, const float *s_rec, i
     const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2];
     const float f[9] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x};
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        R.f[k].x = f[k];
-        R.f[k].y = f[k];
-    }
+    for (int k = 0; k < 9; k++) R.f[k] = f[k];
     R.lo = v2.y;
     R.hi = v2.z;
 }
 
 // the cheap value g for two matches per lane; dd returned for the caller's denormal check
+__device__ __forceinline__ v2f cnt_splat(float f) {
+    v2f r;
+    r.x = f;
+    r.y = f;
+    return r;
+}
 __device__ __forceinline__ v2f cnt_cheap(const CntRec &R, const v2f X1, const v2f Y1, const v2f X2, const v2f Y2, v2f &dd) {
-    const v2f a0 = (R.f[0] * X1 + R.f[1] * Y1) + R.f[2];
-    const v2f a1 = (R.f[3] * X1 + R.f[4] * Y1) + R.f[5];
-    const v2f a2 = (R.f[6] * X1 + R.f[7] * Y1) + R.f[8];
+    const v2f f0 = cnt_splat(R.f[0]), f1 = cnt_splat(R.f[1]), f2 = cnt_splat(R.f[2]), f3 = cnt_splat(R.f[3]), f4 = cnt_splat(R.f[4]),
+              f5 = cnt_splat(R.f[5]), f6 = cnt_splat(R.f[6]), f7 = cnt_splat(R.f[7]), f8 = cnt_splat(R.f[8]);
+    const v2f a0 = (f0 * X1 + f1 * Y1) + f2;
+    const v2f a1 = (f3 * X1 + f4 * Y1) + f5;
+    const v2f a2 = (f6 * X1 + f7 * Y1) + f8;
     const v2f n = (X2 * a0 + Y2 * a1) + a2;
     const v2f nn = n * n;
     dd = a0 * a0;
@@ -1336,8 +1341,8 @@ __device__ __forceinline__ v2f cnt_cheap(const CntRec &R, const v2f X1, const v2
     r.x = __builtin_amdgcn_rcpf(dd.x);
     r.y = __builtin_amdgcn_rcpf(dd.y);
     v2f g = __builtin_elementwise_fma(a1, a1, nn * r);
-    const v2f t0 = __builtin_elementwise_fma(R.f[3], Y2, __builtin_elementwise_fma(R.f[0], X2, R.f[6]));
-    const v2f t1 = __builtin_elementwise_fma(R.f[4], Y2, __builtin_elementwise_fma(R.f[1], X2, R.f[7]));
+    const v2f t0 = __builtin_elementwise_fma(f3, Y2, __builtin_elementwise_fma(f0, X2, f6));
+    const v2f t1 = __builtin_elementwise_fma(f4, Y2, __builtin_elementwise_fma(f1, X2, f7));
     g = __builtin_elementwise_fma(t0, t0, g);
     g = __builtin_elementwise_fma(t1, t1, g);
     return g;
