@@ -1472,7 +1472,7 @@ __device__ __forceinline__ int cnt_exact_ranked(const float *F9, const float *r,
 }
 
 // One workgroup per pair.  Wave w counts pilot hypothesis w exactly (lanes over the matches) and leaves its inlier mask in
-// LDS; cbound[pair] = the best of those counts: a first lower bound on the pair's maximum count (any count of any
+// LDS; cbound[pair] = the best of those counts (stored, not accumulated: nothing has to clear it): a first lower bound on the pair's maximum count (any count of any
 // hypothesis is a valid bound; a better one only prunes more).  Then the matches are ordered by the number of pilots that
 // miss them, most-missed first, original order among equals (a counting sort over 9 keys), and written as four arrays
 // rk[pair][0..3][kp_pad] = x1, y1, x2, y2, padded with a real match up to the next multiple of 256.
@@ -1486,7 +1486,7 @@ __global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
     const int m = min(m_arr[b], kp_stride);
     if (m < min_m) return;
     __shared__ unsigned long long s_bits[kPilotHyps][VSLAM_MAX_KP / 64];
-    __shared__ int s_hist[kPilotHyps][kPilotHyps + 1], s_off[kPilotHyps][kPilotHyps + 1];
+    __shared__ int s_hist[kPilotHyps][kPilotHyps + 1], s_off[kPilotHyps][kPilotHyps + 1], s_pcount[kPilotHyps];
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
     const float2 *P2 = reinterpret_cast<const float2 *>(xy2) + (size_t)b * kp_stride;
     const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
@@ -1522,7 +1522,7 @@ __global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
                 c2 = fmaxf(c2, fmaxf(fabsf(c[u].x), fabsf(c[u].y)));
             }
         }
-        if (lane == 0) atomicMax(&cbound[b], count);
+        if (lane == 0) s_pcount[wave] = count;
         if (wave == 0) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1556,6 +1556,9 @@ __global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
     }
     __syncthreads();
     if (tid == 0) {
+        int best = 0;   // the first word written to cbound[pair] in a call: a plain store, nothing to clear beforehand
+        for (int w = 0; w < npil; w++) best = max(best, s_pcount[w]);
+        cbound[b] = best;
         int run = 0;
         for (int v = kPilotHyps; v >= 0; v--)
             for (int w = 0; w < kPilotHyps; w++) {
@@ -2287,7 +2290,6 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         if ((rc = vs_arena_get(ctx, "ransac.pot0", sizeof(int32_t) * (size_t)batch * hyp, (void **)&pot0))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.rk", sizeof(float) * 4 * (size_t)kp_pad * batch, (void **)&rk))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.cmax", sizeof(float) * 2 * (size_t)batch, (void **)&cmax))) return rc;
-        VS_HIP(ctx, hipMemsetAsync(cbound, 0, sizeof(int32_t) * (size_t)batch, ctx->stream));
         {
             VsProfScope ps(ctx, "ransac_rank_kernel");
             ransac_rank_kernel<<<batch, kRankThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, kp_pad, hyp, threshold, hypF,

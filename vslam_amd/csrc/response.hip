@@ -620,7 +620,7 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
 
 
 // Responses + candidate keys for vs_launch_good_features: keys[f][0 .. counts[f]) = (ordered response << 32 | pixel
-// offset [| kKeyCheck*]), frame_max[f] = ordered maximum response.  counts must be zero on entry.  The streaming
+// offset [| kKeyCheck*]), frame_max[f] = ordered maximum response.  counts and fmax must be zero on entry.  The streaming
 // form fills edge[f][strip][2][h] (vs_response_strips(w) strips) and leaves eig untouched; the tiled form fills eig.
 int vs_response_strips(int w) { return vs_div_up(w, kSW); }
 
@@ -629,8 +629,7 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
                                   size_t key_cap) {
     int rc;
     const bool fused = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
-    if (fused) {
-        VS_HIP(ctx, hipMemsetAsync(fmax, 0, sizeof(uint32_t) * (size_t)frames, ctx->stream));
+    if (fused) {   // fmax is zero on entry, like counts (the caller clears both with one memset)
         VsProfScope ps(ctx, "min_eigen_kernel");
         const int strips = vs_div_up(w, kSW);
         const int segs = vs_stream_segments(h, frames, strips);

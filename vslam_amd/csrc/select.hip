@@ -786,8 +786,9 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     const int strips = vs_response_strips(w);
     if ((rc = vs_arena_get(ctx, "gf.eig", sizeof(float) * px * frames, (void **)&eig))) return rc;
     if ((rc = vs_arena_get(ctx, "gf.edge", sizeof(float) * 2 * (size_t)strips * h * frames, (void **)&edge))) return rc;
-    if ((rc = vs_arena_get(ctx, "gf.fmax", sizeof(uint32_t) * (size_t)frames, (void **)&fmax))) return rc;
-    if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), (void **)&counts))) return rc;
+    // counts[frames], overflow, frame maxima[frames]: one block, so that one memset clears all of it
+    if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * (2 * (size_t)frames + 1), (void **)&counts))) return rc;
+    fmax = counts + frames + 1;
     if ((rc = vs_arena_get(ctx, "gf.state", px * frames, (void **)&state))) return rc;
     // every interior pixel can be a candidate (a plateau equals its own dilation), so the key list
     // is sized for the whole image: exactness over memory
@@ -795,7 +796,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     if ((rc = vs_arena_get(ctx, "gf.keys", sizeof(unsigned long long) * key_cap * frames, (void **)&keys))) return rc;
     overflow = reinterpret_cast<int32_t *>(counts + frames);
 
-    VS_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)frames + sizeof(int32_t), ctx->stream));
+    VS_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (2 * (size_t)frames + 1), ctx->stream));
     if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, edge, fmax, keys, counts, key_cap))) return rc;
     if (ctx->fork_after_eigen) {   // the caller runs an independent stage on the auxiliary stream beside the selection
         VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
