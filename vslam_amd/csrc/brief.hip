@@ -219,6 +219,19 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
 
 }  // namespace
 
+// The rotated pattern table depends on the pattern and the angle alone: a caller that has an idle stream ahead of the
+// description stage (vslam_extract_features: the auxiliary stream, in front of the blur) launches it there and
+// vs_launch_orb_describe skips its own launch.  The caller guarantees the ordering (it joins that stream before describing).
+int vs_launch_rbrief_rotate(vslam_ctx *ctx, const int8_t *pattern, float ca, float sa) {
+    int32_t *table = nullptr;
+    int rc = vs_arena_get(ctx, "rbrief.table", sizeof(int32_t) * 513, (void **)&table);
+    if (rc) return rc;
+    rbrief_rotate_kernel<<<1, 512, 0, ctx->stream>>>(pattern, ca, sa, table);
+    VS_HIP(ctx, hipGetLastError());
+    ctx->rbrief_table_ready = true;
+    return VSLAM_OK;
+}
+
 int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, int w, int h,
                            const float *xy_in, const int32_t *n_in, int kp_stride, float ca, float sa,
                            const int8_t *pattern, float *xy_out, uint8_t *desc, int32_t *n_out) {
@@ -235,7 +248,7 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
             int32_t *table = nullptr;
             int rc = vs_arena_get(ctx, "rbrief.table", sizeof(int32_t) * 513, (void **)&table);
             if (rc) return rc;
-            rbrief_rotate_kernel<<<1, 512, 0, ctx->stream>>>(pattern, ca, sa, table);
+            if (!ctx->rbrief_table_ready) rbrief_rotate_kernel<<<1, 512, 0, ctx->stream>>>(pattern, ca, sa, table);
             const int per_frame_lds = vs_div_up(kp_stride, kRGroups * (kKT / 32));
             rbrief_lds_kernel<<<vs_xcd_grid(frames, per_frame_lds), kKT, 0, ctx->stream>>>(
                 blurred, w, h, xy_out, n_out, kp_stride, table, desc, frames, per_frame_lds);
@@ -244,6 +257,7 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
                                                                                     sa, pattern, desc, frames, per_frame);
         }
     }
+    ctx->rbrief_table_ready = false;   // a caller's early launch (vs_launch_rbrief_rotate) covers one describe call
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }

@@ -458,6 +458,9 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     {
         hipStream_t main_stream = ctx->stream;
         if (overlap) ctx->stream = ctx->aux_stream;
+        if (overlap && width % 4 == 0)   // the table the description stage will want: off the main stream's critical path
+            rc = vs_launch_rbrief_rotate(ctx, params->d_pattern, params->cos_a, params->sin_a);
+        if (rc == VSLAM_OK)
         rc = vs_launch_gaussian7(ctx, gray, frames, width, height, blur);                                // ORB::compute
         ctx->stream = main_stream;
         if (rc) return rc;

@@ -40,6 +40,7 @@ struct vslam_ctx {
     int raw_batch = 0, raw_hyp = 0;
     int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, 1 fork after bgr2gray, 2 fork after min_eigen
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
+    bool rbrief_table_ready = false; // transient: the rotated rBRIEF table of the coming describe call is already queued
     int ransac_min_matches = VSLAM_SET_SIZE;   // VSLAM_OPT_RANSAC_MIN_MATCHES
     int ransac_solver = 0;                      // VSLAM_OPT_RANSAC_SOLVER: 0 exact Jacobi replay, 1 Gram / MFMA (not bit-exact)
     int match_shape = 0;                        // VSLAM_OPT_MATCH_SHAPE: 0 by size, 1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows
@@ -165,6 +166,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
                             int max_corners, double quality, double min_distance, int kp_stride,
                             float *xy, int32_t *n);
 int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, uint8_t *out);
+int vs_launch_rbrief_rotate(vslam_ctx *ctx, const int8_t *pattern, float ca, float sa);
 int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, int w, int h,
                            const float *xy_in, const int32_t *n_in, int kp_stride, float ca, float sa,
                            const int8_t *pattern, float *xy_out, uint8_t *desc, int32_t *n_out);
