@@ -377,7 +377,7 @@ __device__ __forceinline__ void jacobi_finish(float *pA, float *pV, float *wout,
 #undef FA
 #undef FV
 
-template <int M, int N, int N1, bool HASV, bool ROWREG = false>
+template <int M, int N, int N1, bool HASV>
 __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, float *extra_row) {
     static_assert(N1 == N || N1 == N + 1, "FULL_UV asks for at most one row beyond the rank here");
     constexpr int max_iter = M > 30 ? M : 30;
@@ -389,7 +389,6 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
         }
     }
 
-    if (!ROWREG) {
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
         for (int i = 0; i < N - 1; i++)
@@ -458,94 +457,6 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
         if (!changed) break;
     }
 
-    } else {
-    for (int iter = 0; iter < max_iter; iter++) {
-        bool changed = false;
-        for (int i = 0; i < N - 1; i++) {
-            // Row i stays in registers while j walks the rows below it (a rotation updates it in place, under the lane's
-            // mask) and goes back to LDS once per i.  Same operations on the same values as reading both rows per
-            // pair, so the bits do not change; the LDS traffic halves (1.03 -> 0.97 ms at C3).  Fetching row j + 1
-            // ahead of time on top of that was slower (1.06 ms), and the 3x3 instance is faster with the plain form.
-            // So do its double conversions and its squared norm W[i]: both are functions of the current row only, and are
-            // redone (same operations, same order) where a rotation changes it.
-            float ai[M];
-            double dai[M];
-            double a = 0;   // W[i]
-#pragma unroll
-            for (int k = 0; k < M; k++) {
-                ai[k] = VS_A(i, k);
-                dai[k] = (double)ai[k];
-                a = __builtin_fma(dai[k], dai[k], a);
-            }
-            for (int j = i + 1; j < N; j++) {
-                float aj[M];
-#pragma unroll
-                for (int k = 0; k < M; k++) aj[k] = VS_A(j, k);
-                double p = 0, b = 0;
-#pragma unroll
-                for (int k = 0; k < M; k++) {
-                    const double dj = (double)aj[k];
-                    p = __builtin_fma(dai[k], dj, p);
-                    b = __builtin_fma(dj, dj, b);   // W[j]
-                }
-                if (jacobi_converged(p, a, b)) continue;
-
-                p *= 2;
-                const double beta = a - b;
-                const double g2 = p * p + beta * beta;
-                float c, s;
-                // see the plain form above for the range argument
-                const bool safe = g2 > 0x1p-400 && g2 < 0x1p400 && fabs(p) > 0x1p-300;
-                if (!__any(!safe)) {
-                    const double gamma = sqrt_inrange(g2);   // pinned hypot
-                    if (beta < 0) {
-                        const double delta = (gamma - beta) * 0.5;
-                        s = (float)sqrt_inrange(div_inrange(delta, gamma));
-                        c = (float)div_inrange(p, gamma * (double)s * 2);
-                    } else {
-                        c = (float)sqrt_inrange(div_inrange(gamma + beta, gamma * 2));
-                        s = (float)div_inrange(p, gamma * (double)c * 2);
-                    }
-                } else {
-                    const double gamma = sqrt(g2);   // pinned hypot
-                    if (beta < 0) {
-                        const double delta = (gamma - beta) * 0.5;
-                        s = (float)sqrt(delta / gamma);
-                        c = (float)(p / (gamma * (double)s * 2));
-                    } else {
-                        c = (float)sqrt((gamma + beta) / (gamma * 2));
-                        s = (float)(p / (gamma * (double)c * 2));
-                    }
-                }
-                a = 0;
-#pragma unroll
-                for (int k = 0; k < M; k++) {
-                    const float t0 = c * ai[k] + s * aj[k];
-                    const float t1 = (-s) * ai[k] + c * aj[k];
-                    ai[k] = t0;
-                    VS_A(j, k) = t1;
-                    dai[k] = (double)t0;
-                    a = __builtin_fma(dai[k], dai[k], a);
-                }
-                changed = true;
-                if (HASV) {
-#pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        const float vi = VS_V(i, k), vj = VS_V(j, k);
-                        const float t0 = c * vi + s * vj;
-                        const float t1 = (-s) * vi + c * vj;
-                        VS_V(i, k) = t0;
-                        VS_V(j, k) = t1;
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < M; k++) VS_A(i, k) = ai[k];
-        }
-        if (!changed) break;
-    }
-
-    }
     jacobi_finish<M, N, N1, HASV, kSolveThreads>(sA + tid, HASV ? sV + tid : nullptr, wout, extra_row);
 }
 
@@ -557,7 +468,7 @@ __device__ void jacobi_svd_lanes(float *sA, float *sV, int tid, float *wout, flo
 // eight rows in registers (72 VGPRs; every (i, j) step written out, the row indices compile-time) the sweeps touch no
 // LDS at all, 128 VGPRs suffice and 4 waves fit.  Only the part after the sweeps wants rows by run-time index: rows
 // 0..3 go to LDS for it (36 floats per lane).  Every operation on every value is the one
-// jacobi_svd_lanes<9, 8, 9, false, true> performs, in the same order.
+// jacobi_svd_lanes<9, 8, 9, false> (the plain restatement above) would perform, in the same order.
 constexpr int kSolveLdsRows = 4;
 constexpr int kSolveSplitFloats = kSolveLdsRows * 9;
 
