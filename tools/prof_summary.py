@@ -10,7 +10,7 @@ import sys
 
 OURS = re.compile(r"\(anonymous namespace\)::((?:bgr2gray|min_eigen|corner_[a-z]+|gaussian7|keypoint_border|rbrief|"
                   r"kdtree_[a-z]+|match_[a-z0-9]+|ransac_[a-z]+|fast_[a-z]+|pyr_[a-z0-9]+|grid_[a-z_]+|orb_[a-z]+|harris|"
-                  r"ic_angle|retain_best)(?:_v4|_stream|_lds|_rotate|_mfma)?_kernel)[<(]")
+                  r"ic_angle|retain_best)(?:_v4|_stream|_tiered|_lds|_rotate|_mfma)?_kernel)[<(]")
 
 
 def main(src, dst):

@@ -9,7 +9,7 @@ import re
 import sys
 
 NAME = re.compile(r"((?:bgr2gray|min_eigen|corner_[a-z]+|gaussian7|keypoint_border|rbrief|kdtree_[a-z]+|match_[a-z0-9]+|"
-                  r"ransac_[a-z]+)(?:_v4|_stream|_lds|_rotate|_mfma)?_kernel)")
+                  r"ransac_[a-z]+)(?:_v4|_stream|_tiered|_lds|_rotate|_mfma)?_kernel)")
 
 
 def main(src, dst):

@@ -158,10 +158,24 @@ int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, in
                        uint8_t *gray);
 int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, float *eig,
                         uint32_t *frame_max_bits);
-int vs_response_strips(int w);   // column strips of the streaming response kernel (edge buffer layout)
+// per-frame counters of the corner pipeline: one zero-initialised block (select.hip lays it out)
+struct VsCornerCounters {
+    uint32_t *counts;    // entries in the detector's list
+    uint32_t *fmax;      // ordered exact maximum response
+    uint32_t *low;       // two-tier detector: certified lower bound of maximum / c0 (ordered)
+    uint32_t *count2;    // exact keys above the cut
+    uint32_t *count3;    // exact keys of the rerun (flagged frames, nothing cut)
+    uint32_t *need;      // the selection ran out of candidates above the cut: rerun this frame with everything
+    uint32_t *cutkey;    // ordered response below which keys2 is incomplete (0: complete)
+    uint32_t *hist;      // two-tier detector: the listed upper bounds by magnitude
+};
+size_t vs_response_hist_words(int frames);
 int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, double quality,
-                                  float *eig, float *edge, uint32_t *fmax, unsigned long long *keys, uint32_t *counts,
-                                  size_t key_cap);
+                                  float *eig, const VsCornerCounters &c, unsigned long long *keys,
+                                  unsigned long long *keys2, size_t key_cap, uint32_t n_safe, int *raw_list);
+int vs_launch_corner_exact(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, const VsCornerCounters &c,
+                           const unsigned long long *keys, unsigned long long *keys2, size_t key_cap, uint32_t n_safe,
+                           int mode);
 int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h,
                             int max_corners, double quality, double min_distance, int kp_stride,
                             float *xy, int32_t *n);

@@ -71,11 +71,115 @@ __device__ __forceinline__ float dpp_wave_shl1(float v, float fill) {   // lane 
 }
 
 
-// Strips do not overlap, so the 3x3 test of a strip's first and last column lacks the neighbouring strip's
-// column.  Such candidates are emitted with a flag in the (otherwise unused) top bits of the pixel offset and
-// corner_select_kernel completes their test against the stored responses before anything else looks at them.
-constexpr uint32_t kKeyCheckLeft = 0x80000000u, kKeyCheckRight = 0x40000000u;
-constexpr uint32_t kOffMask = 0x3FFFFFFFu;   // pixel offset part of a key's low word
+// ---- candidate lists of the corner pipeline (response.hip -> select.hip) -----------------------------------------
+// 64-bit entries, ordered float in the high word so that an unsigned compare is the float compare.
+//   exact key   = ordered(response) << 32 | pixel offset
+//   raw entry   = ordered(certified UPPER bound of response / c0) << 32 | kKeyUncertain? | pixel offset
+//                 (the two-tier detector's list; kKeyUncertain: the cheap values cannot show that the pixel is a 3x3
+//                 maximum, so it has to be compared with its exact neighbours)
+constexpr uint32_t kKeyUncertain = 0x20000000u;
+constexpr uint32_t kOffMask = 0x0FFFFFFFu;   // pixel offset part of an entry's low word
 
+// ---- cornerMinEigenVal at single pixels, the oracle's exact sequence (oracle/vso_extract.cpp:44-114) -------------
+__device__ __forceinline__ float sqrt_rn1(float t) {   // correctly rounded, per lane
+    const uint32_t b = __float_as_uint(t) - 1u;
+    if (__builtin_expect(b < 0x0F800000u - 1u, 0)) return sqrtf(t);   // 0 < t < 2^-96
+    return sqrt_rn_fast1(t);
+}
+
+// calcMinEigenVal in float from the three box sums
+__device__ __forceinline__ float min_eigen_from_sums(double Sxx, double Sxy, double Syy) {
+    const float sxx = (float)Sxx, sxy = (float)Sxy, syy = (float)Syy;
+    const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
+    const float amc = a - c;
+    const float t = amc * amc + b * b;
+    return (a + c) - sqrt_rn1(t);
+}
+
+// A pixel whose 5x5 gray window lies inside the image (2 <= x < w - 2, 2 <= y < h - 2): float Sobel with the scale
+// folded into the smoothing taps, products, horizontal sums then vertical in double.
+__device__ __forceinline__ float min_eigen_exact_interior(const uint8_t *src, int w, int x, int y, float k0, float k1) {
+    float g[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint8_t *p = src + (size_t)(y - 2 + r) * w + (x - 2);
+        uint32_t d;
+        __builtin_memcpy(&d, p, 4);
+        g[r][0] = cvt_ubyte<0>(d); g[r][1] = cvt_ubyte<1>(d); g[r][2] = cvt_ubyte<2>(d); g[r][3] = cvt_ubyte<3>(d);
+        g[r][4] = (float)p[4];
+    }
+    float hx[5][3], rr[5][3];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            hx[r][c] = g[r][c + 2] - g[r][c];
+            const float a = g[r][c + 1] * k0;
+            const float b = (g[r][c] + g[r][c + 2]) * k1;
+            rr[r][c] = a + b;
+        }
+    double rxx[3], rxy[3], ryy[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float cxx[3], cxy[3], cyy[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float a = hx[r + 1][c] * k0;
+            const float b = (hx[r][c] + hx[r + 2][c]) * k1;
+            const float dx = a + b;
+            const float dy = rr[r + 2][c] - rr[r][c];
+            cxx[c] = dx * dx;
+            cxy[c] = dx * dy;
+            cyy[c] = dy * dy;
+        }
+        rxx[r] = ((double)cxx[0] + (double)cxx[1]) + (double)cxx[2];
+        rxy[r] = ((double)cxy[0] + (double)cxy[1]) + (double)cxy[2];
+        ryy[r] = ((double)cyy[0] + (double)cyy[1]) + (double)cyy[2];
+    }
+    return min_eigen_from_sums((rxx[0] + rxx[1]) + rxx[2], (rxy[0] + rxy[1]) + rxy[2], (ryy[0] + ryy[1]) + ryy[2]);
+}
+
+// Any pixel: the box filter's BORDER_REFLECT_101 on product coordinates, the Sobel's on gray coordinates.  Rolled
+// loops on purpose (rare path, small code); the sums accumulate in the oracle's order.
+__device__ __forceinline__ float min_eigen_exact_border(const uint8_t *src, int w, int h, int x, int y, float k0, float k1) {
+    double Sxx = 0, Sxy = 0, Syy = 0;
+#pragma nounroll
+    for (int r = 0; r < 3; r++) {
+        double rxx = 0, rxy = 0, ryy = 0;
+#pragma nounroll
+        for (int c = 0; c < 3; c++) {
+            const int px = reflect101(x - 1 + c, w), py = reflect101(y - 1 + r, h);
+            const int xm = reflect101(px - 1, w), xp = reflect101(px + 1, w);
+            float hx[3], rr[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint8_t *row = src + (size_t)reflect101(py - 1 + k, h) * w;
+                const float gm = (float)row[xm], g0 = (float)row[px], gp = (float)row[xp];
+                hx[k] = gp - gm;
+                const float a = g0 * k0;
+                const float b = (gm + gp) * k1;
+                rr[k] = a + b;
+            }
+            const float a = hx[1] * k0;
+            const float b = (hx[0] + hx[2]) * k1;
+            const float dx = a + b;
+            const float dy = rr[2] - rr[0];
+            const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
+            // ((c0 + c1) + c2): the first addition is 0 + c0, which is exact
+            rxx = rxx + (double)cxx;
+            rxy = rxy + (double)cxy;
+            ryy = ryy + (double)cyy;
+        }
+        Sxx = Sxx + rxx;
+        Sxy = Sxy + rxy;
+        Syy = Syy + ryy;
+    }
+    return min_eigen_from_sums(Sxx, Sxy, Syy);
+}
+
+__device__ __forceinline__ float min_eigen_exact(const uint8_t *src, int w, int h, int x, int y, float k0, float k1) {
+    if (x >= 2 && x < w - 2 && y >= 2 && y < h - 2) return min_eigen_exact_interior(src, w, x, y, k0, k1);
+    return min_eigen_exact_border(src, w, h, x, y, k0, k1);
+}
 
 }  // namespace

@@ -249,213 +249,279 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------
-// Streaming form of the fused response + 3x3-maxima kernel (width % 4 == 0)
+// Two-tier streaming form (the front-end path): certified cheap responses for every pixel, the oracle's exact
+// arithmetic only where a value can be observed
 // ------------------------------------------------------------------------------------------
-// One wave owns a column strip (64 lanes x 4 pixels) and walks down a segment of rows.  Everything that the
-// tile form recomputes at tile seams rolls in registers instead: the two previous rows of horizontal Sobel
-// parts, the two previous rows of horizontal product sums, the two previous rows of responses and of their
-// horizontal 3-maxima.  The corner threshold needs the frame's maximum, which is not known yet, so candidates
-// are prefiltered with a running maximum (always <= the final one, hence a superset) and
-// corner_select_kernel applies the exact threshold.  Gray rows come straight from
-// global memory (three coalesced dwords per lane and row, issued three rows ahead), responses of the
-// neighbouring lanes come through DPP wave shifts, so the kernel uses no LDS except the candidate queue
-// and has no barriers.  It writes no response image: candidate keys, the frame maximum and each strip's two
-// edge columns of responses are everything later stages read.  Arithmetic and its order are those of min_eigen_v4_kernel (see there).
+// What later stages can observe of cornerMinEigenVal is (a) the frame maximum, (b) which interior pixels are above
+// max * quality and not below any 3x3 neighbour, and (c) the responses of exactly those pixels (they rank the
+// corners).  About 2 % of the pixels.  min_eigen_stream_kernel nevertheless pays the exact sequence — f64 box sums,
+// correctly rounded sqrt — for every pixel, and is bound by those instructions.  Here every pixel first gets
+//     U~ = (A + C) - sqrt((A - C)^2 + 4 B^2),   A = sum dxi^2, B = sum dxi dyi, C = sum dyi^2 over the 3x3 window,
+// where dxi, dyi are the INTEGER Sobel responses of the 8-bit image.  All of it up to A, B, C is integer arithmetic on
+// values below 2^24, carried in f32 registers (v_add / v_sub / v_mul_f32 are the cheapest vector instructions of this
+// chip and exact on such values), so A, B, C are the exact real quantities that the reference's float pipeline
+// approximates; only tr = A + C (< 2^25), the square root and the last subtraction round.
 //
-// Step t of a segment owning rows [ys, ye):   gray row g = ys - 3 + t   (Sobel parts of row g)
-//   t >= 2: products and their horizontal sums on row p = g - 1
-//   t >= 4: response row y = p - 1 = ys - 5 + t  (stored when ys <= y < ye)
-//   t >= 6: 3x3-maxima test of row y - 1 = ys - 6 + t  -> candidates
-// so a segment takes (ye - ys) + 6 steps, 6 of them warm-up (7 % at 90 rows per segment).
+// Certified distance to the reference value e (float, scaled by c0 = 0.5 / (4*3*255)^2):  |e / c0 - U~| <= m(tr),
+//     m(tr) = 0.016 sqrt(tr) + 32 u tr + 1e-3,     u = 2^-24.
+// Derivation (s = 1 / 3060; "int units" = multiples of s resp. s^2):
+//   * Dx = fl(fl(hx0 k0) + fl((hxm + hxp) k1)), k1 = fl(s), k0 = 2 k1: each product carries a relative error u on a
+//     term of up to 510 s, the sum may cancel, so |Dx / s - dxi| <= u (2 |dxi| + 1020) <= 3060 u.  Dy = fl(R2 - R0)
+//     with R = fl(fl(g0 k0) + fl((gm + gp) k1)) <= 1020 s carrying three roundings each:
+//     |Dy / s - dyi| <= 3.01 u * 2040 + 1.01 u |dyi| <= 7200 u =: ed = 4.3e-4 (absolute, whatever the derivative is —
+//     this is the "rounding residue" of a derivative that is zero in exact arithmetic).
+//   * products: |c / s^2 - di dj| <= ed (|di| + |dj|) + ed^2 + u (|di| + ed)(|dj| + ed); nine of them, summed exactly
+//     enough in f64 (2^-53), rounded once to float: with Cauchy-Schwarz (sum |di| <= 3 sqrt(A)),
+//     |Sxx/s^2 - A| <= 6 ed sqrt(A) + 2.1 u A + 1e-5, likewise C, and |Sxy/s^2 - B| <= 3 ed (sqrt A + sqrt C) + 2.1 u sqrt(AC) + u|B| + 1e-5.
+//   * U is 2-Lipschitz in each of A, C, B; calcMinEigenVal's own float steps add <= 5 u tr; this kernel's tr, square
+//     root (v_sqrt_f32, 1 ulp) and subtraction add <= 5 u tr.  Together
+//     |e / c0 - U~| <= 25.5 ed sqrt(tr) + 19.3 u tr + 6e-5 = 0.011 sqrt(tr) + 19.3 u tr + 6e-5  <  m(tr).
+//   tests/test_min_eigen_bound.py measures the distance on synthetic and adversarial images (noise at 0/255, bright
+//   low-contrast noise, checkerboards, ramps): it stays below 4 % of m.
+//
+// A pixel p is POSSIBLE if U~p + 2 mw >= every neighbour's U~ and >= the running threshold bound, where mw is m() of
+// the largest tr in the lane's 6 x 3 neighbourhood (so it bounds the margin of p and of every neighbour, plus the
+// roundings of these comparisons).  Possible pixels (a superset of the candidates and of the frame maximum) queue up
+// per wave in LDS and are evaluated 64 at a time with the oracle's exact sequence — that value is what is stored in the
+// key.  If U~p - 2 mw >= every neighbour's U~ the pixel is certainly a 3x3 maximum; otherwise (0.7 % of the possible
+// ones on image data: near-ties, and the candidates on a strip's first / last column, whose outer neighbours the wave
+// does not have) the needed neighbours are evaluated exactly as well, eight candidates x eight neighbours per round,
+// and compared as the reference compares them.  The first / last row and column are not candidate positions but count
+// for the maximum: they queue when U~ + 2 mw reaches the best certified lower bound of the maximum.
+// Keys, the frame maximum and their consumers (corner_select_kernel) are unchanged; no key carries a strip flag.
 constexpr int kSW = 256;     // pixels per strip (64 lanes x 4), all owned
-constexpr int kSQ = 512;     // candidate queue entries per wave
-struct StreamState {
-    float hx[3][6], rr[3][6];      // per gray row: x-derivative parts and smoothed values, columns x-1 .. x+4
-    double T[12], X[2][12];        // horizontal 3-sums of xx, xy, yy for the lane's 4 pixels: X[t & 1] = those of the
-                                   // product row of step t, X[~t & 1] of the row before, T = the sum of the two rows
-                                   // before this step's.  The column sum S(y) = (r(y-1) + r(y)) + r(y+1) is T + r(y+1)
-                                   // — the same two additions in the same order as three stored rows would give —
-                                   // and neither a third row of state nor a register copy per value is needed: the
-                                   // new row is computed straight into the slot of the row that just left the window
-                                   // (the difference between 2 and 3 waves per SIMD)
-    float ctr[3][4], hm[3][4];     // per response row: the values and their horizontal 3-maxima
-    uint32_t raw[3][3];            // prefetched gray dwords (x-4, x, x+4) of the next three rows
-    float emax;
+constexpr int kTQ1 = 576;    // possible pixels staged per wave for its next global append (at most 63 left over + 2 rows of 256)
+constexpr float kTierSqrt = 0.032f, kTierLin = 80.f / 16777216.f, kTierAbs = 0.004f;   // 2 m(tr) + comparison roundings
+constexpr float kTierC0Up = 5.3398290e-8f;   // c0 = 0.5 / 3060^2 = 5.33982656e-8, rounded up by 2^-21 and more
+// histogram of the listed upper bounds: 8 bins per octave (exponent + 3 mantissa bits) from 2^-6 to 2^26 (U~ < 2^25.2);
+// smaller values share bin 0, whose lower edge is therefore "everything"
+constexpr int kTierBins = 256, kTierBin0 = (127 - 6) << 3;
+__device__ __forceinline__ uint32_t tier_bin(uint32_t ordered_hi) {
+    const int b = (int)((ordered_hi >> 20) & 0x7FFu) - kTierBin0;
+    return (uint32_t)(b < 0 ? 0 : (b > kTierBins - 1 ? kTierBins - 1 : b));
+}
+__device__ __forceinline__ uint32_t tier_bin_edge(uint32_t bin) {   // smallest ordered value of a bin
+    return bin == 0u ? 0u : (0x80000000u | ((bin + (uint32_t)kTierBin0) << 20));
+}
+
+// Every ring has two slots (index t & 1): a value of row t - 2 is read, at the latest, while row t's is formed.
+struct TierState {
+    float hx[2][6], q[2][6], rs[2][6];   // per gray row: x-derivative parts, their two-row sums, smoothed values (columns x-1 .. x+4)
+    float T[12], X[2][12];               // horizontal 3-sums of xx, xy, yy (see StreamState), integers in f32
+    float ctr[2][4], hm[2][4];           // per response row: U~ and its horizontal 3-maxima
+    float lf[2], rg[2], trm[2];          // U~ of the lane to the left / right, largest tr of the row's six columns
+    uint32_t raw[2][3];                  // gray dwords (x-4, x, x+4) of the next two rows
+    float lanelow;                       // certified lower bound of the best response of this lane's pixels (U units)
 };
 
-struct StreamArgs {
-    const uint8_t *src;          // frame base
-    float *edge_l, *edge_r;      // this strip's first / last column of responses, indexed by row
-    unsigned long long *queue;   // this wave's LDS queue
-    unsigned long long *keys;    // frame base
-    uint32_t *count;             // this frame's candidate counter
-    size_t key_cap;
+struct TierArgs {
+    const uint8_t *src;
+    unsigned long long *queue;       // this wave's LDS staging queue
+    unsigned long long *list;        // this frame's list of possible pixels
+    uint32_t *whist;                 // this wave's histogram of the listed upper bounds (LDS)
+    uint32_t *count;
+    size_t cap;
     int w, h, ys, ye, x, steps;
     uint32_t voff_l, voff_c, voff_r;
     bool edge, left_fix, right_fix, own_lane;
-    unsigned long long col_ok[4];   // lanes whose pixel i is an owned, testable column (1 <= x < w - 1)
-    float k0, k1, thr_p;
+    unsigned long long cand_ok[4];   // lanes whose pixel i is an owned candidate position (1 <= x < w - 1)
+    unsigned long long bord[4];      // lanes whose pixel i is an owned first / last column
+    unsigned long long own;          // owned lanes
+    float thrU;                      // lower bound of the final threshold, U units (-inf: none yet)
+    float lowU;                      // certified lower bound of the frame maximum, U units
+    float qf;                        // quality level, a hair low
+    uint32_t *low_max;               // this frame's shared lower bound (ordered float)
+    uint32_t published;
+    int qn;
 };
 
-__device__ __forceinline__ void stream_flush(const StreamArgs &a, int &qn, int lane) {
-    if (qn == 0) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(a.count, (uint32_t)qn);
-    base = __builtin_amdgcn_readfirstlane(base);
-    for (int i = lane; i < qn; i += 64) {
-        const size_t pos = (size_t)base + i;
-        if (pos < a.key_cap) a.keys[pos] = a.queue[i];
+// Tighten the wave's bounds with the best certified response its lanes have seen, and share it with the frame's other waves.
+__device__ __forceinline__ void tier_tighten(TierArgs &a, float lanelow, int lane) {
+    const float ninf = -__builtin_inff();
+    float low = a.own_lane ? lanelow : ninf;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) low = fmaxf(low, __shfl_xor(low, off, 64));
+    if (low > a.lowU) {
+        a.lowU = low;
+        a.thrU = low > 0.f ? low * a.qf : ninf;
+        const uint32_t k = f2ord(low);
+        if (lane == 0 && k > a.published) atomicMax(a.low_max, k);   // fire and forget
+        a.published = k > a.published ? k : a.published;
     }
-    qn = 0;
 }
 
-template <int K, int P>   // K = t % 3 (three-row rings), P = t % 2 (X)
-__device__ __forceinline__ void stream_step(StreamState &st, const StreamArgs &a, int t, int &qn, int lane) {
-    constexpr int K1 = (K + 2) % 3, K2 = (K + 1) % 3;   // slots of the previous row and the one before
-    uint32_t d0 = st.raw[K][0];
-    const uint32_t d1 = st.raw[K][1];
-    uint32_t d2 = st.raw[K][2];
-    {   // Prefetch the row three steps ahead into the slot just consumed (past the segment's last step the index is
-        // clamped: a redundant load costs less than the register copies a conditional one brings).  The lane offsets
-        // are made opaque so that their zero-extension is not hoisted into 64-bit register pairs: base in SGPRs +
-        // 32-bit lane offset is an addressing mode, a 64-bit vector add is an instruction per load.
-        const int tn = t + 3 < a.steps ? t + 3 : a.steps - 1;
+__device__ __forceinline__ void tier_flush(TierArgs &a, int lane) {
+    if (a.qn == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.count, (uint32_t)a.qn);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int i = lane; i < a.qn; i += 64) {
+        const size_t pos = (size_t)base + i;
+        const unsigned long long ent = a.queue[i];
+        if (pos < a.cap) a.list[pos] = ent;
+        atomicAdd(a.whist + tier_bin((uint32_t)(ent >> 32)), 1u);   // this wave's histogram, in LDS
+    }
+    a.qn = 0;
+}
+
+template <int P>   // P = t % 2
+__device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int lane) {
+    constexpr int Q = P ^ 1;
+    uint32_t d0 = st.raw[P][0];
+    const uint32_t d1 = st.raw[P][1];
+    uint32_t d2 = st.raw[P][2];
+    {   // prefetch two rows ahead into the slot just consumed (see stream_step)
+        const int tn = t + 2 < a.steps ? t + 2 : a.steps - 1;
         const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.w;
         uint32_t ol = a.voff_l, oc = a.voff_c, orr = a.voff_r;
         asm volatile("" : "+v"(ol), "+v"(oc), "+v"(orr));
-        st.raw[K][0] = *reinterpret_cast<const uint32_t *>(rowp + ol);
-        st.raw[K][1] = *reinterpret_cast<const uint32_t *>(rowp + oc);
-        st.raw[K][2] = *reinterpret_cast<const uint32_t *>(rowp + orr);
+        st.raw[P][0] = *reinterpret_cast<const uint32_t *>(rowp + ol);
+        st.raw[P][1] = *reinterpret_cast<const uint32_t *>(rowp + oc);
+        st.raw[P][2] = *reinterpret_cast<const uint32_t *>(rowp + orr);
     }
-    if (a.edge) {   // BORDER_REFLECT_101 in x: columns -2, -1 are columns 2, 1; columns w, w+1 are w-2, w-3
+    if (a.edge) {
         if (a.left_fix) d0 = (d1 & 0x00FF0000u) | ((d1 & 0x0000FF00u) << 16);
         if (a.right_fix) d2 = ((d1 >> 16) & 0xFFu) | (d1 & 0xFF00u);
     }
-    // gray at columns x-2 .. x+5.  The conversions are opaque to the compiler on purpose: it would otherwise
-    // rewrite float(a) - float(b) as float(a - b) with byte-select integer ops, which issue slower here
-    // than one v_cvt_f32_ubyteN per pixel plus plain float subtract / add (tools/valu_rate.hip).
     float g[8];
     g[0] = cvt_ubyte<2>(d0); g[1] = cvt_ubyte<3>(d0);
     g[2] = cvt_ubyte<0>(d1); g[3] = cvt_ubyte<1>(d1); g[4] = cvt_ubyte<2>(d1); g[5] = cvt_ubyte<3>(d1);
     g[6] = cvt_ubyte<0>(d2); g[7] = cvt_ubyte<1>(d2);
+    float dy[6];
+    {
+        float pr[7];
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-        st.hx[K][c] = g[c + 2] - g[c];
-        const float p = g[c + 1] * a.k0;
-        const float q = (g[c] + g[c + 2]) * a.k1;
-        st.rr[K][c] = p + q;
+        for (int j = 0; j < 7; j++) pr[j] = g[j] + g[j + 1];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            st.hx[P][c] = g[c + 2] - g[c];
+            st.q[P][c] = st.hx[Q][c] + st.hx[P][c];          // hx of this row and the one before
+            const float rs = pr[c] + pr[c + 1];              // g(c-1) + 2 g(c) + g(c+1)
+            dy[c] = rs - st.rs[P][c];                        // the slot still holds row g - 2
+            st.rs[P][c] = rs;
+        }
     }
     if (t < 2) return;
 
-    // products on row p = g - 1
+    // integer Sobel responses on row p = g - 1 and their products
     const int prow = a.ys - 4 + t;
     const bool rowflip = prow < 0 || prow >= a.h;
-    float cxx[6], cxy[6], cyy[6];
+    float dx[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-        const float p = st.hx[K1][c] * a.k0;
-        const float q = (st.hx[K2][c] + st.hx[K][c]) * a.k1;
-        const float dx = p + q;
-        const float dy = st.rr[K][c] - st.rr[K2][c];
-        cxx[c] = dx * dx;
-        cxy[c] = dx * dy;
-        cyy[c] = dy * dy;
+    for (int c = 0; c < 6; c++) dx[c] = st.q[Q][c] + st.q[P][c];   // hx(p-1) + 2 hx(p) + hx(p+1)
+    float dx0 = dx[0], dx5 = dx[5];   // for the xy products only: a mirrored column changes that product's sign
+    if (a.edge) {
+        if (a.left_fix) dx0 = -dx0;
+        if (a.right_fix) dx5 = -dx5;
     }
-    if (a.edge) {    // mirrored column: the xy product changes sign (see min_eigen_v4_kernel)
-        if (a.left_fix) cxy[0] = -cxy[0];
-        if (a.right_fix) cxy[5] = -cxy[5];
+    float (&r)[12] = st.X[P];
+    const float (&rp)[12] = st.X[Q];
+    {   // r(i) = c(i) + c(i+1) + c(i+2), i = 0..3, over the six columns: 3 multiplies, 5 fused and 4 plain adds per channel
+        const float a1 = dx[1] * dx[1], a2 = dx[2] * dx[2], a3 = dx[3] * dx[3];
+        r[0] = __builtin_fmaf(dx[0], dx[0], a1) + a2;
+        r[1] = (a1 + a2) + a3;
+        r[2] = __builtin_fmaf(dx[4], dx[4], a2 + a3);
+        r[3] = __builtin_fmaf(dx[5], dx[5], __builtin_fmaf(dx[4], dx[4], a3));
+        const float b1 = dx[1] * dy[1], b2 = dx[2] * dy[2], b3 = dx[3] * dy[3];
+        r[4] = __builtin_fmaf(dx0, dy[0], b1) + b2;
+        r[5] = (b1 + b2) + b3;
+        r[6] = __builtin_fmaf(dx[4], dy[4], b2 + b3);
+        r[7] = __builtin_fmaf(dx5, dy[5], __builtin_fmaf(dx[4], dy[4], b3));
+        const float c1 = dy[1] * dy[1], c2 = dy[2] * dy[2], c3 = dy[3] * dy[3];
+        r[8] = __builtin_fmaf(dy[0], dy[0], c1) + c2;
+        r[9] = (c1 + c2) + c3;
+        r[10] = __builtin_fmaf(dy[4], dy[4], c2 + c3);
+        r[11] = __builtin_fmaf(dy[5], dy[5], __builtin_fmaf(dy[4], dy[4], c3));
     }
-    double (&r)[12] = st.X[P];
-    const double (&rp)[12] = st.X[P ^ 1];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        r[i] = ((double)cxx[i] + (double)cxx[i + 1]) + (double)cxx[i + 2];
-        r[4 + i] = ((double)cxy[i] + (double)cxy[i + 1]) + (double)cxy[i + 2];
-        r[8 + i] = ((double)cyy[i] + (double)cyy[i + 1]) + (double)cyy[i + 2];
-    }
-    if (rowflip) {   // mirrored row (two per frame): same rule; negating the sums equals summing the negated products
-        asm volatile("" ::: "memory");   // keep this a branch: as selects it would cost every row
+    if (rowflip) {
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; i++) r[4 + i] = -r[4 + i];
     }
     if (t >= 4) {
-        const int y = a.ys - 5 + t;
-        float apc[4], tt[4], rt[4], e4[4];
+        float u4[4], tr4[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            // column sums S(y) = (r(y-1) + r(y)) + r(y+1)
-            const float sxx = (float)(st.T[i] + r[i]);
-            const float sxy = (float)(st.T[4 + i] + r[4 + i]);
-            const float syy = (float)(st.T[8 + i] + r[8 + i]);
-            const float ea = sxx * 0.5f, eb = sxy, ec = syy * 0.5f;
-            const float amc = ea - ec;
-            tt[i] = amc * amc + eb * eb;
-            apc[i] = ea + ec;
+            const float A = st.T[i] + r[i], B = st.T[4 + i] + r[4 + i], C = st.T[8 + i] + r[8 + i];
+            const float tr = A + C, d = A - C, b2 = B + B;
+            const float tt = __builtin_fmaf(b2, b2, d * d);
+            tr4[i] = tr;
+            u4[i] = tr - __builtin_amdgcn_sqrtf(tt);
         }
-        sqrt_rn4(tt, rt);
-#pragma unroll
-        for (int i = 0; i < 4; i++) e4[i] = apc[i] - rt[i];
-        if (y >= a.ys && y < a.ye && a.own_lane) {
-            st.emax = max3_nonan(max3_nonan(e4[0], e4[1], e4[2]), e4[3], st.emax);
-            // the response image itself is not kept: all that is read back later are the strip's edge columns
-            // (corner_select_kernel completes the 3x3 test of the neighbouring strips' edge candidates with them)
-            if (lane == 0) a.edge_l[y] = e4[0];
-            if (lane == 63) a.edge_r[y] = e4[3];
-        }
-        // rows y < 0 or y >= h, and the pixels of lanes outside the image, are never a neighbour of a testable
-        // pixel (tests cover rows 1 .. h-2 and columns 1 .. w-2), so their values need no special marking
-        const float ninf = -__builtin_inff();   // what lane 0 / lane 63 see beyond the strip: resolved later (kKeyCheck*)
-        const float lf = dpp_wave_shr1(e4[3], ninf), rg = dpp_wave_shl1(e4[0], ninf);
-#pragma unroll
-        for (int i = 0; i < 4; i++) st.ctr[K][i] = e4[i];
-        st.hm[K][0] = max3_nonan(lf, e4[0], e4[1]);
-        st.hm[K][1] = max3_nonan(e4[0], e4[1], e4[2]);
-        st.hm[K][2] = max3_nonan(e4[1], e4[2], e4[3]);
-        st.hm[K][3] = max3_nonan(e4[2], e4[3], rg);
+        const float ninf = -__builtin_inff();
+        const float lf = dpp_wave_shr1(u4[3], ninf), rg = dpp_wave_shl1(u4[0], ninf);
+        float hmn[4];
+        hmn[0] = max3_nonan(lf, u4[0], u4[1]);
+        hmn[1] = max3_nonan(u4[0], u4[1], u4[2]);
+        hmn[2] = max3_nonan(u4[1], u4[2], u4[3]);
+        hmn[3] = max3_nonan(u4[2], u4[3], rg);
+        const float trn = max3_nonan(max3_nonan(tr4[0], tr4[1], tr4[2]), dpp_wave_shr1(tr4[3], 0.f),
+                                     max3_nonan(tr4[3], dpp_wave_shl1(tr4[0], 0.f), 0.f));
         if (t >= 6) {
-            const int ty = y - 1;   // ys <= ty < ye by construction
-            if (qn > kSQ - 256) stream_flush(a, qn, lane);
-            const bool row_ok = ty >= 1 && ty < a.h - 1;   // uniform; the lane's part of the test is in a.col_ok
+            const int ty = a.ys - 6 + t;   // ys <= ty < ye by construction
+            const float tm = max3_nonan(st.trm[P], st.trm[Q], trn);
+            const float m2 = __builtin_fmaf(kTierSqrt, __builtin_amdgcn_sqrtf(tm), __builtin_fmaf(kTierLin, tm, kTierAbs));
+            const float (&v)[4] = st.ctr[Q];
+            st.lanelow = max3_nonan(st.lanelow, max3_nonan(v[0], v[1], v[2]) - m2, v[3] - m2);
+            const bool brow = ty == 0 || ty == a.h - 1;   // uniform
+            if (brow) tier_tighten(a, st.lanelow, lane);   // this row's pixels only count for the maximum: know it first
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float v = st.ctr[K1][i];
-                const float m = max3_nonan(st.hm[K2][i], st.hm[K1][i], st.hm[K][i]);
-                const int xx = a.x + i;
-                // candidate: v > thr && !(m > v), in the columns and rows that can be tested — formed from compare masks
-                // (as a bool the compiler materialises it per lane and compares it again to get the ballot)
-                const unsigned long long bal = row_ok ? (__builtin_amdgcn_fcmpf(v, a.thr_p, 2) & ~__builtin_amdgcn_fcmpf(m, v, 2) & a.col_ok[i]) : 0ull;
-                const bool cand = (bal >> lane) & 1ull;
-                if (bal) {
-                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    uint32_t lo = (uint32_t)(ty * a.w + xx);
-                    if (i == 0 && lane == 0) lo |= kKeyCheckLeft;     // xx >= 1 here, so a strip lies to the left
-                    if (i == 3 && lane == 63) lo |= kKeyCheckRight;   // xx < w - 1 here, so a strip lies to the right
-                    if (cand) a.queue[pos] = ((unsigned long long)f2ord(v) << 32) | lo;
-                    qn += __popcll(bal);
+                const float left = i == 0 ? st.lf[Q] : v[i - 1], right = i == 3 ? st.rg[Q] : v[i + 1];
+                const float m8 = max3_nonan(max3_nonan(st.hm[P][i], hmn[i], left), right, a.thrU);
+                const float vp = v[i] + m2;
+                unsigned long long bal = 0ull, bmax = 0ull;
+                if (!brow) {
+                    bal = __builtin_amdgcn_fcmpf(vp, m8, 3) & a.cand_ok[i];   // 3 = ordered >=
+                    if (a.edge && (i == 0 || i == 3)) bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & a.bord[i];
+                } else {
+                    bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & a.own;
+                }
+                const unsigned long long both = bal | bmax;
+                if (both) {
+                    const int pos = a.qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(both >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)both, 0u));
+                    if ((both >> lane) & 1ull) {
+                        // entry: upper bound (vp > 0, so | sign bit = its ordered form) << 32 | offset | "not certainly a
+                        // 3x3 maximum".  What else the exact tier has to know follows from the position: first / last row
+                        // or column = counts for the maximum only; first / last column of a strip = the neighbours beyond
+                        // the strip were -inf here.
+                        uint32_t lo = (uint32_t)(ty * a.w + a.x + i);
+                        if (!((v[i] - m2) - m8 >= 0.f)) lo |= kKeyUncertain;
+                        a.queue[pos] = ((unsigned long long)(__float_as_uint(vp) | 0x80000000u) << 32) | lo;
+                    }
+                    a.qn += __popcll(both);
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            st.ctr[P][i] = u4[i];
+            st.hm[P][i] = hmn[i];
+        }
+        st.lf[P] = lf;
+        st.rg[P] = rg;
+        st.trm[P] = trn;
     }
-    // the two-row sum moves on only now: the block above read the old one
 #pragma unroll
     for (int e = 0; e < 12; e++) st.T[e] = rp[e] + r[e];
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void min_eigen_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
-                                                               float *__restrict__ edge, uint32_t *__restrict__ frame_max,
-                                                               double quality, unsigned long long *__restrict__ keys,
-                                                               uint32_t *__restrict__ counts, size_t key_cap, int seg_rows,
-                                                               int frames, int strips, int per_frame) {
-    __shared__ unsigned long long queue[4][kSQ];
+// Tier 1: U~ for every pixel; the possible pixels go to list[f][0 .. counts[f]) as raw entries (image_common.h; the
+// upper bound in units of c0); low_max[f] collects the certified lower bound of the frame maximum (ordered float, same
+// units) that the waves share, hist[f][] counts the entries by upper bound.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void min_eigen_tiered_kernel(
+    const uint8_t *__restrict__ gray, int w, int h, uint32_t *__restrict__ low_max, uint32_t *__restrict__ hist,
+    double quality, unsigned long long *__restrict__ list, uint32_t *__restrict__ counts, size_t cap, int seg_rows,
+    int frames, int strips, int per_frame) {
+    __shared__ unsigned long long queue[4][kTQ1];
+    __shared__ uint32_t whist[4][kTierBins];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    // all strips and segments of a frame run on one XCD: the cache lines two neighbouring strips (or segments)
-    // both touch are then fetched from HBM once, into that XCD's L2
     int f, blk;
     vs_xcd_item_block(blockIdx.x, per_frame, f, blk);
     if (f >= frames) return;
     const int strip = blk % strips, segblk = blk / strips;
-    StreamArgs a;
+    TierArgs a;
     a.ys = (segblk * 4 + wave) * seg_rows;
     if (a.ys >= h) return;   // whole wave; the kernel has no barriers
     a.ye = a.ys + seg_rows < h ? a.ys + seg_rows : h;
@@ -463,17 +529,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     a.w = w;
     a.h = h;
     a.src = gray + (size_t)f * w * h;
-    a.edge_l = edge + (((size_t)f * strips + strip) * 2 + 0) * h;   // [frames][strips][2][h]
-    a.edge_r = a.edge_l + h;
     a.queue = queue[wave];
-    a.keys = keys + (size_t)f * key_cap;
+    a.list = list + (size_t)f * cap;
+    a.whist = whist[wave];
+    for (int i = lane; i < kTierBins; i += 64) a.whist[i] = 0u;
     a.count = counts + f;
-    a.key_cap = key_cap;
+    a.cap = cap;
     const int x0 = strip * kSW;
     a.x = x0 + 4 * lane;
     a.own_lane = a.x < w;
+    a.own = __ballot(a.own_lane);
 #pragma unroll
-    for (int i = 0; i < 4; i++) a.col_ok[i] = __ballot(a.own_lane && a.x + i >= 1 && a.x + i < w - 1);
+    for (int i = 0; i < 4; i++) {
+        a.cand_ok[i] = __ballot(a.own_lane && a.x + i >= 1 && a.x + i < w - 1);
+        a.bord[i] = __ballot(a.own_lane && (a.x + i == 0 || a.x + i == w - 1));
+    }
     a.edge = x0 == 0 || x0 + kSW + 4 > w;
     a.left_fix = a.x == 0;
     a.right_fix = a.x + 4 == w;
@@ -481,59 +551,267 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     a.voff_c = (uint32_t)xc;
     a.voff_l = (uint32_t)(xc - 4 < 0 ? 0 : xc - 4);
     a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
-    const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0);
-    a.k1 = (float)scale;
-    a.k0 = 2.0f * a.k1;
     const float ninf = -__builtin_inff();
+    const float qf = (float)quality * (1.f - 1.f / 1048576.f);   // threshold bound: quality, a hair low
+    a.qn = 0;
 
-    StreamState st;
-    st.emax = ninf;
+    TierState st;
+    st.lanelow = ninf;
 #pragma unroll
-    for (int i = 0; i < 12; i++) st.T[i] = st.X[0][i] = st.X[1][i] = 0.0;
+    for (int i = 0; i < 12; i++) st.T[i] = st.X[0][i] = st.X[1][i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int c = 0; c < 6; c++) st.hx[0][c] = st.hx[1][c] = st.q[0][c] = st.q[1][c] = st.rs[0][c] = st.rs[1][c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        st.trm[k] = 0.f;
         const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
         st.raw[k][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
         st.raw[k][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
         st.raw[k][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
     }
-    // candidate prefilter: the best maximum known so far (other waves publish theirs as they go); always <= the
-    // frame's final maximum, so the candidates are a superset and corner_select_kernel applies the exact threshold
-    uint32_t run_max = frame_max[f];
-    a.thr_p = (float)((double)ord2f(run_max) * quality);
-    if (run_max == 0u) a.thr_p = ninf;   // nothing published yet
-    int qn = 0;
-    for (int t0 = 0; t0 < a.steps; t0 += 6) {   // six steps per trip: every ring index (t % 3, t % 2) is a compile-time constant
-        stream_step<0, 0>(st, a, t0, qn, lane);
-        if (t0 + 1 < a.steps) stream_step<1, 1>(st, a, t0 + 1, qn, lane);
-        if (t0 + 2 < a.steps) stream_step<2, 0>(st, a, t0 + 2, qn, lane);
-        if (t0 + 3 < a.steps) stream_step<0, 1>(st, a, t0 + 3, qn, lane);
-        if (t0 + 4 < a.steps) stream_step<1, 0>(st, a, t0 + 4, qn, lane);
-        if (t0 + 5 < a.steps) stream_step<2, 1>(st, a, t0 + 5, qn, lane);
-        if ((t0 % 12) == 6) {   // every 12 rows: tighten the prefilter with this wave's own maximum and publish it
-            uint32_t k = st.emax == ninf ? 0u : f2ord(st.emax);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = __shfl_xor(k, off, 64);
-                k = o > k ? o : k;
+    // what other waves have certified so far (0 = nothing yet)
+    a.qf = qf;
+    a.low_max = low_max + f;
+    a.published = low_max[f];
+    a.lowU = a.published == 0u ? ninf : ord2f(a.published);
+    a.thrU = a.lowU > 0.f ? a.lowU * qf : ninf;
+    for (int t0 = 0; t0 < a.steps; t0 += 2) {
+        tier_step<0>(st, a, t0, lane);
+        if (t0 + 1 < a.steps) tier_step<1>(st, a, t0 + 1, lane);
+        if (a.qn >= kTQ1 - 512) tier_flush(a, lane);
+        // after the first two tested rows, then every 12 rows: tighten the bounds with what this wave has seen
+        if ((t0 % 12) == 10 || t0 == 6) tier_tighten(a, st.lanelow, lane);
+    }
+    tier_tighten(a, st.lanelow, lane);
+    tier_flush(a, lane);
+    for (int i = lane; i < kTierBins; i += 64) {   // this wave's share of the frame's histogram
+        const uint32_t c = a.whist[i];
+        if (c) atomicAdd(hist + (size_t)f * kTierBins + i, c);
+    }
+}
+
+// Tier 2: the oracle's exact arithmetic for the listed pixels that can matter.  The selection needs the best-ranked
+// candidates only (about 1.3 x maxCorners, twice that when the suppression rejects many), so the entries are cut at the
+// upper bound above which the list holds `n_safe` entries (from the detector's histogram; a listed bound is never below
+// the exact response, so whatever is cut lies below that edge exactly as well); entries that may hold the frame maximum
+// are kept in any case.  Kept entries are evaluated 64 at a time per wave: their own value first — certain 3x3 maxima
+// become keys — then, eight pixels x eight neighbours per round, the neighbours of those that still have to be
+// compared (featureselect.cpp: val == dilate(val)).  Output: keys2[f][0 .. count2[f]) exact keys, unordered;
+// frame_max[f] exact; cutkey[f] = the edge in response units (0: nothing was cut).  mode 1 is the rerun for the frames
+// the selection flagged in need[] because it ran out of candidates above the edge: everything is evaluated.
+constexpr int kXQ1 = 320, kXQ2 = 72, kXKQ = 256;   // kept entries (63 left over + 4 x 64 per scan step), neighbour work, finished keys
+struct ExactLds {
+    uint32_t q1[kXQ1];
+    uint32_t q2pos[kXQ2], q2e[kXQ2], q2mask[kXQ2];
+    unsigned long long keys[kXKQ];
+};
+struct ExactWave {
+    const uint8_t *src;
+    ExactLds *lds;
+    unsigned long long *out;
+    uint32_t *out_count;
+    size_t cap;
+    int w, h;
+    float k0, k1;
+    int q1n, q2n, kqn;
+    float emax;   // per lane
+};
+
+__device__ __forceinline__ void exact_flush_keys(ExactWave &x, int lane) {
+    if (x.kqn == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(x.out_count, (uint32_t)x.kqn);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int i = lane; i < x.kqn; i += 64) {
+        const size_t pos = (size_t)base + i;
+        if (pos < x.cap) x.out[pos] = x.lds->keys[i];
+    }
+    x.kqn = 0;
+}
+
+__device__ __forceinline__ void exact_emit(ExactWave &x, int lane, bool emit, uint32_t pos, float e) {
+    const unsigned long long bal = __ballot(emit);
+    if (!bal) return;
+    if (x.kqn > kXKQ - 64) exact_flush_keys(x, lane);
+    const int at = x.kqn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (emit) x.lds->keys[at] = ((unsigned long long)f2ord(e) << 32) | pos;
+    x.kqn += __popcll(bal);
+}
+
+// rounds while a queue holds a full one (all: until both are empty)
+__device__ __forceinline__ void exact_rounds(ExactWave &x, int lane, bool all) {
+    const float ninf = -__builtin_inff();
+    while (true) {
+        int mode, take;
+        if (x.q2n >= 8 || (all && x.q1n == 0 && x.q2n > 0)) {
+            mode = 2;
+            take = x.q2n < 8 ? x.q2n : 8;
+        } else if (x.q1n >= 64 || (all && x.q1n > 0)) {
+            mode = 1;
+            take = x.q1n < 64 ? x.q1n : 64;
+        } else {
+            break;
+        }
+        bool have;
+        uint32_t pos = 0, aux = 0, mask = 0;
+        int px, py;
+        const int k = lane & 7;
+        if (mode == 1) {
+            have = lane < take;
+            uint32_t lo = 0;
+            if (have) lo = x.lds->q1[x.q1n - take + lane];
+            pos = lo & kOffMask;
+            x.q1n -= take;
+            py = (int)(pos / (uint32_t)x.w);
+            px = (int)pos - py * x.w;
+            if (have) {
+                // the detector's strips are kSW wide: it did not see the neighbours beyond a strip's first / last column
+                if ((px & (kSW - 1)) == 0) mask |= 0x29u;          // neighbours 0, 3, 5
+                if ((px & (kSW - 1)) == kSW - 1) mask |= 0x94u;    // neighbours 2, 4, 7
+                if (lo & kKeyUncertain) mask = 0xFFu;
+                if (px == 0 || px == x.w - 1 || py == 0 || py == x.h - 1) mask = 0x100u;   // not a candidate position
             }
-            if (k > run_max) {   // fire and forget: later waves start from it (re-reading it here would stall the wave)
-                run_max = k;
-                if (lane == 0) atomicMax(&frame_max[f], k);
+        } else {
+            const int ent = x.q2n - take + (lane >> 3);
+            have = (lane >> 3) < take;
+            if (have) {
+                pos = x.lds->q2pos[ent];
+                aux = x.lds->q2e[ent];
+                mask = x.lds->q2mask[ent];
             }
-            if (run_max != 0u) a.thr_p = (float)((double)ord2f(run_max) * quality);
+            x.q2n -= take;
+            have = have && ((mask >> k) & 1u);
+            py = (int)(pos / (uint32_t)x.w);
+            px = (int)pos - py * x.w;
+            // neighbour k: 0 1 2 / 3 . 4 / 5 6 7
+            px += k < 3 ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6));
+            py += k < 3 ? -1 : (k < 5 ? 0 : 1);
+        }
+        const bool inner = px >= 2 && px < x.w - 2 && py >= 2 && py < x.h - 2;
+        float e = ninf;
+        if (have && inner) e = min_eigen_exact_interior(x.src, x.w, px, py, x.k0, x.k1);
+        if (__builtin_expect(__any(have && !inner), 0)) {   // rare: pixels whose window leaves the image
+            if (have && !inner) e = min_eigen_exact_border(x.src, x.w, x.h, px, py, x.k0, x.k1);
+        }
+        x.emax = e > x.emax ? e : x.emax;   // e = -inf where there was nothing to evaluate
+        if (mode == 1) {
+            exact_emit(x, lane, have && mask == 0u, pos, e);
+            const bool more = have && mask != 0u && mask != 0x100u;
+            const unsigned long long bal = __ballot(more);
+            if (bal) {
+                const int p2 = x.q2n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (more) {
+                    x.lds->q2pos[p2] = pos;
+                    x.lds->q2e[p2] = __float_as_uint(e);
+                    x.lds->q2mask[p2] = mask;
+                }
+                x.q2n += __popcll(bal);
+            }
+        } else {
+            const float ep = __uint_as_float(aux);
+            const unsigned long long gr = __ballot(have && e > ep);
+            const bool rejected = ((gr >> (lane & ~7)) & 0xFFull) != 0ull;
+            exact_emit(x, lane, (lane >> 3) < take && k == 0 && !rejected, pos, ep);
         }
     }
-    {
-        uint32_t k = st.emax == ninf ? 0u : f2ord(st.emax);
+    if (all) exact_flush_keys(x, lane);
+}
+
+__global__ __launch_bounds__(256) void corner_exact_kernel(const uint8_t *__restrict__ gray, int w, int h,
+                                                           const unsigned long long *__restrict__ list,
+                                                           const uint32_t *__restrict__ counts, size_t cap,
+                                                           const uint32_t *__restrict__ hist, const uint32_t *__restrict__ low_max,
+                                                           uint32_t n_safe, unsigned long long *__restrict__ keys2,
+                                                           uint32_t *__restrict__ count2, uint32_t *__restrict__ frame_max,
+                                                           uint32_t *__restrict__ cutkey, const uint32_t *__restrict__ need,
+                                                           int mode, int frames, int per_frame) {
+    __shared__ ExactLds lds[4];
+    __shared__ uint32_t s_wave[4], s_cut;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int lane = tid & 63;
+    int f, blk;
+    vs_xcd_item_block(blockIdx.x, per_frame, f, blk);
+    if (f >= frames) return;
+    if (mode == 1 && need[f] == 0u) return;
+    uint32_t n = counts[f];
+    if ((size_t)n > cap) n = (uint32_t)cap;   // the selection kernel reports the overflow
+
+    // the cut: lower edge of the histogram bin at which the count from the top reaches n_safe
+    uint32_t cut = 0u;
+    if (mode == 0) {
+        const uint32_t *H = hist + (size_t)f * kTierBins;
+        constexpr int per = kTierBins / 256;
+        static_assert(per >= 1, "one thread per bin at least");
+        uint32_t own = 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t o = __shfl_xor(k, off, 64);
-            k = o > k ? o : k;
+        for (int b = 0; b < per; b++) own += H[tid * per + b];
+        uint32_t incl = own;   // becomes the sum over lanes >= lane of this wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_down(incl, off, 64);
+            if (lane + off < 64) incl += o;
         }
-        if (lane == 0 && k != 0u) atomicMax(&frame_max[f], k);
+        if (lane == 0) s_wave[wave] = incl;
+        if (tid == 0) s_cut = 0u;
+        __syncthreads();
+        uint32_t higher = 0;
+        for (int wv = wave + 1; wv < 4; wv++) higher += s_wave[wv];
+        uint32_t run = higher + incl - own;   // entries in bins above this thread's
+        for (int b = per - 1; b >= 0; b--) {
+            const uint32_t mine = H[tid * per + b];
+            if (run < n_safe && n_safe <= run + mine) s_cut = tier_bin_edge((uint32_t)(tid * per + b));   // one bin at most
+            run += mine;
+        }
+        __syncthreads();
+        cut = s_cut;   // 0: fewer than n_safe entries, keep all
+        const uint32_t low = low_max[f];   // whatever may hold the maximum stays in
+        if (low < cut) cut = low;
+        if (blk == 0 && tid == 0) {
+            // the same edge in response units, rounded up: everything that was cut has an exact response below it
+            cutkey[f] = cut > 0x80000000u ? f2ord(ord2f(cut) * kTierC0Up) : 0u;
+        }
     }
-    stream_flush(a, qn, lane);
+
+    ExactWave x;
+    x.src = gray + (size_t)f * w * h;
+    x.lds = &lds[wave];
+    x.out = keys2 + (size_t)f * cap;
+    x.out_count = count2 + f;
+    x.cap = cap;
+    x.w = w;
+    x.h = h;
+    x.k1 = (float)(1.0 / ((double)(1 << 2) * 3 * 255.0));
+    x.k0 = 2.0f * x.k1;
+    x.q1n = x.q2n = x.kqn = 0;
+    x.emax = -__builtin_inff();
+    const unsigned long long *L = list + (size_t)f * cap;
+    // scan this wave's share of the list four batches at a time (independent loads), keep what reaches the cut
+    const uint32_t stride = (uint32_t)per_frame * 256u;
+    for (uint32_t base = (uint32_t)(blk * 4 + wave) * 64u; base < n; base += 4u * stride) {
+        unsigned long long ent[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t idx = base + (uint32_t)u * stride + lane;
+            ent[u] = idx < n ? L[idx] : 0ull;   // 0 never reaches a cut (which is 0 only when everything is kept: then idx < n decides)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t idx = base + (uint32_t)u * stride + lane;
+            const bool keep = idx < n && (uint32_t)(ent[u] >> 32) >= cut;
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                const int at = x.q1n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (keep) x.lds->q1[at] = (uint32_t)ent[u];
+                x.q1n += __popcll(bal);
+            }
+        }
+        if (x.q1n >= 64) exact_rounds(x, lane, false);
+    }
+    exact_rounds(x, lane, true);
+    float em = x.emax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) em = fmaxf(em, __shfl_xor(em, off, 64));
+    if (lane == 0 && em != -__builtin_inff()) atomicMax(&frame_max[f], f2ord(em));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -619,33 +897,52 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
 }
 
 
-// Responses + candidate keys for vs_launch_good_features: keys[f][0 .. counts[f]) = (ordered response << 32 | pixel
-// offset [| kKeyCheck*]), frame_max[f] = ordered maximum response.  counts and fmax must be zero on entry.  The streaming
-// form fills edge[f][strip][2][h] (vs_response_strips(w) strips) and leaves eig untouched; the tiled form fills eig.
-int vs_response_strips(int w) { return vs_div_up(w, kSW); }
+// Candidates for vs_launch_good_features.  Everything in `c` must be zero on entry.
+//   width % 4 == 0 (two-tier detector): keys = the raw list, keys2[f][0 .. count2[f]) = exact keys of the entries above
+//   the cut, fmax exact, cutkey set; returns raw_list = 1.
+//   otherwise (tiled detector): eig filled, keys[f][0 .. counts[f]) = exact keys; raw_list = 0.
+size_t vs_response_hist_words(int frames) { return (size_t)frames * kTierBins; }
 
 int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, double quality,
-                                  float *eig, float *edge, uint32_t *fmax, unsigned long long *keys, uint32_t *counts,
-                                  size_t key_cap) {
+                                  float *eig, const VsCornerCounters &c, unsigned long long *keys,
+                                  unsigned long long *keys2, size_t key_cap, uint32_t n_safe, int *raw_list) {
     int rc;
     const bool fused = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
-    if (fused) {   // fmax is zero on entry, like counts (the caller clears both with one memset)
-        VsProfScope ps(ctx, "min_eigen_kernel");
-        const int strips = vs_div_up(w, kSW);
-        const int segs = vs_stream_segments(h, frames, strips);
-        const int seg_rows = vs_div_up(h, segs);
-        const int per_frame = strips * vs_div_up(segs, 4);
-        min_eigen_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
-            gray, w, h, edge, fmax, quality, keys, counts, key_cap, seg_rows, frames, strips, per_frame);
-        // A frame whose maximum response is negative has no corners (its threshold max * quality lies above every
-        // response, THRESH_TOZERO clears the image and zeros are not corners); corner_select_kernel's exact
-        // threshold drops every key of such a frame, so it needs no special handling here.
+    *raw_list = fused ? 1 : 0;
+    if (fused) {
+        {
+            VsProfScope ps(ctx, "min_eigen_kernel");
+            const int strips = vs_div_up(w, kSW);
+            const int segs = vs_stream_segments(h, frames, strips);
+            const int seg_rows = vs_div_up(h, segs);
+            const int per_frame = strips * vs_div_up(segs, 4);
+            min_eigen_tiered_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
+                gray, w, h, c.low, c.hist, quality, keys, c.counts, key_cap, seg_rows, frames, strips, per_frame);
+        }
+        // A frame whose maximum response is not positive has no corners (its threshold max * quality lies at or above
+        // every response, THRESH_TOZERO clears the image and zeros are not corners); the selection's exact threshold
+        // drops every key of such a frame, so it needs no special handling here.
+        if ((rc = vs_launch_corner_exact(ctx, gray, frames, w, h, c, keys, keys2, key_cap, n_safe, 0))) return rc;
     } else {
-        if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, fmax))) return rc;
+        if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, c.fmax))) return rc;
         VsProfScope ps(ctx, "corner_candidates_kernel");
         dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
-        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, fmax, quality, keys, counts, key_cap);
+        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, c.fmax, quality, keys, c.counts, key_cap);
     }
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+// mode 0: the entries above the cut -> keys2 / count2; mode 1: every entry of the frames flagged in c.need -> keys2 / count3
+int vs_launch_corner_exact(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, const VsCornerCounters &c,
+                           const unsigned long long *keys, unsigned long long *keys2, size_t key_cap, uint32_t n_safe,
+                           int mode) {
+    VsProfScope ps(ctx, mode == 0 ? "corner_exact_kernel" : "corner_rerun_kernels");
+    static const char *pf_env = getenv("VSLAM_CORNER_EXACT_WGS");
+    const int per_frame = pf_env ? atoi(pf_env) : 4;
+    corner_exact_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
+        gray, w, h, keys, c.counts, key_cap, c.hist, c.low, n_safe, keys2, mode == 0 ? c.count2 : c.count3, c.fmax, c.cutkey,
+        c.need, mode, frames, per_frame);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }

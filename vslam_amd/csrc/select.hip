@@ -215,9 +215,9 @@ __device__ uint32_t gather_sorted(const unsigned long long *K, uint32_t n, unsig
 // gathered set would not fit the buffer (heavy ties); the caller then uses the generic radix select.
 // n_kept receives the number of keys above the threshold, N_io is clamped to it.
 template <int EPT>
-__device__ bool rank_window_2pass(unsigned long long *K, uint32_t n, unsigned long long tkey, uint32_t t32,
+__device__ bool rank_window_2pass(const unsigned long long *K, uint32_t n, unsigned long long tkey, uint32_t t32,
                                   uint32_t m32, uint32_t &N_io, unsigned long long *sortbuf, int sort_cap,
-                                  SelectShared &sh, uint32_t &n_kept, const float *__restrict__ edge, int w, int h) {
+                                  SelectShared &sh, uint32_t &n_kept) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *hist = reinterpret_cast<uint32_t *>(sortbuf);
     const int bins = 2 * sort_cap < 4096 ? 2 * sort_cap : 4096;
@@ -237,25 +237,6 @@ __device__ bool rank_window_2pass(unsigned long long *K, uint32_t n, unsigned lo
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t lo = (uint32_t)key[u];
-            if (lo & (kKeyCheckLeft | kKeyCheckRight)) {
-                // candidate on the first / last column of a detector strip: finish its 3x3 test with the column the
-                // strip could not see, then store the key without the flag (or 0: never a candidate)
-                const uint32_t off = lo & kOffMask;
-                const float v = ord2f((uint32_t)(key[u] >> 32));
-                const int y = (int)(off / (uint32_t)w), strip = ((int)off - y * w) >> 8;   // strips are 256 wide
-                bool ok = true;
-                if (lo & kKeyCheckLeft) {    // the last column of the strip to the left, rows y-1 .. y+1
-                    const float *e = edge + (((size_t)(strip - 1)) * 2 + 1) * h + (y - 1);
-                    ok = ok && !(e[0] > v) && !(e[1] > v) && !(e[2] > v);
-                }
-                if (lo & kKeyCheckRight) {   // the first column of the strip to the right
-                    const float *e = edge + (((size_t)(strip + 1)) * 2 + 0) * h + (y - 1);
-                    ok = ok && !(e[0] > v) && !(e[1] > v) && !(e[2] > v);
-                }
-                key[u] = ok ? ((key[u] & 0xFFFFFFFF00000000ull) | off) : 0ull;
-                K[i0 + u * kST + tid] = key[u];
-            }
             if (key[u] > tkey) atomicAdd(&hist[((uint32_t)(key[u] >> 32) >> shift) & dmask], 1u);
         }
     }
@@ -480,8 +461,8 @@ __device__ __forceinline__ int nms_visit_lds(const volatile uint32_t *offs, cons
 //  slow path (N would exceed the LDS sort buffer): suppression over every candidate, then select.
 template <int EPT>
 __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) void corner_select_kernel(
-    float *__restrict__ eig, const float *__restrict__ edge, int strips, int w, int h, uint8_t *__restrict__ state,
-    unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
+    float *__restrict__ eig, const uint32_t *__restrict__ cutkey, uint32_t *__restrict__ need, int pass, int w, int h,
+    uint8_t *__restrict__ state, unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
     int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
     int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow,
     const uint32_t *__restrict__ frame_max, double quality, int use_lists, const DiscTable disc) {
@@ -491,8 +472,9 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
     const int f = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    // pass 1 = the rerun of the frames whose first selection ran out of keys above the cut (their list is complete now)
+    if (pass == 1 && need[f] == 0u) return;
     float *E = eig + (size_t)f * w * h;   // slow path only: responses of the candidates, scattered from their keys
-    const float *EDGE = edge + (size_t)f * strips * 2 * h;
     uint8_t *S = state + (size_t)f * w * h;
     unsigned long long *K = keys + (size_t)f * key_cap;
     float2 *O = reinterpret_cast<float2 *>(out_xy) + (size_t)f * kp_stride;
@@ -508,7 +490,20 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // > (float)(max * quality) count (every key of an exactly-thresholded list passes)
     float thr = (float)((double)ord2f(frame_max[f]) * quality);
     if (thr == 0.f) thr = 0.f;   // -0 -> +0 so the ordered-key compare equals the float compare
-    const uint32_t t32 = f2ord(thr), m32 = frame_max[f];
+    // The two-tier detector's key list is complete only above cutkey[f] (a key below it may be outranked by a pixel that
+    // was never evaluated): such keys are ignored, and if the selection then runs out of keys before it has max_corners
+    // corners the frame is flagged and redone (pass 1) on the complete list.
+    const uint32_t cut32 = (pass == 0 && cutkey) ? cutkey[f] : 0u;
+    const bool cut_binds = cut32 > f2ord(thr);
+    const uint32_t t32 = cut_binds ? cut32 - 1u : f2ord(thr), m32 = frame_max[f];   // keys >= cut32 pass
+    auto finish = [&](uint32_t found) {   // tid 0: the count, or the request for the rerun
+        if (cut_binds && found < want_max) {
+            need[f] = 1u;
+            out_n[f] = 0;
+        } else {
+            out_n[f] = (int32_t)(found < want_max ? found : want_max);
+        }
+    };
     unsigned long long tkey = ((unsigned long long)t32 << 32) | 0xFFFFFFFFull;
     bool compacted = false;
     // drop the keys at or below the threshold from K (generic paths only; the two-pass window filters on the fly)
@@ -552,7 +547,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (R == 0) N = want_max;
         while (true) {
             uint32_t got = N, n_kept = 0;
-            if (!rank_window_2pass<EPT>(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept, EDGE, w, h)) {
+            if (!rank_window_2pass<EPT>(K, n, tkey, t32, m32, got, sortbuf, sort_cap, sh, n_kept)) {
                 if (!compacted) compact_keys();
                 n_kept = n;
                 got = N < n ? N : n;
@@ -687,7 +682,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 base += tot;
             }
             if (base >= want_max || got == n_kept) {
-                if (tid == 0) out_n[f] = (int32_t)(base < want_max ? base : want_max);
+                if (tid == 0) finish(base);
                 done = true;
                 break;
             }
@@ -762,7 +757,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int y = off / w, x = off - y * w;
         O[i] = make_float2((float)x, (float)y);
     }
-    if (tid == 0) out_n[f] = (int32_t)want;
+    if (tid == 0) finish(n_acc);
 }
 
 }  // namespace
@@ -774,30 +769,43 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     VS_REQUIRE(ctx, frames > 0 && w >= 3 && h >= 3, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, max_corners > 0 && max_corners <= kp_stride, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, min_distance < 64.0, VSLAM_ERR_CAPACITY);
-    VS_REQUIRE(ctx, (size_t)w * h < (1u << 30), VSLAM_ERR_CAPACITY);   // pixel offsets carry 2 status bits in the selection
+    VS_REQUIRE(ctx, (size_t)w * h < (1u << 28), VSLAM_ERR_CAPACITY);   // pixel offsets share their word with 4 flag bits (image_common.h)
     const size_t px = (size_t)w * h;
     float *eig = nullptr;
-    uint32_t *fmax = nullptr, *counts = nullptr;
+    uint32_t *block = nullptr;
     uint8_t *state = nullptr;
-    unsigned long long *keys = nullptr;
-    int32_t *overflow = nullptr;
+    unsigned long long *keys = nullptr, *keys2 = nullptr;
     int rc;
-    float *edge = nullptr;
-    const int strips = vs_response_strips(w);
     if ((rc = vs_arena_get(ctx, "gf.eig", sizeof(float) * px * frames, (void **)&eig))) return rc;
-    if ((rc = vs_arena_get(ctx, "gf.edge", sizeof(float) * 2 * (size_t)strips * h * frames, (void **)&edge))) return rc;
-    // counts[frames], overflow, frame maxima[frames]: one block, so that one memset clears all of it
-    if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * (2 * (size_t)frames + 1), (void **)&counts))) return rc;
-    fmax = counts + frames + 1;
+    // every per-frame counter of the pipeline in one block, so that one memset clears all of it:
+    // counts[F], overflow[1], fmax[F], low[F], count2[F], count3[F], need[F], cutkey[F], hist[F][bins]
+    const size_t F = (size_t)frames, words = 7 * F + 1 + vs_response_hist_words(frames);
+    if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * words, (void **)&block))) return rc;
+    VsCornerCounters c;
+    c.counts = block;
+    int32_t *overflow = reinterpret_cast<int32_t *>(block + F);
+    c.fmax = block + F + 1;
+    c.low = c.fmax + F;
+    c.count2 = c.low + F;
+    c.count3 = c.count2 + F;
+    c.need = c.count3 + F;
+    c.cutkey = c.need + F;
+    c.hist = c.cutkey + F;
     if ((rc = vs_arena_get(ctx, "gf.state", px * frames, (void **)&state))) return rc;
-    // every interior pixel can be a candidate (a plateau equals its own dilation), so the key list
-    // is sized for the whole image: exactness over memory
+    // every interior pixel can be a candidate (a plateau equals its own dilation), so the lists are sized for the whole
+    // image: exactness over memory.  keys = the detector's list, keys2 = the exact keys of the two-tier path.
     const size_t key_cap = px;
     if ((rc = vs_arena_get(ctx, "gf.keys", sizeof(unsigned long long) * key_cap * frames, (void **)&keys))) return rc;
-    overflow = reinterpret_cast<int32_t *>(counts + frames);
+    if ((rc = vs_arena_get(ctx, "gf.keys2", sizeof(unsigned long long) * key_cap * frames, (void **)&keys2))) return rc;
 
-    VS_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (2 * (size_t)frames + 1), ctx->stream));
-    if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, edge, fmax, keys, counts, key_cap))) return rc;
+    VS_HIP(ctx, hipMemsetAsync(block, 0, sizeof(uint32_t) * words, ctx->stream));
+    // The selection ranks 1.25 x max_corners + 64 candidates (twice that if the suppression leaves it short, which it
+    // rarely does): evaluate exactly that first window plus slack — the exact tier is bound by its scattered window
+    // reads, about 640 B per pixel — and rerun a frame completely if it runs out.
+    static const char *ns_env = getenv("VSLAM_CORNER_NSAFE_PCT");   // percent of max_corners, for A/B timing
+    const uint32_t n_safe = (uint32_t)max_corners * (uint32_t)(ns_env ? atoi(ns_env) : 135) / 100u + 128u;
+    int raw_list = 0;
+    if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, c, keys, keys2, key_cap, n_safe, &raw_list))) return rc;
     if (ctx->fork_after_eigen) {   // the caller runs an independent stage on the auxiliary stream beside the selection
         VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
@@ -824,30 +832,42 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
                 }
         }
         for (int k = disc.n; k < disc.n + 3 && k < kDiscMax + 3; k++) disc.e[k] = disc.n ? disc.e[0] : 0;
-        VsProfScope ps(ctx, "corner_select_kernel");
-#define VS_SELECT_LAUNCH(EPT)                                                                                              \
+#define VS_SELECT_LAUNCH(EPT, PASS, KEYS, COUNTS)                                                                          \
     do {                                                                                                                   \
         if (!ctx->attr_done["corner_select" #EPT]) {                                                                       \
             VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(corner_select_kernel<EPT>),                     \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                     \
             ctx->attr_done["corner_select" #EPT] = true;                                                                   \
         }                                                                                                                  \
-        corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(eig, edge, strips, w, h, state, keys, counts, key_cap, \
-                                                                     max_corners, md, md2, sort_cap, xy, n, kp_stride,     \
-                                                                     overflow, fmax,                                       \
+        corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(eig, raw_list ? c.cutkey : nullptr, c.need, PASS, w, h, \
+                                                                     state, KEYS, COUNTS, key_cap, max_corners, md, md2,   \
+                                                                     sort_cap, xy, n, kp_stride, overflow, c.fmax,         \
                                                                      quality, use_lists, disc);                            \
     } while (0)
-        switch (sort_cap / kST) {
-            case 1: VS_SELECT_LAUNCH(1); break;
-            case 2: VS_SELECT_LAUNCH(2); break;
-            case 4: VS_SELECT_LAUNCH(4); break;
-            case 8: VS_SELECT_LAUNCH(8); break;
-            case 16: VS_SELECT_LAUNCH(16); break;
-            default: VS_SELECT_LAUNCH(0); break;   // sort_cap < kST
+#define VS_SELECT_DISPATCH(PASS, KEYS, COUNTS)                                                                             \
+    switch (sort_cap / kST) {                                                                                              \
+        case 1: VS_SELECT_LAUNCH(1, PASS, KEYS, COUNTS); break;                                                            \
+        case 2: VS_SELECT_LAUNCH(2, PASS, KEYS, COUNTS); break;                                                            \
+        case 4: VS_SELECT_LAUNCH(4, PASS, KEYS, COUNTS); break;                                                            \
+        case 8: VS_SELECT_LAUNCH(8, PASS, KEYS, COUNTS); break;                                                            \
+        case 16: VS_SELECT_LAUNCH(16, PASS, KEYS, COUNTS); break;                                                          \
+        default: VS_SELECT_LAUNCH(0, PASS, KEYS, COUNTS); break; /* sort_cap < kST */                                      \
+    }
+        {
+            VsProfScope ps(ctx, "corner_select_kernel");
+            if (raw_list) VS_SELECT_DISPATCH(0, keys2, c.count2)
+            else VS_SELECT_DISPATCH(0, keys, c.counts)
         }
+        if (raw_list) {
+            // the rerun, for the frames (if any) whose selection ran out of keys above the cut: every listed pixel is
+            // evaluated, then selected from again.  Both launches return at once for the other frames.
+            if ((rc = vs_launch_corner_exact(ctx, gray, frames, w, h, c, keys, keys2, key_cap, 0u, 1))) return rc;
+            VsProfScope ps(ctx, "corner_rerun_kernels");
+            VS_SELECT_DISPATCH(1, keys2, c.count3)
+        }
+#undef VS_SELECT_DISPATCH
 #undef VS_SELECT_LAUNCH
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }
-
