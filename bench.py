@@ -84,18 +84,43 @@ ALG_OPS = {
     # the matcher forms each 256-bit Hamming distance as an int8 dot product on the matrix cores: 256 multiply-adds
     "match_knn2_kernel": ("(query, train) descriptor pairs", 512.0, "int8 op (256 multiply-adds on MFMA)", INT8_MFMA_PEAK_TOPS),
 }
-SQ_PROFILE = os.path.join(ROOT, "profiles", "r02_sq_counters.csv")
+PROFILE_TAG = "r03"
+SQ_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.csv")
+PMC_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_hbm_traffic.csv")
+STAMP_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_source_stamp.txt")
+
+
+def source_stamp():
+    """Hash of the kernel sources: instruction counts per wave and HBM traffic per launch are properties of a BUILD, so
+    the committed counter summaries (tools/prof_all.sh writes this stamp beside them) only describe the running library
+    when the stamps agree."""
+    import hashlib
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "vslam_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                hsh.update(name.encode() + b"\0" + fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def counters_current():
+    try:
+        with open(STAMP_FILE) as fh:
+            return fh.read().split()[0] == source_stamp()
+    except (OSError, IndexError):
+        return False
 
 
 def sq_counters(kernel):
     """(waves per launch, VALU instructions per wave) from the committed rocprofv3 SQ counter summary."""
     import csv
     import re
-    if not os.path.exists(SQ_PROFILE):
+    if not os.path.exists(SQ_PROFILE) or not counters_current():
         return None
     with open(SQ_PROFILE) as f:
         for r in csv.DictReader(f):
-            if re.sub(r"_(v4|stream|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
+            if re.sub(r"_(v4|stream|tiered|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
                 return float(r["waves_per_launch"]), float(r["valu_insts_per_wave"])
     return None
 
@@ -125,12 +150,12 @@ def pmc_traffic(kernel):
     bench.py cannot collect PMC counters on itself."""
     import csv
     import re
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.csv")
-    if not os.path.exists(path):
+    path = PMC_PROFILE
+    if not os.path.exists(path) or not counters_current():
         return None
     with open(path) as f:
         for r in csv.DictReader(f):
-            if re.sub(r"_(v4|stream|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
+            if re.sub(r"_(v4|stream|tiered|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
                 return (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
     return None
 
@@ -155,7 +180,8 @@ def cpu_baseline_all_cores(wl, pairs_per_proc, seed):
 
 def cpu_baseline(wl, sample_pairs, seed):
     """The oracle (oracle/, a CPU port of the reference path; the reference itself cannot be built
-    here) on `sample_pairs` pairs of the same workload, one thread."""
+    here) on `sample_pairs` pairs of the same workload, one thread.  (The all-cores figure's worker; the single-thread
+    figure of the line comes from oracle_on_frames, on the timed batch's own bytes.)"""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
@@ -173,6 +199,43 @@ def cpu_baseline(wl, sample_pairs, seed):
     dt = time.perf_counter() - t0
     return {"value": sample_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": f"{sample_pairs} pairs of {wl} ({w}x{h}, {K} kp, {H} hyp), oracle single thread, {dt:.1f} s"}
+
+
+def oracle_on_frames(frames_a, frames_b, seeds, K, H, thr, gpu_out, pair0, what):
+    """Run the oracle on the very frames the GPU step processed (copied back from the device) and hold the step's
+    output to it: keypoint counts of both frames, the number of inlier matches, the match list and F bit for bit.
+    Returns (cpu_baseline dict, parity dict); the time is the oracle's own (copies excluded)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    from vslam_amd import synth
+    o = Oracle()
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    n = frames_a.shape[0]
+    P = gpu_out["n"].shape[0] // 2
+    bad = []
+    t0 = time.perf_counter()
+    for p in range(n):
+        a = o.extract_features(frames_a[p], K, ca, sa, pat)
+        b = o.extract_features(frames_b[p], K, ca, sa, pat)
+        ref = o.match_features(a["xy"], a["desc"], b["xy"], b["desc"], int(seeds[p]) & 0xFFFFFFFF, H, thr)
+        g = pair0 + p
+        k = len(ref["matches"])
+        ok = (int(gpu_out["n"][g]) == a["n"] and int(gpu_out["n"][P + g]) == b["n"] and int(gpu_out["best"][g, 3]) == k
+              and np.array_equal(gpu_out["matches"][g, :k], ref["matches"])
+              and np.array_equal(gpu_out["F"][g].view(np.uint32), np.asarray(ref["F"], np.float32).reshape(-1).view(np.uint32)))
+        if not ok:
+            bad.append(g)
+    dt = time.perf_counter() - t0
+    h, w = frames_a.shape[1:3]
+    base = {"value": n / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n} pairs of the timed batch itself ({what}: {w}x{h}, {K} kp, {H} hyp) copied back from the device, "
+                      f"oracle single thread, {dt:.1f} s"}
+    parity = {"pairs": n, "bit_exact": not bad, "checked": "keypoint counts, inlier-match lists and F (as uint32) of the timed step's output vs the oracle on the same bytes"}
+    if bad:
+        parity["mismatching_pairs"] = bad[:16]
+    return base, parity
 
 
 def self_launch(n_gpus, argv):
@@ -227,7 +290,9 @@ def dry_run(args, rank, world):
         out = shard.gather_records(rec, world, n_items=world * P)
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    all_t = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(all_t, t)
+    rank_ms = [float(x.item()) / max(args.steps, 1) * 1e3 for x in all_t]
     F, best, m = shard.unpack_records(out, K)
     ok = torch.equal(F.view(torch.int32), F_all.view(torch.int32)) and torch.equal(best, best_all) and torch.equal(m, m_all)
     flag = torch.tensor([1 if ok else 0])
@@ -235,6 +300,8 @@ def dry_run(args, rank, world):
     line = json.dumps({"metric": "DRY RUN: launcher + record gather only, no kernels, not a measurement", "value": None,
                        "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                        "ms_per_step": None, "gather_ok": bool(flag.item()), "data": "synthetic",
+                       "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms,
+                                                "note": "dry run: gather time only"},
                        "config": {"workload": "dry", "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}, gloo all_gather of result records"}})
     dist.barrier()
     dist.destroy_process_group()
@@ -252,7 +319,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch)")
-    ap.add_argument("--cpu-pairs", type=int, default=150, help="pairs the CPU baseline times (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=150,
+                    help="pairs of the timed batch that the oracle recomputes on the host: the CPU baseline and the in-bench parity "
+                         "check at once (0 = no CPU leg; the parity check then still covers 4 pairs)")
+    ap.add_argument("--data", default="easy", choices=["easy", "hard"],
+                    help="easy = translated texture + one moving block (the headline's data since round 1); hard = SURVEY 8(d)'s "
+                         "regime: rotation + parallax, sub-pixel resampling, 40-45 %% outlier matches (synth.frames_torch_hard)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (hard-data regime, full-evaluation worst case, C2 / C5)")
     ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
                     help="pairs per process for the all-host-cores CPU figure (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -321,7 +395,8 @@ def main():
     assert P % lanes == 0
     PL = P // lanes
     lane_ctx = [ctx] if lanes == 1 else [Context(local_rank, use_torch_stream=False) for _ in range(lanes)]
-    bgr = synth.frames_torch(seed + 1000 * rank, P, w, h, dev)
+    make_frames = synth.frames_torch if args.data == "easy" else synth.frames_torch_hard
+    bgr = make_frames(seed + 1000 * rank, P, w, h, dev)
     pat = torch.from_numpy(synth.brief_pattern()).to(dev)
     ca, sa = synth.keypoint_rotation()
     lo, hi = shard.shard_range(world * P, rank, world)          # this rank's slice of the global batch
@@ -382,14 +457,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    rank_ms = None
     if multi:
+        # the step time is the slowest rank's; every rank's own time travels along so that a scaling curve shows stragglers
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in all_t]
+        dt = max(float(x.item()) for x in all_t)
 
     # sanity on the timed output: every pair produced keypoints, matches and an accepted model
-    best = out["best"].cpu().numpy()
-    n_kp = out["n"].cpu().numpy()
+    host_out = {k: out[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
+    best = host_out["best"]
+    n_kp = host_out["n"]
     assert (best[:, 0] >= 0).all() and (best[:, 3] >= 8).all() and (n_kp > K // 2).all(), "bench output degenerate"
 
     result = None
@@ -407,11 +487,14 @@ def main():
             "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/f32/f64", "data": "synthetic",
+            "dtype": "u8/f32/f64",
+            "data": "synthetic" + ("" if args.data == "easy" else " (hard regime: rotation + parallax, sub-pixel resampling, 40-45 % outlier matches)"),
             "config": {"workload": f"{args.workload}: {w}x{h}, {K} keypoints, {H} hypotheses, batch {P} pairs per GPU",
                        "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}" + (f", {backend_label} all_gather of result records" if multi else "")},
             "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
         }
+        if rank_ms:
+            result["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms}
         if args.solver != "exact":
             result["solver"] = "gram-mfma: opt-in approximate 8-point solver, results NOT bit-exact with the reference path"
             result["metric"] += " [NON-PARITY SOLVER]"
@@ -475,13 +558,94 @@ def main():
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["alg_GBps"] / HBM_PEAK_GBS,
                                           "traffic": pmc_traffic(st["kernel"]) if (args.workload == "C3" and P == WORKLOADS["C3"][4]) else None,
                                           "avg_launch_ms": st["ms_per_launch"]}
+        result["counter_profiles"] = {"tag": PROFILE_TAG, "match_this_build": counters_current(),
+                                      "note": "traffic / valu_issue come from the committed rocprofv3 PMC summaries and are omitted (null) "
+                                              "unless their source stamp equals this build's"}
         result["kernels"] = kernels
         result["profile_pass_ms_per_step"] = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels)
 
-    if rank == 0 and world == 1 and args.cpu_pairs > 0:
-        result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_pairs, seed)
-        if args.cpu_all_cores_pairs > 0:
-            result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, args.cpu_all_cores_pairs, seed)
+    # ---- the oracle on the timed batch's own bytes: parity of what was timed, and the CPU baseline, in one go
+    exit_code = 0
+    if rank == 0:
+        n_cpu = min(P, args.cpu_pairs if (world == 1 and args.cpu_pairs > 0) else 4)
+        fa = bgr[:n_cpu].cpu().numpy()
+        fb = bgr[P:P + n_cpu].cpu().numpy()
+        pair_seeds = shard.pair_seeds(seed, lo, hi)[:n_cpu]
+        base, parity = oracle_on_frames(fa, fb, pair_seeds, K, H, thr, host_out, 0, args.workload + ", " + args.data + " data")
+        result["parity_in_bench"] = parity
+        if world == 1 and args.cpu_pairs > 0:
+            result["cpu_baseline"] = base
+            if args.cpu_all_cores_pairs > 0:
+                result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, args.cpu_all_cores_pairs, seed)
+        if not parity["bit_exact"]:
+            exit_code = 3
+        del fa, fb
+
+    # ---- secondary measurements (rank 0, one GPU): the harder data regime, the full-evaluation worst case, the other workloads
+    if rank == 0 and world == 1 and not args.no_extras and lanes == 1:
+        def timed(c, frames, pairs, kk, hh, sd, steps=10):
+            o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr)
+            for _ in range(2):
+                o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=o)
+            c.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=o)
+            c.synchronize()
+            return (time.perf_counter() - t1) / steps * 1e3, o
+
+        def kernel_ms(c, frames, pairs, kk, hh, sd, names):
+            c.prof_enable(True)
+            c.prof_reset()
+            c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr)
+            rep = c.prof_report()
+            c.prof_enable(False)
+            return {nm: rep[nm][0] / max(rep[nm][1], 1) for nm in names if nm in rep}
+
+        scoring = ("ransac_rank_kernel", "ransac_screen_kernel", "ransac_cand_kernel", "ransac_count_kernel",
+                   "ransac_ties_kernel", "ransac_tiesum_kernel", "ransac_select_kernel", "ransac_score_kernel")
+        regimes = {}
+        other = "hard" if args.data == "easy" else "easy"
+        for kind in (args.data, other):
+            frames = bgr if kind == args.data else (synth.frames_torch if kind == "easy" else synth.frames_torch_hard)(seed, P, w, h, dev)
+            ms, o = timed(ctx, frames, P, K, H, seeds)
+            ho = {k: o[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
+            entry = {"ms_per_step": ms, "frame_pairs_per_s": P / ms * 1e3, "mean_keypoints": float(ho["n"].mean()),
+                     "mean_inlier_matches": float(ho["best"][:, 3].mean()),
+                     "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, seeds, scoring)}
+            # worst case of the data-dependent scoring kernels: every (hypothesis, match) pair evaluated, every sum formed
+            ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, True)
+            ms_all, _ = timed(ctx, frames, P, K, H, seeds, steps=5)
+            entry["full_evaluation"] = {"ms_per_step": ms_all, "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, seeds, scoring),
+                                        "what": "VSLAM_OPT_RANSAC_ALL_SUMS: no bail-out, no screen: the count and residual sum of every hypothesis"}
+            ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
+            if kind != args.data:   # the timed batch itself was checked above; check this regime's output too
+                nchk = min(P, 4)
+                _, par = oracle_on_frames(frames[:nchk].cpu().numpy(), frames[P:P + nchk].cpu().numpy(),
+                                          shard.pair_seeds(seed, lo, hi)[:nchk], K, H, thr, ho, 0, args.workload + ", " + kind + " data")
+                entry["parity_in_bench"] = par
+                if not par["bit_exact"]:
+                    exit_code = 3
+                del frames
+            regimes[kind] = entry
+        result["data_regimes"] = regimes
+        others = {}
+        for wl in sorted(WORKLOADS):
+            if wl == args.workload:
+                continue
+            w2, h2, K2, H2, P2 = WORKLOADS[wl]
+            c2 = Context(local_rank)
+            f2 = synth.frames_torch(0x5EED0000 + sorted(WORKLOADS).index(wl), P2, w2, h2, dev)
+            s2 = torch.from_numpy(shard.pair_seeds(0x5EED0000 + sorted(WORKLOADS).index(wl), 0, P2).view(np.int32)).to(dev)
+            ms2, o2 = timed(c2, f2, P2, K2, H2, s2)
+            b2 = o2["best"].cpu().numpy()
+            others[wl] = {"workload": f"{w2}x{h2}, {K2} keypoints, {H2} hypotheses, batch {P2} pairs", "ms_per_step": ms2,
+                          "frame_pairs_per_s": P2 / ms2 * 1e3, "steps": 10, "mean_inlier_matches": float(b2[:, 3].mean()),
+                          "degenerate": bool((b2[:, 0] < 0).any())}
+            c2.close()
+            del f2, o2, c2
+            torch.cuda.empty_cache()
+        result["other_workloads"] = others
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -490,6 +654,7 @@ def main():
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     os.close(real_stdout)
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

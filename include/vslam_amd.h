@@ -77,6 +77,11 @@ const char *vslam_version(void);
 #define VSLAM_OPT_RANSAC_MIN_MATCHES 2
 #define VSLAM_OPT_RANSAC_SOLVER 3
 #define VSLAM_OPT_MATCH_SHAPE 4
+/*   VSLAM_OPT_CORNER_WINDOW_PCT  135 (default): how many of the detector's possible corners get the exact arithmetic
+ *       at once, in percent of max_corners (+ 128).  The selection ranks about 1.3 x max_corners candidates; a frame
+ *       whose selection needs more than were evaluated is redone with all of them, so the value changes speed, never
+ *       results (0 = always everything; a small value forces the redo: a test knob).                              */
+#define VSLAM_OPT_CORNER_WINDOW_PCT 5
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

@@ -52,3 +52,26 @@ def test_under_the_drivers_launcher_stdout_is_one_json_line():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, r.stdout
+
+
+def test_the_drivers_scale_command_at_eight_ranks():
+    """SCALE's last point exactly as the driver launches it — `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W` — rehearsed here
+    with eight gloo ranks in the dry mode: the 8-way slices, the gather of 8 x P records and the per-rank timing fields
+    of the line are what is under test."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VSLAM_BENCH_DRY="1", VSLAM_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["gather_ok"] is True and d["steps"] == 2 and d["warmup"] == 1
+    pr = d["per_rank_ms_per_step"]
+    assert len(pr["ranks"]) == 8 and pr["min"] <= pr["max"]

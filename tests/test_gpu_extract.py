@@ -53,6 +53,27 @@ def test_good_features_bit_exact(ctx, oracle, w, h, maxc):
         assert np.array_equal(xy[f, :n[f]], ref), f
 
 
+@pytest.mark.parametrize("pct", [1, 20, 0, 100000])
+def test_exact_window_size_never_changes_results(ctx, oracle, pct):
+    """The two-tier detector evaluates only the best-ranked possible corners exactly (VSLAM_OPT_CORNER_WINDOW_PCT) and
+    redoes a frame with all of them when the selection needs more: pct 1 and 20 leave far fewer than max_corners above
+    the cut, so every frame takes the redo; 0 / 100000 evaluate everything up front.  Same corners, same order."""
+    ctx.set_option(ctx.OPT_CORNER_WINDOW_PCT, pct)
+    try:
+        for (w, h, maxc, md) in ((640, 480, 1000, 3.0), (320, 240, 300, 7.0), (1280, 96, 2000, 1.0)):
+            bgr = frames_for(w, h, 77 + w)
+            gray = ctx.bgr2gray(torch.from_numpy(bgr).cuda())
+            xy, n = ctx.good_features(gray, maxc, min_distance=md)
+            ctx.synchronize()
+            gray, xy, n = gray.cpu().numpy(), xy.cpu().numpy(), n.cpu().numpy()
+            for f in range(bgr.shape[0]):
+                ref = oracle.good_features(gray[f], maxc, min_dist=md)
+                assert n[f] == len(ref), (pct, w, h, f, n[f], len(ref))
+                assert np.array_equal(xy[f, :n[f]], ref), (pct, w, h, f)
+    finally:
+        ctx.set_option(ctx.OPT_CORNER_WINDOW_PCT, 135)
+
+
 def test_good_features_plateaus_and_flat(ctx, oracle):
     """Synthetic eigenvalue plateaus: a checkerboard gives many pixels with EQUAL response, so the
     address tie-break of the sort and the equal-value suppression chains are exercised; a flat

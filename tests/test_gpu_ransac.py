@@ -285,6 +285,51 @@ def test_threshold_and_scale_outside_certified_range(ctx, oracle, sums_mode):
             _compare(out, ref, b, n, sums_mode)
 
 
+def test_tiny_denominators_take_the_exact_path(ctx, oracle, sums_mode):
+    """Hypotheses whose first row is about 1e-20 and smaller: the residual's denominator Fx1[0]^2 is a float denormal
+    or zero, where v_rcp_f32 is not a reciprocal.  The counting kernel's cheap evaluation certifies nothing there and
+    must hand every such evaluation to the exact sequence (the guard compares with 2^-120, "unordered or less than")."""
+    K, Hy, thr = 700, 160, 10.0
+    sizes = [700, 300]
+    xy1, xy2, pairs, m = _batch(7100, sizes, K, 1280, 720)
+    sets = np.stack([oracle.ransac_sets(3 + b, n, Hy) for b, n in enumerate(sizes)])
+    t = lambda a: torch.from_numpy(a).cuda()
+    solved = ctx.ransac_fundamental(t(xy1), t(xy2), t(pairs), t(m), t(sets), thr)
+    ctx.synchronize()
+    hypF = solved["hypF"].cpu().numpy().copy()
+    rng = np.random.default_rng(5)
+    for b in range(2):
+        for h in range(Hy):
+            kind = h % 4
+            if h % 16 == 0:    # the whole matrix tiny: n^2 and Fx1[0]^2 both denormal, their quotient an ordinary number
+                hypF[b, h] *= np.float32(10.0 ** -rng.uniform(16.5, 19.5))
+            elif kind == 1:    # denormal squares
+                hypF[b, h, 0:3] *= np.float32(10.0 ** -rng.uniform(18, 21))
+            elif kind == 2:    # squares that underflow to zero, and an exactly zero row
+                hypF[b, h, 0:3] = 0 if h % 8 == 2 else hypF[b, h, 0:3] * np.float32(1e-30)
+            elif kind == 3:    # one tiny coefficient only: tiny for some matches, not for others
+                hypF[b, h, 2] = np.float32(-(hypF[b, h, 0] * 640 + hypF[b, h, 1] * 360)) + np.float32(1e-22)
+    out = ctx.ransac_evaluate(t(xy1), t(xy2), t(pairs), t(m), t(hypF), thr)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for b, n in enumerate(sizes):
+        counts = np.zeros(Hy, np.int32); sums = np.zeros(Hy, np.float32)
+        best, best_sum, winner = 0, np.float32(0.0), -1
+        with np.errstate(all="ignore"):
+            for h in range(Hy):
+                _, c, s_ = oracle.residual(xy1[b], xy2[b], pairs[b, :n], hypF[b, h], thr)
+                counts[h], sums[h] = c, s_
+                if c > best or (c == best and s_ > best_sum):      # src/RansacFilter.cpp:59
+                    best, best_sum, winner = c, s_, h
+        check_counts(out["hyp_count"][b], counts, sums_mode, b)
+        check_sums(out["hyp_sum"][b], counts, sums, sums_mode, b)
+        assert out["best"][b, 0] == winner, (b, out["best"][b], winner, best)
+        if winner >= 0:
+            assert out["best"][b, 1] == best, b
+            mask, _, _ = oracle.residual(xy1[b], xy2[b], pairs[b, :n], hypF[b, winner], thr)
+            assert np.array_equal(out["mask"][b, :n], mask), b
+
+
 def test_mfma_solver_is_opt_in_and_agrees_within_its_stated_tolerance(ctx, oracle):
     """VSLAM_OPT_RANSAC_SOLVER = 1 (BASELINE.json configs[4]: the 8-point solve as an MFMA contraction) is an
     approximate solver and says so: it is off unless asked for, and what it promises is

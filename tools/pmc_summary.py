@@ -12,7 +12,7 @@ from collections import defaultdict
 
 NAME = re.compile(r"((?:bgr2gray|min_eigen|corner_[a-z]+|gaussian7|keypoint_border|rbrief|kdtree_[a-z]+|match_[a-z0-9]+|"
                   r"ransac_[a-z]+|pmc_calib_copy\d+)(?:_v4|_stream|_tiered|_lds|_rotate|_mfma)?_kernel)")
-WIDE = {"min_eigen_stream_kernel": "w"}   # 16 B/lane side: write
+WIDE = {}   # 16 B/lane side: write
 # (calibration shows the same factors for 4 B and 16 B per lane: FETCH_SIZE x2, WRITE_SIZE x1)
 
 

@@ -1,21 +1,23 @@
 # rocprofv3 passes over the default bench command (C3): kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in their own
 # passes, with the calibration copies), SQ counters.  Usage (on the GPU box): bash tools/prof_all.sh <tag>
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--steps 5 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass"
+B="--steps 5 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass --no-extras"
 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py $B > $O/stats.log 2>&1
 echo stats done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass --pmc-calibrate > $O/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass --no-extras --pmc-calibrate > $O/fetch.log 2>&1
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass --pmc-calibrate > $O/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass --no-extras --pmc-calibrate > $O/write.log 2>&1
 echo write done
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $O/sq -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass > $O/sq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $O/sq -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --cpu-all-cores-pairs 0 --no-profile-pass --no-extras > $O/sq.log 2>&1
 echo sq done
 cd $R
 python3 tools/prof_summary.py $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_summary.csv > /dev/null
 python3 tools/pmc_summary.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_hbm_traffic.csv > /dev/null
 python3 tools/sq_summary.py $(find $O/sq -name "*counter_collection.csv" | head -1) $O/sq_counters.csv
+python3 -c "import sys; sys.path.insert(0, '.'); import bench; print(bench.source_stamp())" > $O/source_stamp.txt
+rm -rf $O/stats $O/fetch $O/write $O/sq   # the raw traces are large; the summaries are what is kept

@@ -104,6 +104,7 @@ class Context:
     OPT_RANSAC_MIN_MATCHES = 2
     OPT_RANSAC_SOLVER = 3
     OPT_MATCH_SHAPE = 4
+    OPT_CORNER_WINDOW_PCT = 5
 
     def set_option(self, option, value):
         self._check(self.lib.vslam_ctx_set_option(self.handle, C.c_int(option), C.c_int(int(value))))
@@ -176,6 +177,29 @@ class Context:
             self.handle, _ptr(xy1), _ptr(xy2), _ptr(pairs), _ptr(m), _ptr(sets), C.c_int(B), C.c_int(K),
             C.c_int(H), C.c_float(threshold), _ptr(out["F"]), _ptr(out["mask"]), _ptr(out["best"]),
             _ptr(out["matches"]), _ptr(out["hypF"]), _ptr(out["hyp_count"]), _ptr(out["hyp_sum"])))
+        return out
+
+    def ransac_evaluate(self, xy1, xy2, pairs, m, hypF, threshold):
+        """compute_fundamental_residual for GIVEN hypotheses + the accept rule (vslam_ransac_evaluate)."""
+        torch = self.torch
+        B, K, _ = xy1.shape
+        H = hypF.shape[1]
+        dev = xy1.device
+        for t, dt, nm in ((xy1, torch.float32, "xy1"), (xy2, torch.float32, "xy2"), (pairs, torch.int32, "pairs"),
+                          (m, torch.int32, "m"), (hypF, torch.float32, "hypF")):
+            self._dev(t, dt, nm)
+        out = dict(
+            F=torch.zeros((B, 9), dtype=torch.float32, device=dev),
+            mask=torch.zeros((B, K), dtype=torch.uint8, device=dev),
+            best=torch.zeros((B, 4), dtype=torch.int32, device=dev),
+            matches=torch.zeros((B, K, 2), dtype=torch.int32, device=dev),
+            hyp_count=torch.zeros((B, H), dtype=torch.int32, device=dev),
+            hyp_sum=torch.zeros((B, H), dtype=torch.float32, device=dev),
+        )
+        self._check(self.lib.vslam_ransac_evaluate(
+            self.handle, _ptr(xy1), _ptr(xy2), _ptr(pairs), _ptr(m), _ptr(hypF), C.c_int(B), C.c_int(K), C.c_int(H),
+            C.c_float(threshold), _ptr(out["F"]), _ptr(out["mask"]), _ptr(out["best"]), _ptr(out["matches"]),
+            _ptr(out["hyp_count"]), _ptr(out["hyp_sum"])))
         return out
 
     def kdtree_build(self, xy, n):

@@ -226,6 +226,11 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
         ctx->ransac_solver = value;
         return VSLAM_OK;
     }
+    if (option == VSLAM_OPT_CORNER_WINDOW_PCT) {
+        VS_REQUIRE(ctx, value >= 0 && value <= 100000, VSLAM_ERR_INVALID);
+        ctx->corner_window_pct = value;
+        return VSLAM_OK;
+    }
     if (option == VSLAM_OPT_MATCH_SHAPE) {
         VS_REQUIRE(ctx, value >= 0 && value <= 2, VSLAM_ERR_INVALID);
         ctx->match_shape = value;
@@ -422,12 +427,25 @@ int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int
                                   cos_a, sin_a, d_pattern, d_xy_out, d_desc, d_n_out);
 }
 
+// State that one entry point arms for a later stage of the same call (the rotated rBRIEF table queued ahead of the
+// description stage; the raw generator outputs queued ahead of vslam_match_features) must not outlive that call: on
+// an error return in between, the next call would otherwise skip work it needs.  Cleared on every exit.
+struct VsTableGuard {
+    vslam_ctx *c;
+    ~VsTableGuard() { c->rbrief_table_ready = false; c->fork_after_eigen = false; }
+};
+struct VsPrefetchGuard {
+    vslam_ctx *c;
+    ~VsPrefetchGuard() { c->raw_seeds = nullptr; }
+};
+
 // extract_features(Frame&), src/Frame.cpp:53-80
 int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
                            int row_stride, const vslam_extract_params *params, int kp_stride,
                            float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
                            int32_t *d_n_detected) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    VsTableGuard table_guard{ctx};
     VS_REQUIRE(ctx, d_bgr && params && d_xy && d_desc && d_n, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, params->d_pattern, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, params->max_corners > 0 && params->max_corners <= kp_stride, VSLAM_ERR_INVALID);
@@ -595,6 +613,7 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
                          uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches,
                          int32_t *d_best, float *d_F) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    VsPrefetchGuard prefetch_guard{ctx};
     VS_REQUIRE(ctx, pairs > 0, VSLAM_ERR_INVALID);
     // The k-d trees are an output of the path but not an input of match/RANSAC: build them on the
     // auxiliary stream beside the matching stages (fork after extraction, join at the end).  With
@@ -660,6 +679,7 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
                             uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches,
                             int32_t *d_best, float *d_F) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    VsPrefetchGuard prefetch_guard{ctx};
     VS_REQUIRE(ctx, frames >= 2, VSLAM_ERR_INVALID);
     const bool overlap = d_nodes && !ctx->prof;   // k-d trees beside the matching stages, as in vslam_frontend_pairs
     int rc = vs_sets_prefetch(ctx, d_seeds, frames - 1, hyp);

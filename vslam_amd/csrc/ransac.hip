@@ -1339,7 +1339,7 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const float4 X1, 
     y2a.x = Y2.x; y2a.y = Y2.y; y2b.x = Y2.z; y2b.y = Y2.w;
     cnt_eval_pair<PARTIAL>(R, x1a, y1a, x2a, y2a, ix, m, c, u0, u1, ddmin, acc);
     cnt_eval_pair<PARTIAL>(R, x1b, y1b, x2b, y2b, ix + 2, m, c, u2, u3, ddmin, acc);
-    if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, 9) != 0ull) {   // 9 = unordered or <: some dd is zero / denormal (or NaN)
+    if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, 12) != 0ull) {   // 12 = unordered or <: some dd is zero / denormal (or NaN)
         // nothing of this sub-block is certified: all of it is queued, and the hypothesis' cheap sum means nothing
         if (lane == 0) s_unk[hh] = 1;
         c = 0;
@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(256) void ransac_screen_kernel(
             const unsigned long long oa = __builtin_amdgcn_fcmpf(g[u].x, R[u].hi, 2), ob = __builtin_amdgcn_fcmpf(g[u].y, R[u].hi, 2);
             int p = __popcll(va & ~oa) + __popcll(vb & ~ob);
             // a zero / denormal (or NaN) dd: v_rcp_f32 is not a 1-ulp reciprocal there, nothing is certified
-            if (__builtin_amdgcn_fcmpf(fminf(dd[u].x, dd[u].y), kCntTinyDD, 9) != 0ull) p = n0;
+            if (__builtin_amdgcn_fcmpf(fminf(dd[u].x, dd[u].y), kCntTinyDD, 12) != 0ull) p = n0;   // 12 = unordered or <
             mine = lane == j + u ? p : mine;
         }
     }

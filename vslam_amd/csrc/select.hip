@@ -802,8 +802,9 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     // The selection ranks 1.25 x max_corners + 64 candidates (twice that if the suppression leaves it short, which it
     // rarely does): evaluate exactly that first window plus slack — the exact tier is bound by its scattered window
     // reads, about 640 B per pixel — and rerun a frame completely if it runs out.
-    static const char *ns_env = getenv("VSLAM_CORNER_NSAFE_PCT");   // percent of max_corners, for A/B timing
-    const uint32_t n_safe = (uint32_t)max_corners * (uint32_t)(ns_env ? atoi(ns_env) : 135) / 100u + 128u;
+    const uint32_t n_safe = ctx->corner_window_pct > 0
+                                ? (uint32_t)((unsigned long long)max_corners * (unsigned)ctx->corner_window_pct / 100u) + 128u
+                                : 0xFFFFFFFFu;   // 0: everything
     int raw_list = 0;
     if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, c, keys, keys2, key_cap, n_safe, &raw_list))) return rc;
     if (ctx->fork_after_eigen) {   // the caller runs an independent stage on the auxiliary stream beside the selection

@@ -187,16 +187,22 @@ uint64_t hash_points(uint64_t h, const cv::Point2f *p, size_t n) {
     }
     return h;
 }
-uint64_t hash_tree(const frame_kdtree &kd, const std::vector<cv::Point2f> &points) {
-    uint64_t h = mix(0x5EED, points.size());
-    for (size_t i = 0; i < points.size(); i++) h = mix(h, (uint64_t)kd.root[i].pt_index);
+// nodes a tree really has (its array holds exactly these, in pre-order): the caller's point vector may have grown
+// since construct_kdtree, and the reference only ever dereferences pt_index values
+template <class Node>
+int node_count(const Node *nd) { return nd ? 1 + node_count(nd->left) + node_count(nd->right) : 0; }
+
+uint64_t hash_tree(const frame_kdtree &kd, int nodes, const std::vector<cv::Point2f> &points) {
+    uint64_t h = mix(0x5EED, (uint64_t)nodes);
+    for (int i = 0; i < nodes; i++) h = mix(h, (uint64_t)kd.root[i].pt_index);
     return hash_points(h, points.data(), points.size());
 }
 
-std::shared_ptr<DevTree> alloc_tree(int n) {
+// n nodes over npts points (npts >= n: the nodes index into the caller's point vector, which may have grown)
+std::shared_ptr<DevTree> alloc_tree(int n, int npts = -1) {
     auto t = std::make_shared<DevTree>();
     t->count = n;
-    t->stride = n > 0 ? n : 1;
+    t->stride = std::max(std::max(n, npts), 1);
     Layout L;
     const size_t o_n = L.add(4), o_nodes = L.add(4 * (size_t)t->stride), o_xy = L.add(8 * (size_t)t->stride);
     auto &pool = device().tree_blocks;
@@ -229,8 +235,9 @@ void remember_tree(const void *root, const std::shared_ptr<DevTree> &t) {
 }
 
 // upload (count, pre-order index column, points) in one copy
-std::shared_ptr<DevTree> upload_tree(const int32_t *pre_idx, const cv::Point2f *pts, int n) {
-    auto t = alloc_tree(n);
+std::shared_ptr<DevTree> upload_tree(const int32_t *pre_idx, const cv::Point2f *pts, int n, int npts = -1) {
+    if (npts < n) npts = n;
+    auto t = alloc_tree(n, npts);
     const size_t bytes = (size_t)(reinterpret_cast<uint8_t *>(t->xy) - static_cast<uint8_t *>(t->block)) + 8 * (size_t)t->stride;
     uint8_t *h = static_cast<uint8_t *>(pinned_scratch("tree.stage", bytes));
     std::memset(h, 0, 4);
@@ -238,7 +245,7 @@ std::shared_ptr<DevTree> upload_tree(const int32_t *pre_idx, const cv::Point2f *
     std::memcpy(h, &nn, 4);
     if (n > 0) {
         std::memcpy(h + (reinterpret_cast<uint8_t *>(t->nodes) - static_cast<uint8_t *>(t->block)), pre_idx, 4 * (size_t)n);
-        std::memcpy(h + (reinterpret_cast<uint8_t *>(t->xy) - static_cast<uint8_t *>(t->block)), pts, 8 * (size_t)n);
+        std::memcpy(h + (reinterpret_cast<uint8_t *>(t->xy) - static_cast<uint8_t *>(t->block)), pts, 8 * (size_t)npts);
     }
     check(vslam_copy_h2d(ctx(), t->block, h, bytes), "copy_h2d");
     return t;
@@ -278,23 +285,24 @@ Node *link_preorder(Node *base, int pos, int len) {
 u8 tree_height(int n) { return (u8)(std::floor(std::log2((double)n)) + 1); }   // src/KDTree.cpp:33,119
 
 std::shared_ptr<DevTree> device_tree_for(const frame_kdtree &kd, const std::vector<cv::Point2f> &points) {
-    const uint64_t h = hash_tree(kd, points);
+    const int n = node_count(kd.root);
+    const uint64_t h = hash_tree(kd, n, points);
     auto it = g_trees.find(kd.root);
-    if (it != g_trees.end() && it->second->count == (int)points.size() && it->second->hash == h) {
+    if (it != g_trees.end() && it->second->count == n && it->second->hash == h) {
         it->second->stamp = ++g_stamp;
         return it->second;
     }
     // built elsewhere, forgotten, or changed since it was uploaded: its array is in pre-order, upload it
-    const int n = (int)points.size();
     std::vector<int32_t> pre(n);
-    for (int i = 0; i < n; i++) pre[i] = (int32_t)kd.root[i].pt_index;
-    auto t = upload_tree(pre.data(), points.data(), n);
+    for (int i = 0; i < n; i++) {
+        pre[i] = (int32_t)kd.root[i].pt_index;
+        if (pre[i] < 0 || (size_t)pre[i] >= points.size()) throw std::runtime_error("frame_kdtree: pt_index outside points");
+    }
+    auto t = upload_tree(pre.data(), points.data(), n, (int)points.size());
     t->hash = h;
     remember_tree(kd.root, t);
     return t;
 }
-
-int node_count(const KDTree::KDTreeNode *nd) { return nd ? 1 + node_count(nd->left) + node_count(nd->right) : 0; }
 
 // a KDTree carries its points inside the nodes (array order == pre-order): identity index column over them
 std::shared_ptr<DevTree> device_tree_for(const KDTree &kd, std::vector<cv::Point2f> &pts) {
@@ -440,7 +448,7 @@ void construct_kdtree(frame_kdtree &kdtree, const std::vector<cv::Point2f> &poin
     kdtree.root = nodes;
     kdtree.size += (u32)N;   // the reference never resets size
     kdtree.height = tree_height((int)N);
-    dev->hash = hash_tree(kdtree, points);
+    dev->hash = hash_tree(kdtree, (int)N, points);
     remember_tree(nodes, dev);
 }
 

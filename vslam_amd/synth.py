@@ -132,3 +132,72 @@ def frames_torch(seed, n_pairs, width, height, device):
             tint = torch.tensor([-4.0, 0.0, 4.0], device=device)
             out[f] = torch.clamp(img[:, :, None] + noise + tint, 0, 255).to(torch.uint8)
     return out
+
+
+def frames_torch_hard(seed, n_pairs, width, height, device, outlier_area=0.55):
+    """The harder regime SURVEY.md 8(d) specifies, on `device`: frame B is frame A seen after a small camera motion —
+    an in-plane rotation of up to 1.5 degrees about the image centre and a shift of up to 12 px (the infinite
+    homography) plus a parallax of 0..10 px along one epipolar direction that depends on which of four depth layers a
+    96-px cell belongs to — resampled bilinearly at sub-pixel positions, with fresh noise; so one fundamental matrix
+    explains every true correspondence and the scene is not a single plane.  On `outlier_area` of the image (cells
+    drawn at random) B instead shows the texture displaced by an unrelated vector of up to 40 px (matches there are
+    outliers to the dominant geometry: 40-45 % of the matches) or, for a quarter of those cells, texture that A does
+    not contain at all.
+    Returns uint8 (2 * n_pairs, H, W, 3): frames [0, n) are 'last', [n, 2n) 'current', like frames_torch."""
+    import torch
+    import torch.nn.functional as Fn
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) ^ 0x4A7D)
+    pad = 64
+    H2, W2 = height + 2 * pad, width + 2 * pad
+    out = torch.empty((2 * n_pairs, height, width, 3), dtype=torch.uint8, device=device)
+    ys, xs = torch.meshgrid(torch.arange(height, device=device, dtype=torch.float32),
+                            torch.arange(width, device=device, dtype=torch.float32), indexing="ij")
+    cell = 96
+    ch, cw = (height + cell - 1) // cell, (width + cell - 1) // cell
+    tint = torch.tensor([-4.0, 0.0, 4.0], device=device)
+    chunk = 16   # pairs per texture batch (memory)
+    for p0 in range(0, n_pairs, chunk):
+        nb = min(chunk, n_pairs - p0)
+        base = torch.zeros((nb + 1, H2, W2), dtype=torch.float32, device=device)   # the last one: texture A never sees
+        for c, amp in ((16, 70.0), (24, 50.0), (10, 25.0)):
+            gh, gw = H2 // c + 2, W2 // c + 2
+            grid = (torch.rand((nb + 1, gh, gw), generator=g, device=device) * 2 - 1) * amp
+            up = grid.repeat_interleave(c, dim=1).repeat_interleave(c, dim=2)
+            base += up[:, 3:3 + H2, 5:5 + W2]
+        base = torch.clamp(128 + base, 8, 247)
+        par = torch.rand((nb, 8), generator=g, device=device).cpu()
+        for i in range(nb):
+            p = p0 + i
+            theta = float(par[i, 0] * 2 - 1) * 1.5 * math.pi / 180.0
+            sx, sy = float(par[i, 1] * 2 - 1) * 12.0, float(par[i, 2] * 2 - 1) * 12.0
+            phi = float(par[i, 3]) * 2 * math.pi
+            ex, ey = math.cos(phi), math.sin(phi)
+            # per-cell motion class in B's pixel domain
+            layer = torch.randint(0, 4, (ch, cw), generator=g, device=device)
+            depth_shift = torch.tensor([0.0, 3.0, 6.5, 10.0], device=device)[layer]
+            r = torch.rand((ch, cw), generator=g, device=device)
+            is_out = r < outlier_area
+            is_new = r < outlier_area / 4.0
+            ov = (torch.rand((ch, cw, 2), generator=g, device=device) * 2 - 1) * 40.0
+            dx_c = torch.where(is_out, ov[..., 0], depth_shift * ex)
+            dy_c = torch.where(is_out, ov[..., 1], depth_shift * ey)
+            up = lambda t: t.repeat_interleave(cell, 0).repeat_interleave(cell, 1)[:height, :width]
+            dxm, dym, newm = up(dx_c), up(dy_c), up(is_new)
+            # where B's pixel (x, y) comes from in A's frame: undo the rotation and shift, then the layer's displacement
+            cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
+            ct, st = math.cos(theta), math.sin(theta)
+            ux, uy = xs - cx - sx, ys - cy - sy
+            srcx = ct * ux + st * uy + cx - dxm
+            srcy = -st * ux + ct * uy + cy - dym
+            gx = (srcx + pad) / (W2 - 1) * 2 - 1
+            gy = (srcy + pad) / (H2 - 1) * 2 - 1
+            grid = torch.stack([gx, gy], -1)[None]
+            b_img = Fn.grid_sample(base[i][None, None], grid, mode="bilinear", padding_mode="border", align_corners=True)[0, 0]
+            n_img = Fn.grid_sample(base[nb][None, None], grid, mode="bilinear", padding_mode="border", align_corners=True)[0, 0]
+            b_img = torch.where(newm, n_img, b_img)
+            a_img = base[i, pad:pad + height, pad:pad + width]
+            for f, img in ((p, a_img), (n_pairs + p, b_img)):
+                noise = torch.randint(-6, 7, (height, width, 3), generator=g, device=device).float()
+                out[f] = torch.clamp(img[:, :, None] + noise + tint, 0, 255).to(torch.uint8)
+    return out
