@@ -184,6 +184,17 @@ int vslam_kdtree_nearest(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_
                          const int32_t *d_nq, int q_stride, float max_distance_sq,
                          int32_t *d_best_idx);
 
+/* The points of a tree filed by integer pixel cell, for callers that ask ONE radius query at a time
+ * (radius_search(frame.kdtree, frame.points, q, 2) once per in-view map point, src/vslam.cpp:146-160): a device round
+ * trip per query costs 200 x the reference's pointer chase, a probe of this table on the host does not.
+ * d_table [batch][slots][2] uint32 = {cell key ((floor(y) + 32768) << 16 | (floor(x) + 32768)), pre-order position},
+ * 0xFFFFFFFF = empty; open addressing from ((key * 2654435761) >> 7) & (slots - 1), linear; every point owns a slot;
+ * slots a power of two >= 2 * kp_stride.  d_ok [batch] = 0 when a coordinate does not fit the key (table unusable).
+ * Hits of a radius query = the points of the cells floor(q - r) .. floor(q + r) with dx * dx + dy * dy < r * r, in
+ * ascending pre-order position: exactly the reference's result and order (src/KDTree.cpp:151-171).              */
+int vslam_kdtree_cell_table(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_xy, const int32_t *d_n, int batch,
+                            int kp_stride, int slots, uint32_t *d_table, int32_t *d_ok);
+
 /* ---------------------------------------------------------------- extraction */
 typedef struct vslam_extract_params {
     int32_t max_corners;     /* goodFeaturesToTrack maxCorners (3000 in src/Frame.cpp:61)      */

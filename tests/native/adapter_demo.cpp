@@ -5,6 +5,7 @@
 // usage: adapter_demo <in.bin> <out.bin>
 //   in : int32 w, h, max_corners, hyp, seed ; then 2 BGR frames (h*w*3 bytes each) ; 1024 int8 pattern
 //   out: flat int32/float32 records, see the writes below
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -75,6 +76,35 @@ int main(int argc, char **argv) {
     int same = 1;
     for (size_t k = 0; k < qs.size(); k++) same &= (batch[k] == radius_search(f1.kdtree, f1.points, qs[k], 2));
     wr_i(fo, same);
+    // single queries are answered from the device-built cell table: many of them, several radii (on and off the grid,
+    // exactly r away from a keypoint: the test is strict), against the host walk of the same nodes (src/KDTree.cpp:151-171
+    // through the public node-pointer overload) and against the batched device query
+    {
+        int ok = 1, nonempty = 0;
+        unsigned lcg = 12345u;
+        auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) * (1.0f / 16777216.0f); };
+        const float radii[6] = {2.f, 0.f, 0.5f, 1.5f, 3.75f, 8.f};
+        for (int t = 0; t < 3000; t++) {
+            const float r = radii[t % 6];
+            const cv::Point2f &kp = f1.points[(size_t)(rnd() * f1.points.size()) % f1.points.size()];
+            cv::Point2f q;
+            switch (t % 5) {
+                case 0: q = cv::Point2f(kp.x + r, kp.y); break;                                   // exactly r away: not a hit
+                case 1: q = cv::Point2f(kp.x + (rnd() - 0.5f) * 6.f, kp.y + (rnd() - 0.5f) * 6.f); break;
+                case 2: q = cv::Point2f(std::floor(kp.x + rnd() * 4.f - 2.f), std::floor(kp.y + rnd() * 4.f - 2.f)); break;
+                case 3: q = cv::Point2f(rnd() * 330.f - 5.f, rnd() * 250.f - 5.f); break;         // anywhere, also outside the frame
+                default: q = kp; break;
+            }
+            std::vector<usize> want;
+            radius_search(f1.kdtree.root, f1.points, q, want, r, r * r, 0);
+            const std::vector<usize> got = radius_search(f1.kdtree, f1.points, q, r);
+            ok &= got == want ? 1 : 0;
+            nonempty += want.empty() ? 0 : 1;
+            if (t % 97 == 0) ok &= vslam::radius_search_batch(f1.kdtree, f1.points, std::vector<cv::Point2f>{q}, r)[0] == want ? 1 : 0;
+        }
+        wr_i(fo, ok);
+        wr_i(fo, nonempty);
+    }
 
     // the point-storing KDTree the reference's own test drives (tests/test_kdtree.cpp)
     KDTree kd;

@@ -65,6 +65,8 @@ def test_cpp_surfaces_match_oracle(oracle, tmp_path):
         c = int(take(np.int32, 1)[0])
         assert c == cnt and np.array_equal(take(np.int32, c), ref)
     assert int(take(np.int32, 1)[0]) == 1          # batch form == single-query form
+    assert int(take(np.int32, 1)[0]) == 1          # 3000 single queries (cell table) == host walk == batched device query
+    assert int(take(np.int32, 1)[0]) > 1000        # ... and most of them had hits
 
     import ctypes as C
     tree = np.zeros((len(pts), 2), np.float32)

@@ -392,6 +392,12 @@ int vslam_kdtree_nearest(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_
                                     max_distance_sq, d_best_idx);
 }
 
+int vslam_kdtree_cell_table(vslam_ctx *ctx, const int32_t *d_nodes, const float *d_xy, const int32_t *d_n, int batch,
+                            int kp_stride, int slots, uint32_t *d_table, int32_t *d_ok) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_kdtree_cell_table(ctx, d_nodes, d_xy, d_n, batch, kp_stride, slots, d_table, d_ok);
+}
+
 int vslam_bgr2gray(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
                    int row_stride, uint8_t *d_gray) {
     if (!ctx) return VSLAM_ERR_INVALID;

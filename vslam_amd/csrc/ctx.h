@@ -155,6 +155,8 @@ int vs_launch_kdtree_radius(vslam_ctx *ctx, const int32_t *nodes, const float *x
 int vs_launch_kdtree_nearest(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n,
                              int batch, int kp_stride, const float *queries, const int32_t *nq,
                              int q_stride, float max_distance_sq, int32_t *best_idx);
+int vs_launch_kdtree_cell_table(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n, int batch,
+                                int kp_stride, int slots, uint32_t *table, int32_t *ok);
 int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, int h, int stride,
                        uint8_t *gray);
 int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, float *eig,

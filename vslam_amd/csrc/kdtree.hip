@@ -214,6 +214,48 @@ __global__ __launch_bounds__(kQueryThreads) void kdtree_nearest_kernel(
 
 }  // namespace
 
+// The tree's points filed by integer pixel cell (floor x, floor y) in an open-addressing table, one slot per point:
+// slot = {cell key, pre-order position}.  A radius query then only has to look at the (2 r + 2)^2 cells around it — a
+// handful of host-side probes for the reference's r = 2 (src/vslam.cpp:149) — and sorting the hits by pre-order position
+// gives the reference's visit order (src/KDTree.cpp:151-171 pushes a node before its subtrees, left before right, and
+// every point with d^2 < r^2 is visited: a subtree is skipped only when it lies beyond r along the split axis).
+// ok[b] = 0 if a coordinate falls outside the key range (the caller then does not use the table).
+__global__ __launch_bounds__(256) void kdtree_cell_table_kernel(const int32_t *__restrict__ nodes, const float *__restrict__ xy,
+                                                                const int32_t *__restrict__ n_arr, int kp_stride, int slots,
+                                                                uint32_t *__restrict__ table, int32_t *__restrict__ ok) {
+    const int b = blockIdx.y, rank = blockIdx.x * 256 + threadIdx.x;
+    if (rank >= n_arr[b]) return;
+    const float2 pt = reinterpret_cast<const float2 *>(xy)[(size_t)b * kp_stride + nodes[(size_t)b * kp_stride + rank]];
+    const float fx = floorf(pt.x), fy = floorf(pt.y);
+    if (!(fx >= -32768.f && fx <= 32766.f && fy >= -32768.f && fy <= 32766.f)) {   // also NaN
+        ok[b] = 0;
+        return;
+    }
+    const uint32_t key = ((uint32_t)((int)fy + 32768) << 16) | (uint32_t)((int)fx + 32768);
+    uint32_t *T = table + (size_t)b * slots * 2;
+    uint32_t slot = (key * 2654435761u) >> 7;
+    while (true) {
+        slot &= (uint32_t)slots - 1u;
+        if (atomicCAS(&T[2 * slot], 0xFFFFFFFFu, key) == 0xFFFFFFFFu) break;   // every point takes a slot of its own
+        slot++;
+    }
+    T[2 * slot + 1] = (uint32_t)rank;
+}
+
+int vs_launch_kdtree_cell_table(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n, int batch,
+                                int kp_stride, int slots, uint32_t *table, int32_t *ok) {
+    VS_REQUIRE(ctx, nodes && xy && n && table && ok, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, batch > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, slots >= 2 * kp_stride && (slots & (slots - 1)) == 0, VSLAM_ERR_INVALID);   // power of two, load <= 1/2
+    VS_HIP(ctx, hipMemsetAsync(table, 0xFF, sizeof(uint32_t) * 2 * (size_t)slots * batch, ctx->stream));
+    VS_HIP(ctx, hipMemsetAsync(ok, 0x01, sizeof(int32_t) * (size_t)batch, ctx->stream));   // non-zero = usable
+    VsProfScope ps(ctx, "kdtree_cell_table_kernel");
+    dim3 grid(vs_div_up(kp_stride, 256), batch);
+    kdtree_cell_table_kernel<<<grid, 256, 0, ctx->stream>>>(nodes, xy, n, kp_stride, slots, table, ok);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
 int vs_launch_kdtree_nearest(vslam_ctx *ctx, const int32_t *nodes, const float *xy, const int32_t *n,
                              int batch, int kp_stride, const float *queries, const int32_t *nq,
                              int q_stride, float max_distance_sq, int32_t *best_idx) {

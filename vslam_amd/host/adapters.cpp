@@ -164,6 +164,16 @@ struct DevTree {
     float *xy = nullptr;
     int count = 0, stride = 0;
     uint64_t hash = 0, stamp = 0;
+    // Single radius queries (src/vslam.cpp:149 asks one per map point) are answered from a table the device built when
+    // the tree was constructed — the tree's points filed by pixel cell, vslam_kdtree_cell_table — copied to the host
+    // once.  Valid for the very point vector the tree was built from (identity + sampled contents; an in-place edit of
+    // the points calls for construct_kdtree or vslam::forget_kdtree, as a changed tree does in the reference).
+    std::vector<uint32_t> cells;      // [slots][2]
+    std::vector<int32_t> pre;         // pre-order position -> point index
+    uint32_t cell_mask = 0;
+    const void *pts_ptr = nullptr;
+    size_t pts_size = 0;
+    uint64_t pts_sample = 0;
     ~DevTree() {   // the block goes back to the pool, not to hipFree
         if (block) device().tree_blocks.push_back(Block{block, block_bytes});
     }
@@ -251,6 +261,79 @@ std::shared_ptr<DevTree> upload_tree(const int32_t *pre_idx, const cv::Point2f *
     return t;
 }
 
+uint64_t sample_points(const std::vector<cv::Point2f> &p) {
+    uint64_t h = mix(0xC311, p.size());
+    const size_t n = p.size(), step = n > 16 ? n / 16 : 1;
+    for (size_t i = 0; i < n; i += step) {
+        uint64_t v;
+        std::memcpy(&v, &p[i], 8);
+        h = mix(h, v);
+    }
+    return h;
+}
+
+// file the tree's points by pixel cell on the device and keep the table on the host (one kernel, one copy)
+void build_cell_table(DevTree &t, const std::vector<int32_t> &pre, const std::vector<cv::Point2f> &points) {
+    const int n = t.count;
+    t.cells.clear();
+    if (n <= 0) return;
+    int slots = 64;
+    while (slots < 2 * t.stride) slots <<= 1;
+    Layout in, res, work;
+    const size_t o_tab = res.add(8 * (size_t)slots), o_ok = res.add(4);
+    Call c(in, res, work);
+    check(vslam_kdtree_cell_table(ctx(), t.nodes, t.xy, t.n, 1, t.stride, slots, c.dout<uint32_t>(o_tab), c.dout<int32_t>(o_ok)),
+          "kdtree_cell_table");
+    c.download();
+    if (*c.hout<int32_t>(o_ok) == 0) return;   // coordinates outside the key range: single queries take the device path
+    t.cells.assign(c.hout<uint32_t>(o_tab), c.hout<uint32_t>(o_tab) + 2 * (size_t)slots);
+    t.cell_mask = (uint32_t)slots - 1u;
+    t.pre = pre;
+    t.pts_ptr = points.data();
+    t.pts_size = points.size();
+    t.pts_sample = sample_points(points);
+}
+
+// radius_search from the cell table: the hits in the reference's visit order.  false = not answerable here.
+bool cell_query(const DevTree &t, const std::vector<cv::Point2f> &points, const cv::Point2f &q, float radius,
+                std::vector<usize> &out) {
+    if (t.cells.empty() || t.pts_ptr != points.data() || t.pts_size != points.size()) return false;
+    if (!(radius >= 0.f && radius <= 8.f) || !(std::fabs(q.x) < 30000.f && std::fabs(q.y) < 30000.f)) return false;
+    if (t.pts_sample != sample_points(points)) return false;
+    const float r2 = radius * radius;   // SQ(radius), src/KDTree.cpp:146
+    const int x0 = (int)std::floor(q.x - radius), x1 = (int)std::floor(q.x + radius);
+    const int y0 = (int)std::floor(q.y - radius), y1 = (int)std::floor(q.y + radius);
+    std::pair<uint32_t, int32_t> hits[64];
+    int nh = 0;
+    const uint32_t *T = t.cells.data();
+    for (int cy = y0; cy <= y1; cy++)
+        for (int cx = x0; cx <= x1; cx++) {
+            const uint32_t key = ((uint32_t)(cy + 32768) << 16) | (uint32_t)(cx + 32768);
+            uint32_t slot = (key * 2654435761u) >> 7;
+            while (true) {
+                slot &= t.cell_mask;
+                const uint32_t k = T[2 * slot];
+                if (k == 0xFFFFFFFFu) break;
+                if (k == key) {
+                    const uint32_t rank = T[2 * slot + 1];
+                    const int32_t idx = t.pre[rank];
+                    const cv::Point2f &pt = points[(size_t)idx];
+                    const float dx = q.x - pt.x, dy = q.y - pt.y;
+                    const float xx = dx * dx, yy = dy * dy;
+                    if (xx + yy < r2) {   // strict, src/KDTree.cpp:161
+                        if (nh == 64) return false;   // a crowd: let the device path size its answer
+                        hits[nh++] = {rank, idx};
+                    }
+                }
+                slot++;
+            }
+        }
+    std::sort(hits, hits + nh);   // pre-order position = the order the reference pushes them in
+    out.resize((size_t)nh);
+    for (int i = 0; i < nh; i++) out[(size_t)i] = (usize)hits[i].second;
+    return true;
+}
+
 // build on the device; returns the pre-order pt_index column, keeps the device copy
 std::vector<int32_t> device_build(const std::vector<cv::Point2f> &points, std::shared_ptr<DevTree> *keep) {
     const int n = (int)points.size();
@@ -288,11 +371,15 @@ std::shared_ptr<DevTree> device_tree_for(const frame_kdtree &kd, const std::vect
     const int n = node_count(kd.root);
     const uint64_t h = hash_tree(kd, n, points);
     auto it = g_trees.find(kd.root);
+    std::shared_ptr<DevTree> table_of;   // an entry that so far only carries the host-side cell table (extract_features)
     if (it != g_trees.end() && it->second->count == n && it->second->hash == h) {
-        it->second->stamp = ++g_stamp;
-        return it->second;
+        if (it->second->block) {
+            it->second->stamp = ++g_stamp;
+            return it->second;
+        }
+        table_of = it->second;
     }
-    // built elsewhere, forgotten, or changed since it was uploaded: its array is in pre-order, upload it
+    // built elsewhere, forgotten, not on the device yet, or changed since it was uploaded: its array is in pre-order, upload it
     std::vector<int32_t> pre(n);
     for (int i = 0; i < n; i++) {
         pre[i] = (int32_t)kd.root[i].pt_index;
@@ -300,6 +387,14 @@ std::shared_ptr<DevTree> device_tree_for(const frame_kdtree &kd, const std::vect
     }
     auto t = upload_tree(pre.data(), points.data(), n, (int)points.size());
     t->hash = h;
+    if (table_of) {
+        t->cells.swap(table_of->cells);
+        t->pre.swap(table_of->pre);
+        t->cell_mask = table_of->cell_mask;
+        t->pts_ptr = table_of->pts_ptr;
+        t->pts_size = table_of->pts_size;
+        t->pts_sample = table_of->pts_sample;
+    }
     remember_tree(kd.root, t);
     return t;
 }
@@ -449,6 +544,7 @@ void construct_kdtree(frame_kdtree &kdtree, const std::vector<cv::Point2f> &poin
     kdtree.size += (u32)N;   // the reference never resets size
     kdtree.height = tree_height((int)N);
     dev->hash = hash_tree(kdtree, (int)N, points);
+    build_cell_table(*dev, pre, points);
     remember_tree(nodes, dev);
 }
 
@@ -472,6 +568,12 @@ void construct_kdtree(KDTree &kdtree, const std::vector<cv::Point2f> &points) {
 
 std::vector<usize> radius_search(const frame_kdtree kdtree, const std::vector<cv::Point2f> &points,
                                  const cv::Point2f &query_pt, float radius) {
+    if (kdtree.root != nullptr) {   // the tree this library built, asked about the points it was built from
+        Lock lk(g_mu);
+        auto it = g_trees.find(kdtree.root);
+        std::vector<usize> out;
+        if (it != g_trees.end() && cell_query(*it->second, points, query_pt, radius, out)) return out;
+    }
     return vslam::radius_search_batch(kdtree, points, std::vector<cv::Point2f>{query_pt}, radius)[0];
 }
 
@@ -709,6 +811,9 @@ void extract_features(Frame &frame) {
     in.add(0);
     const size_t o_n = res.add(4), o_nd = res.add(4), o_xy = res.add(8 * (size_t)K), o_desc = res.add(32 * (size_t)K),
                  o_nodes = res.add(4 * (size_t)K);
+    int slots = 64;   // the tree's points by pixel cell, for the single radius queries of src/vslam.cpp:149
+    while (slots < 2 * K) slots <<= 1;
+    const size_t o_tab = res.add(8 * (size_t)slots), o_ok = res.add(4);
     Call c(in, res, work);
     uint8_t *dimg = static_cast<uint8_t *>(dev_scratch("frame.image", img_bytes));
     check(vslam_copy_h2d(ctx(), dimg, img.data, img_bytes), "image upload");
@@ -717,6 +822,9 @@ void extract_features(Frame &frame) {
     check(vslam_extract_features(ctx(), dimg, 1, w, h, (int)img.step, &p, K, c.dout<float>(o_xy), c.dout<uint8_t>(o_desc),
                                  c.dout<int32_t>(o_nodes), c.dout<int32_t>(o_n), c.dout<int32_t>(o_nd)),
           "extract_features");
+    check(vslam_kdtree_cell_table(ctx(), c.dout<int32_t>(o_nodes), c.dout<float>(o_xy), c.dout<int32_t>(o_n), 1, K, slots,
+                                  c.dout<uint32_t>(o_tab), c.dout<int32_t>(o_ok)),
+          "kdtree_cell_table");
     c.download();
     const int32_t n = *c.hout<int32_t>(o_n), nd = *c.hout<int32_t>(o_nd);
     const size_t old = frame.points.size();
@@ -734,7 +842,21 @@ void extract_features(Frame &frame) {
         frame.kdtree.root = nodes;
         frame.kdtree.size += (u32)n;
         frame.kdtree.height = tree_height(n);
-        // (its device copy is made by the first radius query that needs it, src/vslam.cpp:149)
+        // its device copy is made by the first batched query that needs it; single queries (src/vslam.cpp:149) are
+        // answered from the cell table that came down with this call
+        auto t = std::make_shared<DevTree>();
+        t->count = n;
+        t->stride = n;
+        t->hash = hash_tree(frame.kdtree, n, frame.points);
+        if (*c.hout<int32_t>(o_ok) != 0) {
+            t->cells.assign(c.hout<uint32_t>(o_tab), c.hout<uint32_t>(o_tab) + 2 * (size_t)slots);
+            t->cell_mask = (uint32_t)slots - 1u;
+            t->pre.assign(pre, pre + n);
+            t->pts_ptr = frame.points.data();
+            t->pts_size = frame.points.size();
+            t->pts_sample = sample_points(frame.points);
+        }
+        remember_tree(nodes, t);
     } else {
         construct_kdtree(frame.kdtree, frame.points);
     }
