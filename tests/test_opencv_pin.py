@@ -1,7 +1,8 @@
 """Pins the oracle to REAL OpenCV output — when somebody has produced it.
 
-Everything the reference computes inside OpenCV (cvtColor, goodFeaturesToTrack,
-ORB::compute, BFMatcher::knnMatch, SVDecomp, the cv::Mat algebra of the residual) is restated in oracle/ from
+Everything the reference computes inside OpenCV (SURVEY.md 8 a2, a3, a4, a8, a11-a13 and the 8f pose helpers: cvtColor,
+goodFeaturesToTrack, ORB::detect / compute, FAST, resize, BFMatcher::knnMatch, SVDecomp / SVD::compute, the cv::Mat algebra
+of the residual and of extract_Rt / triangulate) is restated in oracle/ from
 OpenCV's published algorithms, and OpenCV is not in this image, so that restatement is unverified: PARITY UNPINNED.
 tools/opencv_dump.cpp runs the reference's own OpenCV calls on the seeded inputs of tests/golden/frontend_v1.npz on a
 machine that has OpenCV; its output, committed as tests/golden/opencv_v1.npz, turns this file from a skip into the pin.
@@ -78,3 +79,42 @@ def test_ransac_arithmetic_matches_opencv(oracle):
     assert np.array_equal(bits(r["hypF"]), bits(D["cv_hypF"])), "two SVDecomp + U diag(D) Vt"
     assert np.array_equal(r["hyp_count"], D["cv_hyp_count"]), "inlier counts"
     assert np.array_equal(bits(r["hyp_sum"]), bits(D["cv_hyp_sum"])), "cv::sum(e_sq) (element order inside cv::sum is build dependent)"
+
+
+def test_grid_extractor_matches_opencv(oracle):
+    """a4: extract_features(Frame&, nrows, ncols), src/Frame.cpp:16-51 — ORB's pyramid, FAST, Harris ranking, retainBest,
+    intensity-centroid angles — and two of its building blocks on their own."""
+    D = _dump()
+    if "cv_g_xy" not in D.files:
+        pytest.skip("PARITY UNPINNED for the grid extractor: the dump predates tools/opencv_dump.cpp's grid block")
+    G2 = np.load(os.path.join(ROOT, "tests", "golden", "frontend_v2_grid.npz"))
+    gray = oracle.bgr2gray(G2["g_bgr"])
+    assert np.array_equal(oracle.fast9_16(gray, 20), D["cv_g_fast20"]), "FAST-9/16 threshold 20 + non-max"
+    assert np.array_equal(oracle.resize_linear_exact(gray, 213, 160), D["cv_g_resized"]), "resize INTER_LINEAR_EXACT"
+    pat_path = os.environ.get("VSLAM_BRIEF_PATTERN")
+    pat = np.fromfile(pat_path, np.int8).reshape(256, 4) if pat_path else G2["g_pattern"]
+    img, xy, desc, ao = oracle.extract_features_grid(G2["g_bgr"], 2, 2, pat)
+    assert np.array_equal(img, D["cv_g_outlined"].reshape(img.shape)), "cv::rectangle outlines"
+    assert np.array_equal(xy, D["cv_g_xy"]), "grid keypoints (positions, order)"
+    assert np.array_equal(bits(ao), bits(D["cv_g_angle_octave"])), "ICAngles / octaves"
+    if pat_path:
+        assert np.array_equal(desc, D["cv_g_desc"]), "steered BRIEF descriptors"
+
+
+def test_pose_helpers_match_opencv(oracle):
+    """8f: extract_Rt and triangulate, src/helpers.cpp:3-80, on the golden pair's F and inlier matches."""
+    D = _dump()
+    if "cv_t_R" not in D.files:
+        pytest.skip("PARITY UNPINNED for the pose helpers: the dump predates tools/opencv_dump.cpp's pose block")
+    if int(D["opencv_have_lapack_macro"][0]):
+        pytest.skip("this OpenCV build routes SVD through LAPACK (see test_ransac_arithmetic_matches_opencv)")
+    case = opencv_case.case_inputs()
+    R, t = oracle.extract_Rt(case["t_F"], case["t_K"])
+    assert np.array_equal(bits(R), bits(D["cv_t_R"])), "extract_Rt: rotation"
+    assert np.array_equal(bits(t), bits(D["cv_t_t"].reshape(-1))), "extract_Rt: translation"
+    c2 = oracle.camera_matrix(case["t_K"], R, t)
+    assert np.array_equal(bits(c2), bits(D["cv_t_c2"])), "K [R | t]"
+    c1 = np.zeros((3, 4), np.float32)
+    c1[:, :3] = case["t_K"]
+    p4 = oracle.triangulate(case["t_p1"], case["t_p2"], c1, c2)
+    assert np.array_equal(bits(p4), bits(D["cv_t_points4d"])), "triangulate: 4x4 DLT SVD per match"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Inputs for / outputs of tools/opencv_dump.cpp (the OpenCV-side vector dumper).
 
-    python tools/opencv_case.py export <case.bin>              the seeded inputs of tests/golden/frontend_v1.npz
+    python tools/opencv_case.py export <case.bin>              the seeded inputs of tests/golden/frontend_v1.npz / _v2_grid.npz
     python tools/opencv_case.py import <dump.bin> <out.npz>    the dumper's output as an npz (commit it as
                                                                tests/golden/opencv_v1.npz; tests/test_opencv_pin.py reads it)
 
@@ -43,7 +43,15 @@ def read_records(path):
 
 def case_inputs():
     G = np.load(os.path.join(ROOT, "tests", "golden", "frontend_v1.npz"))
+    G2 = np.load(os.path.join(ROOT, "tests", "golden", "frontend_v2_grid.npz"))
+    h, w = G["e_bgr"].shape[1:3]
+    # the pose helpers' inputs: the golden pair's fundamental matrix and inlier matches, intrinsics as src/vslam.cpp:29-33
+    K = np.array([[525.0, 0, w / 2.0], [0, 525.0, h / 2.0], [0, 0, 1]], np.float32)
+    pm = G["p_matches"]
     return {
+        "g_bgr": G2["g_bgr"], "g_grid": np.array([2, 2], np.int32),                    # make_golden.py: a 2 x 2 grid
+        "t_F": G["p_F"].reshape(3, 3), "t_K": K,
+        "t_p1": np.ascontiguousarray(G["e_xy0"][pm[:, 0]]), "t_p2": np.ascontiguousarray(G["e_xy1"][pm[:, 1]]),
         "e_bgr": G["e_bgr"], "e_maxc": np.array([150], np.int32),                     # make_golden.py: maxc = 150
         "m_d1": G["m_d1"], "m_d2": G["m_d2"],
         "r_p1": G["r_p1"], "r_p2": G["r_p2"], "r_pairs": G["r_pairs"], "r_fsets": G["r_fsets"],

@@ -1,5 +1,5 @@
-// OpenCV-side vector dumper: the only way the OpenCV-dependent rows of the hot path
-// can ever be pinned.  It runs the reference's own OpenCV calls on the seeded inputs of tests/golden/make_golden.py
+// OpenCV-side vector dumper: the only way the OpenCV-dependent rows of the hot path (SURVEY.md 8 a2, a3, a4, a8,
+// a11-a13, and the 8f pose helpers) can ever be pinned.  It runs the reference's own OpenCV calls on the seeded inputs of tests/golden/make_golden.py
 // and writes what they return, so that tests/test_opencv_pin.py can hold the oracle (and through it the kernels) to
 // real OpenCV output.  NOT part of the product, never built by build(), never shipped to the GPU box; it builds only
 // on a machine that has OpenCV 4 (the reference's dependency, makefile:4,7):
@@ -210,6 +210,98 @@ int main(int argc, char **argv) {
             put("cv_svd3_D", 2, {(uint32_t)H, 3}, allD3.data());
             put("cv_hyp_count", 1, {(uint32_t)H}, allCount.data());
             put("cv_hyp_sum", 2, {(uint32_t)H}, allSum.data());
+        }
+        // ---------------------------------------------------------------- grid ORB/FAST extractor, src/Frame.cpp:16-51
+        if (in.count("g_bgr")) {
+            const Arr &gb = in.at("g_bgr");   // [h][w][3] u8
+            const int gh = (int)gb.dims[0], gw = (int)gb.dims[1];
+            const int nrows = in.at("g_grid").as<int32_t>()[0], ncols = in.at("g_grid").as<int32_t>()[1];
+            cv::Mat image = cv::Mat(gh, gw, CV_8UC3, const_cast<uint8_t *>(gb.as<uint8_t>())).clone();   // the extractor draws into it
+            {   // the pieces the restatement is built from, on the untouched frame
+                cv::Mat gray;
+                cv::cvtColor(image, gray, cv::COLOR_BGR2GRAY);
+                std::vector<cv::KeyPoint> fk;
+                cv::FAST(gray, fk, 20, true);                                                 // FAST-9/16 + 3x3 non-max, as ORB's detector runs it
+                std::vector<float> ff;
+                for (auto &k : fk) { ff.push_back(k.pt.x); ff.push_back(k.pt.y); ff.push_back(k.response); }
+                put("cv_g_fast20", 2, {(uint32_t)fk.size(), 3}, ff.data());
+                cv::Mat small;
+                cv::resize(gray, small, cv::Size(213, 160), 0, 0, cv::INTER_LINEAR_EXACT);     // ORB's pyramid resampling
+                put_mat("cv_g_resized", small);
+            }
+            const int nfeatures = 500;                                                        // :19
+            const int cw = image.cols / ncols, ch = image.rows / nrows;                        // :20
+            cv::Ptr<cv::ORB> det = cv::ORB::create(nfeatures, 1.2f, 8, 31, 0, 2, cv::ORB::HARRIS_SCORE, 31, 20);   // :22
+            cv::Ptr<cv::ORB> fallback = cv::ORB::create(nfeatures, 1.2f, 8, 31, 0, 2, cv::ORB::HARRIS_SCORE, 31, 5);   // :23
+            std::vector<cv::KeyPoint> keypoints;
+            for (int i = 0; i < ncols; i++)
+                for (int j = 0; j < nrows; j++) {                                             // :27-41
+                    std::vector<cv::KeyPoint> temp;
+                    const int sx = i * cw, sy = j * ch;
+                    const cv::Rect rect(sx, sy, cw, ch);
+                    cv::rectangle(image, rect, cv::Scalar(0, 0, 0));                          // :32
+                    det->detect(image(rect), temp);                                           // :33
+                    if (temp.size() < (size_t)nfeatures) fallback->detect(image(rect), temp); // :34-36
+                    for (auto &kp : temp) keypoints.emplace_back(sx + kp.pt.x, sy + kp.pt.y, kp.size, kp.angle, kp.response, kp.octave, kp.class_id);
+                }
+            cv::Mat gdesc;
+            det->compute(image, keypoints, gdesc);                                            // :43
+            std::vector<float> gxy, gao;
+            for (auto &kp : keypoints) {
+                gxy.push_back(kp.pt.x); gxy.push_back(kp.pt.y);
+                gao.push_back(kp.angle); gao.push_back((float)kp.octave);
+            }
+            put_mat("cv_g_outlined", image);
+            put("cv_g_xy", 2, {(uint32_t)keypoints.size(), 2}, gxy.data());
+            put("cv_g_angle_octave", 2, {(uint32_t)keypoints.size(), 2}, gao.data());
+            put_mat("cv_g_desc", gdesc);                                                      // OpenCV's own learned pattern
+        }
+
+        // ---------------------------------------------------------------- pose helpers, src/helpers.cpp:3-80
+        if (in.count("t_F")) {
+            cv::Mat Fm(3, 3, CV_32FC1, const_cast<float *>(in.at("t_F").as<float>()));
+            cv::Mat K(3, 3, CV_32FC1, const_cast<float *>(in.at("t_K").as<float>()));
+            // extract_Rt, :3-35
+            cv::Mat E = K.t() * Fm * K;                                                        // :4
+            cv::Mat U, D, V_t;
+            cv::SVD::compute(E, D, U, V_t);                                                    // :7
+            cv::Mat translation;
+            U.col(2).copyTo(translation);                                                      // :9
+            translation /= cv::norm(translation);                                              // :11
+            cv::Mat W = cv::Mat::zeros(3, 3, CV_32FC1);
+            W.at<float>(0, 1) = -1; W.at<float>(1, 0) = 1; W.at<float>(2, 2) = 1;             // :13-16
+            cv::Mat R_1 = U * W * V_t;                                                         // :18
+            if (cv::determinant(R_1) < 0) R_1 = -R_1;
+            cv::Mat R_2 = U * W.t() * V_t;                                                     // :23
+            if (cv::determinant(R_2) < 0) R_2 = -R_2;
+            cv::Mat rotation = (R_1.at<float>(0, 0) + R_1.at<float>(1, 1) + R_1.at<float>(2, 2) < 0) ? R_2 : R_1;   // :29
+            if (translation.at<float>(2) < 0) translation *= -1;                               // :31-33
+            put_mat("cv_t_E", E);
+            put_mat("cv_t_R", rotation);
+            put_mat("cv_t_t", translation);
+            // camera matrices as the driver forms them (src/vslam.cpp:83-88,125): c1 = K [I | 0], c2 = K [R | t]
+            cv::Mat Rt1 = cv::Mat::eye(3, 4, CV_32FC1), Rt2(3, 4, CV_32FC1);
+            rotation.copyTo(Rt2(cv::Rect(0, 0, 3, 3)));
+            translation.copyTo(Rt2(cv::Rect(3, 0, 1, 3)));
+            cv::Mat c1 = K * Rt1, c2 = K * Rt2;
+            put_mat("cv_t_c2", c2);
+            // triangulate, :37-80
+            const Arr &a1 = in.at("t_p1"), &a2 = in.at("t_p2");
+            const int N = (int)a1.dims[0];
+            const float *p1d = a1.as<float>(), *p2d = a2.as<float>();
+            cv::Mat points_4d(N, 4, CV_32F), A(4, 4, CV_32F);
+            for (int i = 0; i < N; i++) {
+                A.row(0) = p1d[2 * i] * c1.row(2) - c1.row(0);                                 // :50-53
+                A.row(1) = p1d[2 * i + 1] * c1.row(2) - c1.row(1);
+                A.row(2) = p2d[2 * i] * c2.row(2) - c2.row(0);
+                A.row(3) = p2d[2 * i + 1] * c2.row(2) - c2.row(1);
+                cv::Mat U4, D4, Vt4;
+                cv::SVD::compute(A, D4, U4, Vt4, cv::SVD::MODIFY_A | cv::SVD::FULL_UV);        // :60
+                const float *v = Vt4.ptr<float>(3);
+                float *o = points_4d.ptr<float>(i);
+                o[0] = v[0] / v[3]; o[1] = v[1] / v[3]; o[2] = v[2] / v[3]; o[3] = 1;          // :73-76
+            }
+            put_mat("cv_t_points4d", points_4d);
         }
         fclose(g_out);
         printf("wrote %s (OpenCV %s)\n", argv[2], CV_VERSION);
