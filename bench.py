@@ -41,6 +41,7 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
         "bgr2gray_kernel": 2 * (3 * px + px),
         "min_eigen_kernel": 2 * (px + 80 * K),        # gray in; out: candidate keys, about 10 per kept keypoint, 8 B each
                                                       # (the response image itself is not written on this path)
+        "corner_exact_kernel": 2 * (80 * K + (K * 8 // 5) * (25 + 8)),   # the list in; 5x5 gray windows of the ~1.6 K evaluated pixels in, their keys out
         "corner_select_kernel": 2 * (K * 8),
         "gaussian7_kernel": 2 * (px + px),
         "keypoint_border_kernel": 2 * (K * 8 * 2),
