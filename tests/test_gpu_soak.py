@@ -63,3 +63,49 @@ def test_many_pairs_bit_exact(ctx, w, h, K, H, P, seed):
         assert np.array_equal(out["matches"][p, :k], m["matches"]), p
         if m["rc"] == 0:
             assert out["F"][p].tobytes() == m["F"].tobytes(), p
+
+
+def _oracle_pair_frames(args):
+    fa, fb, K, H, s, p = args
+    sys.path.insert(0, HERE)
+    from oracle_lib import Oracle
+    o = Oracle()
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    a = o.extract_features(fa, K, ca, sa, pat)
+    b = o.extract_features(fb, K, ca, sa, pat)
+    return p, a, b, o.match_features(a["xy"], a["desc"], b["xy"], b["desc"], s, H, 10.0)
+
+
+@pytest.mark.parametrize("w,h,K,H,P,seed", [(1280, 720, 2000, 4096, 16, 0x4A2D0001), (640, 480, 1000, 1024, 16, 0x4A2D0002)])
+def test_hard_regime_pairs_bit_exact(ctx, w, h, K, H, P, seed):
+    """The harder data regime of SURVEY.md 8(d) (synth.frames_torch_hard: rotation + parallax, sub-pixel resampling,
+    40-45 % outlier matches — RANSAC has far fewer inliers to go on, the bail-out bounds of the counting kernel are
+    learnt late, and the responses are those of an interpolated image): every output against the oracle on the same
+    bytes (the frames are generated on the device and copied back)."""
+    bgr = synth.frames_torch_hard(seed, P, w, h, "cuda")
+    host = bgr.cpu().numpy()
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    seeds = shard.pair_seeds(seed, 0, P)
+    out = ctx.frontend_pairs(bgr, P, K, ca, sa, torch.from_numpy(pat).cuda(), torch.from_numpy(seeds.view(np.int32)).cuda(), H, 10.0)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    procs = max(1, min(len(os.sched_getaffinity(0)), 12))
+    with mp.get_context("spawn").Pool(procs) as pool:
+        ref = pool.map(_oracle_pair_frames, [(host[p], host[P + p], K, H, int(seeds[p]), p) for p in range(P)])
+    outlier_share = []
+    for p, a, b, m in ref:
+        for f, r in ((p, a), (P + p, b)):
+            n = len(r["xy"])
+            assert out["n"][f] == n, (p, f)
+            assert np.array_equal(out["xy"][f, :n], r["xy"]), (p, f)
+            assert np.array_equal(out["desc"][f, :n], r["desc"]), (p, f)
+            assert np.array_equal(out["nodes"][f, :n], r["nodes"]), (p, f)
+        k = len(m["matches"])
+        assert out["best"][p, 3] == k, p
+        assert np.array_equal(out["matches"][p, :k], m["matches"]), p
+        if m["rc"] == 0:
+            assert out["F"][p].tobytes() == m["F"].tobytes(), p
+        outlier_share.append(1.0 - k / max(m["prelim"], 1))
+    assert np.mean(outlier_share) > 0.25, outlier_share     # the regime really is the harder one
