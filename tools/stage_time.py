@@ -11,7 +11,7 @@ from vslam_amd import Context, synth  # noqa: E402
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "good_features"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    w, h, K, P = 1280, 720, 2000, 256
+    w, h, K, P = 1280, 720, 2000, int(sys.argv[3]) if len(sys.argv) > 3 else 256
     ctx = Context(0)
     bgr = synth.frames_torch(0x5EED0002, P, w, h, "cuda")
     gray = ctx.bgr2gray(bgr)

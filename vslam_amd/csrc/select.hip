@@ -374,34 +374,56 @@ struct DiscTable {
     int n;                 // 0: no table (R == 0 or R > 7); padded to a multiple of 4 with entries that repeat e[0]
     int e[kDiscMax + 3];
 };
+// The kernel's copy in LDS: read from the kernel-argument segment inside the probing loop, every group of four
+// offsets was a scalar load the wave had to wait for — 8 k cycles per trip, 62 of the workgroup's 115 us.
+struct DiscLds {
+    int n;
+    int e[kDiscMax + 3];
+};
+
+// A 64 Kbit presence filter over the window's pixel offsets (one hash, set at insertion): most of the disc's positions
+// hold no window entry, and asking the table about each of them made a wave walk, for every position, the longest
+// probe chain among its 64 lanes (two dependent LDS reads per step): 62 of the workgroup's 115 us.  With the filter a
+// lane probes the table only for the positions whose bit is set — its real neighbours and 4 % false positives.
+constexpr int kFiltWords = 2048;
+__device__ __forceinline__ uint32_t filt_hash(uint32_t q) { return (q * 0x9E3779B1u) >> 16; }
 
 __device__ __forceinline__ int nms_collect_disc(const uint32_t *offs, const uint32_t *slot32, uint32_t smask, int hshift,
-                                                int w, int h, uint32_t i, const DiscTable &disc,
+                                                const uint32_t *filt, int w, int h, uint32_t i, const DiscLds &disc,
                                                 unsigned long long &packed) {
     const uint32_t off = offs[i] & kOffMask;
     const int y = off / w, x = off - y * w;
     int cnt = 0;
     packed = ~0ull;
-    for (int e0 = 0; e0 < disc.n; e0 += 4) {
-        uint32_t q[4], hs[4], r[4];
-        bool in[4];
+    for (int c0 = 0; c0 < disc.n; c0 += 32) {   // 32 positions at a time: their filter bits first (independent reads)
+        uint32_t hit = 0;
+        const int ce = min(32, disc.n - c0);
+        for (int e0 = 0; e0 < ce; e0 += 4) {
+            uint32_t fw[4], fb[4];
+            bool in[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int pk = disc.e[e0 + u];
-            const int dy = pk >> 16, dx = (int)(int16_t)(pk & 0xFFFF);
-            const int yy = y + dy, xx = x + dx;
-            in[u] = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && e0 + u < disc.n;
-            q[u] = (uint32_t)(yy * w + xx);
-            hs[u] = slot_hash(q[u], hshift);
+            for (int u = 0; u < 4; u++) {
+                const int pk = disc.e[c0 + e0 + u];
+                const int dy = pk >> 16, dx = (int)(int16_t)(pk & 0xFFFF);
+                const int yy = y + dy, xx = x + dx;
+                in[u] = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && e0 + u < ce;
+                fb[u] = filt_hash((uint32_t)(yy * w + xx));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) fw[u] = filt[fb[u] >> 5];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (in[u] && ((fw[u] >> (fb[u] & 31u)) & 1u)) hit |= 1u << (e0 + u);
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) r[u] = (slot32[hs[u] >> 1] >> ((hs[u] & 1u) * 16)) & 0xFFFFu;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (!in[u]) continue;
-            uint32_t rr = r[u], hh = hs[u];
-            while (rr != 0xFFFFu) {   // empty on the first probe for almost every position
-                if ((offs[rr] & kOffMask) == q[u]) {
+        while (hit) {   // the table, for the few positions that may hold an entry (ascending position order)
+            const int e = __ffs(hit) - 1;
+            hit &= hit - 1u;
+            const int pk = disc.e[c0 + e];
+            const uint32_t q = (uint32_t)((y + (pk >> 16)) * w + x + (int)(int16_t)(pk & 0xFFFF));
+            uint32_t hh = slot_hash(q, hshift);
+            uint32_t rr = (slot32[hh >> 1] >> ((hh & 1u) * 16)) & 0xFFFFu;
+            while (rr != 0xFFFFu) {
+                if ((offs[rr] & kOffMask) == q) {
                     if (rr < i) {
                         if (cnt < 4) packed = (packed & ~(0xFFFFull << (16 * cnt))) | ((unsigned long long)rr << (16 * cnt));
                         cnt++;
@@ -469,6 +491,10 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(smem_raw);
     __shared__ SelectShared sh;
+    __shared__ DiscLds sdisc;
+    __shared__ uint32_t sfilt[kFiltWords];
+    for (int i = threadIdx.x; i < kDiscMax + 3; i += kST) sdisc.e[i] = disc.e[i];
+    if (threadIdx.x == 0) sdisc.n = disc.n;   // (the first barrier below orders these)
 
     const int f = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -565,12 +591,15 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
                 __syncthreads();
                 for (int i = tid; i < sort_cap; i += kST) slot32[i] = 0xFFFFFFFFu;
+                for (int i = tid; i < kFiltWords; i += kST) sfilt[i] = 0u;
                 __syncthreads();
                 uint32_t pend = 0;   // bit k: window entry tid + k * kST is undecided (sort_cap <= 16 * kST)
                 {
                     int k = 0;
                     for (uint32_t i = tid; i < got; i += kST, k++) {
                         slot_insert(slot32, smask, hshift, offs[i], i);
+                        const uint32_t fb = filt_hash(offs[i]);
+                        atomicOr(&sfilt[fb >> 5], 1u << (fb & 31u));
                         pend |= 1u << k;
                     }
                 }
@@ -586,7 +615,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                         uint2 ranks;
                         if (disc.n) {
                             unsigned long long packed;
-                            cnt = nms_collect_disc(offs, slot32, smask, hshift, w, h, i, disc, packed);
+                            cnt = nms_collect_disc(offs, slot32, smask, hshift, sfilt, w, h, i, sdisc, packed);
                             ranks = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
                         } else {
                             uint32_t list[4];
