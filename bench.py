@@ -60,6 +60,7 @@ def algorithmic_bytes(kernel, w, h, K, H, M):
         "ransac_ties_kernel": H * 4 + H * 4,
         "ransac_tiesum_kernel": M * 24 + 36 + 4,          # per tied hypothesis; at least one per pair
         "ransac_select_kernel": H * 8 + M * 24 + M + M * 8 + 36,
+        "ransac_finish_kernel": (H * 4 + H * 4) + (M * 24 + 36 + 4) + (H * 8 + M * 24 + M + M * 8 + 36),   # ties + one tie sum + select
     }
     return table.get(kernel, 0)
 

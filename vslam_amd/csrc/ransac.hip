@@ -1808,11 +1808,11 @@ __global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(
 // ransac_tiesum_kernel.  Hypotheses with an uncertified cheap sum carry err = inf and always stay.
 // tie_n[2b] = list length, tie_n[2b+1] = C*.  One workgroup per pair.
 constexpr int kTieThreads = 256;
-__global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t *__restrict__ m_arr, int min_m, int hyp,
-                                                                  int32_t *__restrict__ hyp_count,
-                                                                  const float *__restrict__ approx, float *__restrict__ hyp_sum,
-                                                                  int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n) {
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void ransac_ties_body(const int b, const int32_t *__restrict__ m_arr, int min_m, int hyp,
+                                                 int32_t *__restrict__ hyp_count,
+                                                 const float *__restrict__ approx, float *__restrict__ hyp_sum,
+                                                 int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_w[kTieThreads / 64];
     __shared__ float s_f[kTieThreads / 64];
     __shared__ int s_base;
@@ -1882,6 +1882,12 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
         tie_n[2 * b + 1] = mx;
     }
 }
+__global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t *__restrict__ m_arr, int min_m, int hyp,
+                                                                  int32_t *__restrict__ hyp_count,
+                                                                  const float *__restrict__ approx, float *__restrict__ hyp_sum,
+                                                                  int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n) {
+    ransac_ties_body(blockIdx.x, m_arr, min_m, hyp, hyp_count, approx, hyp_sum, tie_idx, tie_n);
+}
 
 // The exact residual sum (sequential double accumulation in match order, then one rounding to float: the value
 // RansacFilter.cpp:138 returns) for the hypotheses in the tie list.  grid = (kTieGrid, batch), one wave each, looping over
@@ -1891,11 +1897,19 @@ __global__ __launch_bounds__(kTieThreads) void ransac_ties_kernel(const int32_t 
 //   many ties: a lane per tied hypothesis walking all matches (the shape of ransac_score_kernel), 64 per wave.
 constexpr int kTieLaneMode = 192;
 constexpr int kTieGrid = 4;
-__global__ __launch_bounds__(64) void ransac_tiesum_kernel(
+// WAVE_ONLY: the caller is one wave of a larger workgroup (ransac_finish_kernel): `slot` of `nslots` is that wave, and the
+// LDS hand-overs below are inside the wave, where program order is enough (no workgroup barrier: the waves run different
+// numbers of trips).
+template <bool WAVE_ONLY>
+__device__ __forceinline__ void ransac_tiesum_body(
+    const int b, const int slot, const int nslots, const int lane, float *s_e, float4 *sc,
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, const float *__restrict__ hypF,
     const int32_t *__restrict__ tie_idx, const int32_t *__restrict__ tie_n, float *__restrict__ hyp_sum) {
-    const int b = blockIdx.y, lane = threadIdx.x;
+    auto sync = [&]() {
+        if (WAVE_ONLY) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    };
     const int m = min(m_arr[b], kp_stride);
     if (m < min_m) return;
     const int T = tie_n[2 * b];
@@ -1905,8 +1919,7 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
     const int2 *PR = reinterpret_cast<const int2 *>(pairs) + (size_t)b * kp_stride;
 
     if (T >= kTieLaneMode) {
-        __shared__ float4 sc[64];
-        for (int blk = blockIdx.x; blk * 64 < T; blk += gridDim.x) {
+        for (int blk = slot; blk * 64 < T; blk += nslots) {
             const int k = blk * 64 + lane;
             const int h = TI[min(k, T - 1)];
             ResidualF R;
@@ -1918,9 +1931,9 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
             for (int i0 = 0; i0 < m; i0 += 64) {   // 64 matches staged by the wave, then walked in order as broadcasts
                 const int2 pr = PR[min(i0 + lane, m - 1)];
                 const float2 a = P1[pr.x], c = P2[pr.y];
-                __syncthreads();
+                sync();
                 sc[lane] = make_float4(a.x, a.y, c.x, c.y);
-                __syncthreads();
+                sync();
                 const int cnt = min(64, m - i0);
                 for (int t = 0; t < cnt; t++) {
                     const float4 v = sc[t];
@@ -1931,15 +1944,15 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
         }
         return;
     }
-    extern __shared__ __align__(16) float s_e[];   // kp_stride floats: every e of the hypothesis, then summed in order
-    for (int k = blockIdx.x; k < T; k += gridDim.x) {
+    // s_e: kp_stride floats: every e of the hypothesis, then summed in order
+    for (int k = slot; k < T; k += nslots) {
         const int h = TI[k];
         ResidualF R;
         const float *src = hypF + ((size_t)b * hyp + h) * 9;
 #pragma unroll
         for (int j = 0; j < 9; j++) R.f[j] = src[j];
         residual_prepare(R);
-        __syncthreads();   // one wave: the previous hypothesis' reads are done
+        sync();   // one wave: the previous hypothesis' reads are done
         // every e first, four matches per lane and round so that their gathers are in flight together ...
         for (int i0 = 0; i0 < m; i0 += 256) {
             int2 pr[4];
@@ -1958,7 +1971,7 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
                 if (i < m) s_e[i] = e;
             }
         }
-        __syncthreads();
+        sync();
         // ... then the sum, in match order (every lane walks the same broadcast reads and computes the same total);
         // sixteen values are fetched ahead of the dependent additions
         double total = 0;
@@ -1978,6 +1991,16 @@ __global__ __launch_bounds__(64) void ransac_tiesum_kernel(
         for (; t < m; t++) total += (double)s_e[t];
         if (lane == 0) hyp_sum[(size_t)b * hyp + h] = (float)total;
     }
+}
+
+__global__ __launch_bounds__(64) void ransac_tiesum_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, const float *__restrict__ hypF,
+    const int32_t *__restrict__ tie_idx, const int32_t *__restrict__ tie_n, float *__restrict__ hyp_sum) {
+    extern __shared__ __align__(16) float s_e_dyn[];
+    __shared__ float4 sc[64];
+    ransac_tiesum_body<false>(blockIdx.y, blockIdx.x, gridDim.x, threadIdx.x, s_e_dyn, sc, xy1, xy2, pairs, m_arr, min_m, kp_stride,
+                              hyp, hypF, tie_idx, tie_n, hyp_sum);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2006,13 +2029,13 @@ __device__ __forceinline__ uint32_t float_order(float f) {
 //   C* > 0 and sum[i0] is NaN      -> winner i0 (a NaN best_sum is never beaten at equal count)
 //   otherwise                      -> first index among {count == C*, sum not NaN} with maximal sum
 //                                     (for C* == 0 only if that sum > 0.0f, else nothing accepted)
-__global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
-    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+__device__ __forceinline__ void ransac_select_body(
+    const int b, const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
     const float *__restrict__ hypF, const int32_t *__restrict__ hyp_count,
     const float *__restrict__ hyp_sum, float *__restrict__ F_out, uint8_t *__restrict__ mask,
     int32_t *__restrict__ best, int32_t *__restrict__ matches) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = m_arr[b];
     __shared__ unsigned long long s_key[kSelThreads / 64];
@@ -2116,6 +2139,39 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
         BO[2] = __float_as_int(win_sum);
         BO[3] = s_base;
     }
+}
+__global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
+    const float *__restrict__ hypF, const int32_t *__restrict__ hyp_count,
+    const float *__restrict__ hyp_sum, float *__restrict__ F_out, uint8_t *__restrict__ mask,
+    int32_t *__restrict__ best, int32_t *__restrict__ matches) {
+    ransac_select_body(blockIdx.x, xy1, xy2, pairs, m_arr, min_m, kp_stride, hyp, threshold, hypF, hyp_count, hyp_sum, F_out, mask,
+                       best, matches);
+}
+
+// The three closing stages of the counting path in one launch, one workgroup per pair: which maximum-count hypotheses
+// need their exact sum (ransac_ties_kernel), those sums (ransac_tiesum_kernel: the workgroup's four waves are its four
+// slots), the accept rule and the winner's mask (ransac_select_kernel).  Each stage reads what the one before left in
+// memory; they are separated by workgroup barriers, which order a workgroup's own global writes.  Saves two dependent
+// launches per step (each mostly dispatch and drain at one workgroup per pair).
+static_assert(kTieThreads == kSelThreads && kTieThreads == 64 * kTieGrid, "one shape for the fused closing kernel");
+__global__ __launch_bounds__(kSelThreads) void ransac_finish_kernel(
+    const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
+    const float *__restrict__ hypF, int32_t *__restrict__ hyp_count, const float *__restrict__ approx,
+    float *__restrict__ hyp_sum, int32_t *__restrict__ tie_idx, int32_t *__restrict__ tie_n, float *__restrict__ F_out,
+    uint8_t *__restrict__ mask, int32_t *__restrict__ best, int32_t *__restrict__ matches) {
+    extern __shared__ __align__(16) float s_e_all[];   // kTieGrid x kp_stride floats
+    __shared__ float4 sc_all[kTieGrid][64];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ransac_ties_body(b, m_arr, min_m, hyp, hyp_count, approx, hyp_sum, tie_idx, tie_n);
+    __syncthreads();
+    ransac_tiesum_body<true>(b, wave, kTieGrid, lane, s_e_all + (size_t)wave * kp_stride, sc_all[wave], xy1, xy2, pairs, m_arr, min_m,
+                             kp_stride, hyp, hypF, tie_idx, tie_n, hyp_sum);
+    __syncthreads();
+    ransac_select_body(b, xy1, xy2, pairs, m_arr, min_m, kp_stride, hyp, threshold, hypF, hyp_count, hyp_sum, F_out, mask, best,
+                       matches);
 }
 
 }  // namespace
@@ -2237,6 +2293,22 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
             else
                 ransac_count_kernel<false><<<grid, 64 * kCntWaves, dyn, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0,
                                                                                        cmax, hyp_count, hyp_sum, approx, cbound);
+        }
+        // the closing stages: one launch when the four waves' sum buffers fit LDS (kp_stride <= 4096), else three
+        const size_t fin_lds = sizeof(float) * (size_t)kTieGrid * kp_stride;
+        static const bool split_finish = getenv("VSLAM_RANSAC_SPLIT_FINISH") != nullptr;   // A/B timing
+        if (fin_lds <= 64 * 1024 && !split_finish) {
+            VsProfScope ps(ctx, "ransac_finish_kernel");
+            if (fin_lds > 32 * 1024 && !ctx->attr_done["ransac_finish"]) {
+                VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_finish_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                ctx->attr_done["ransac_finish"] = true;
+            }
+            ransac_finish_kernel<<<batch, kSelThreads, fin_lds, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, hyp, threshold, hypF,
+                                                                              hyp_count, approx, hyp_sum, tie_idx, tie_n, F, mask, best,
+                                                                              matches);
+            VS_HIP(ctx, hipGetLastError());
+            return VSLAM_OK;
         }
         {
             VsProfScope ps(ctx, "ransac_ties_kernel");
