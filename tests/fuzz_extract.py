@@ -67,6 +67,8 @@ def run(ctx, o, seed, cases=None, seconds=None):
                 rd, keep = o.orb_describe(bl[f], pts[f], ca, sa, pat)
                 assert no[f] == len(keep) and np.array_equal(de[f, :len(keep)], rd), ("descriptors", w, h, f)
         done += 1
+        if seconds is not None and done % 100 == 0:   # a long run says so as it goes
+            print("fuzz_extract: %d cases ok, %.0f s" % (done, time.time() - t0), flush=True)
     return done
 
 

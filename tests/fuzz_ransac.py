@@ -73,6 +73,8 @@ def run(ctx, o, seed, cases=None, seconds=None):
                 assert np.array_equal(bits(out["F"][b]), bits(ref["F"])), ("F",) + tag
                 assert np.array_equal(out["mask"][b, :n], ref["mask"]), ("mask",) + tag
         done += 1
+        if seconds is not None and done % 200 == 0:   # a long run says so as it goes
+            print("fuzz_ransac: %d cases ok" % done, flush=True)
     ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
     return done
 
