@@ -1,13 +1,22 @@
 // Frame ingest + result records on top of the C ABI (include/vslam/Ingest.h).
 //
-// run_sequence keeps three things busy at once: a reader thread fills one page-locked buffer from the file
-// while the copy stream uploads the other and the compute stream works on the batch before it.
+// run_sequence keeps three things busy at once: a reader (a few threads, each pread()ing its share of the batch's
+// frames: one thread copies about 10 GB/s out of the page cache, a third of what the upload can take) fills one
+// page-locked buffer from the file while the copy stream uploads the other and the compute stream works on the batch
+// before it.
 // Batch k holds frames [k * (B - 1), k * (B - 1) + B): consecutive batches share one frame, so every
 // consecutive pair is computed exactly once and no feature has to survive a batch (re-extracting the shared
 // frame costs 1 / B of the extraction).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -133,16 +142,23 @@ bool RecordReader::next(PairRecord &r) {
 SequenceStats run_sequence(const std::string &video_path, const std::string &record_path, const SequenceOptions &o) {
     if (o.width <= 0 || o.height <= 0 || o.batch_frames < 2 || o.max_corners <= 0 || o.hypotheses <= 0)
         throw std::invalid_argument("run_sequence: bad options");
-    std::FILE *in = std::fopen(video_path.c_str(), "rb");
-    if (!in) throw std::runtime_error("run_sequence: cannot open " + video_path);
+    const int in = ::open(video_path.c_str(), O_RDONLY);
+    if (in < 0) throw std::runtime_error("run_sequence: cannot open " + video_path);
     struct Closer {
-        std::FILE *f;
-        ~Closer() { std::fclose(f); }
+        int fd;
+        ~Closer() { ::close(fd); }
     } closer{in};
+    struct stat st;
+    if (::fstat(in, &st) != 0) throw std::runtime_error("run_sequence: cannot stat " + video_path);
 
     vslam_ctx *ctx = detail::context();
     const int B = o.batch_frames, K = o.max_corners;
     const size_t frame_bytes = (size_t)o.width * o.height * 3;
+    uint64_t file_frames = (uint64_t)st.st_size / frame_bytes;   // a trailing partial frame is dropped
+    if (o.max_frames && file_frames > o.max_frames) file_frames = o.max_frames;
+    int readers = o.reader_threads;
+    if (const char *e = std::getenv("VSLAM_READER_THREADS")) readers = std::atoi(e);   // tuning
+    readers = readers < 1 ? 1 : (readers > 16 ? 16 : readers);
     Pinned hbuf0(frame_bytes * B), hbuf1(frame_bytes * B);
     uint8_t *hbuf[2] = {hbuf0.p, hbuf1.p};
     Dev<uint8_t> dbuf0(frame_bytes * B), dbuf1(frame_bytes * B);
@@ -186,11 +202,32 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
                     std::memcpy(hbuf[b], hbuf[b ^ 1] + frame_bytes * (size_t)(B - 1), frame_bytes);
                     have = 1;
                 }
-                while (have < B && (o.max_frames == 0 || read_total < o.max_frames)) {
-                    const size_t r = std::fread(hbuf[b] + frame_bytes * (size_t)have, 1, frame_bytes, in);
-                    if (r != frame_bytes) break;   // end of file (a trailing partial frame is dropped)
-                    have++;
-                    read_total++;
+                {   // frames read_total .. of the file -> slots have .. of the buffer, shared out over the reader threads
+                    const uint64_t left = file_frames - read_total;
+                    const int want = (int)std::min<uint64_t>((uint64_t)(B - have), left);
+                    std::atomic<bool> failed{false};
+                    auto share = [&](int t) {
+                        for (int j = t; j < want; j += readers) {
+                            uint8_t *dst = hbuf[b] + frame_bytes * (size_t)(have + j);
+                            size_t got = 0;
+                            const off_t at = (off_t)((read_total + (uint64_t)j) * frame_bytes);
+                            while (got < frame_bytes) {
+                                const ssize_t r = ::pread(in, dst + got, frame_bytes - got, at + (off_t)got);
+                                if (r <= 0) {
+                                    failed = true;
+                                    return;
+                                }
+                                got += (size_t)r;
+                            }
+                        }
+                    };
+                    std::vector<std::thread> pool;
+                    for (int t = 1; t < readers && t < want; t++) pool.emplace_back(share, t);
+                    share(0);
+                    for (auto &th : pool) th.join();
+                    if (failed) throw std::runtime_error("read failed (file truncated while in use?)");
+                    have += want;
+                    read_total += (uint64_t)want;
                 }
                 const bool last = have < B;
                 {
