@@ -12,8 +12,9 @@ for r in rows:
     if m and "at::" not in r["Kernel_Name"] and "pmc_calib" not in r["Kernel_Name"]:
         ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], m.group(1)))
 ks.sort()
-idx = [i for i, k in enumerate(ks) if k[3] == "bgr2gray_kernel"]
-s, e = idx[-2], idx[-1]
+# a step starts at the first bgr2gray after a closing RANSAC kernel (the conversion may come in several pieces)
+starts = [i for i, k in enumerate(ks) if k[3] == "bgr2gray_kernel" and (i == 0 or not ks[i - 1][3].startswith(("bgr2gray", "gaussian7", "rbrief_rotate", "ransac_mt")))]
+s, e = starts[-2], starts[-1]
 t0 = ks[s][0]
 for st, en, q, name in ks[s:e + 1]:
     print("%-28s q%s  %8.1f -> %8.1f  (%7.1f)" % (name, q, (st - t0) / 1e3, (en - t0) / 1e3, (en - st) / 1e3))
