@@ -466,17 +466,14 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     if (d_n_detected) n_det = d_n_detected;
     else if ((rc = vs_arena_get(ctx, "extract.n_det", sizeof(int32_t) * (size_t)frames, (void **)&n_det))) return rc;
 
-    if ((rc = vs_launch_bgr2gray(ctx, d_bgr, frames, width, height, row_stride, gray))) return rc;      // :56
+    // cvtColor (:56) is the detector's first kernel (or a launch of its own in front of it, for layouts that one does not take).
     // The blur needs only the gray image: run it on the auxiliary stream beside corner detection, whose
     // selection stage is latency-bound and leaves most of the chip idle (not while per-kernel timing is on).
     const bool overlap = ctx->overlap_blur > 0 && !ctx->prof;
-    if (overlap && ctx->overlap_blur == 1) {
-        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-    }
-    ctx->fork_after_eigen = overlap && ctx->overlap_blur == 2;
-    rc = vs_launch_good_features(ctx, gray, frames, width, height, params->max_corners,                  // :61
-                                 params->quality, params->min_distance, kp_stride, xy_det, n_det);
+    const VsBgrSource src{d_bgr, row_stride};
+    ctx->fork_after_eigen = overlap;
+    rc = vs_launch_good_features(ctx, gray, frames, width, height, params->max_corners,                  // :56, :61
+                                 params->quality, params->min_distance, kp_stride, xy_det, n_det, &src);
     ctx->fork_after_eigen = false;
     if (rc) return rc;
     {

@@ -38,7 +38,7 @@ struct vslam_ctx {
     hipEvent_t ev_raw = nullptr;
     const uint32_t *raw_seeds = nullptr;
     int raw_batch = 0, raw_hyp = 0;
-    int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, 1 fork after bgr2gray, 2 fork after min_eigen
+    int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, otherwise on the auxiliary stream from min_eigen (where the gray image is complete) on
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     bool rbrief_table_ready = false; // transient: the rotated rBRIEF table of the coming describe call is already queued
     int ransac_min_matches = VSLAM_SET_SIZE;   // VSLAM_OPT_RANSAC_MIN_MATCHES
@@ -173,15 +173,22 @@ struct VsCornerCounters {
     uint32_t *hist;      // two-tier detector: the listed upper bounds by magnitude
 };
 size_t vs_response_hist_words(int frames);
+// `gray` still to be formed from a 3-byte image (cvtColor is then the detector's job: fused into its first kernel when
+// the layout allows, a launch of its own otherwise)
+struct VsBgrSource {
+    const uint8_t *data;
+    int stride;   // bytes per row
+};
 int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, double quality,
                                   float *eig, const VsCornerCounters &c, unsigned long long *keys,
-                                  unsigned long long *keys2, size_t key_cap, uint32_t n_safe, int *raw_list);
+                                  unsigned long long *keys2, size_t key_cap, uint32_t n_safe, int *raw_list,
+                                  const VsBgrSource *bgr = nullptr);
 int vs_launch_corner_exact(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, const VsCornerCounters &c,
                            const unsigned long long *keys, unsigned long long *keys2, size_t key_cap, uint32_t n_safe,
                            int mode);
 int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h,
                             int max_corners, double quality, double min_distance, int kp_stride,
-                            float *xy, int32_t *n);
+                            float *xy, int32_t *n, const VsBgrSource *bgr = nullptr);
 int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, uint8_t *out);
 int vs_launch_rbrief_rotate(vslam_ctx *ctx, const int8_t *pattern, float ca, float sa);
 int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, int w, int h,

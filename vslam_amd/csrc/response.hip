@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__rest
 // for the maximum: they queue when U~ + 2 mw reaches the best certified lower bound of the maximum.
 // Keys, the frame maximum and their consumers (corner_select_kernel) are unchanged; no key carries a strip flag.
 constexpr int kSW = 256;     // pixels per strip (64 lanes x 4), all owned
+constexpr int kTierMaxSteps = 144;   // rows a wave visits: at most 134 + 6 (vs_stream_segments)
 constexpr int kTQ1 = 576;    // possible pixels staged per wave for its next global append (at most 63 left over + 2 rows of 256)
 constexpr float kTierSqrt = 0.032f, kTierLin = 80.f / 16777216.f, kTierAbs = 0.004f;   // 2 m(tr) + comparison roundings
 constexpr float kTierC0Up = 5.3398290e-8f;   // c0 = 0.5 / 3060^2 = 5.33982656e-8, rounded up by 2^-21 and more
@@ -304,13 +305,22 @@ __device__ __forceinline__ uint32_t tier_bin_edge(uint32_t bin) {   // smallest 
     return bin == 0u ? 0u : (0x80000000u | ((bin + (uint32_t)kTierBin0) << 20));
 }
 
+// cvtColor(BGR2GRAY) of one pixel (bytes B, G, R, x of px; gray.hip has the plain form): twice the weighted sum, so that
+// the gray value (sum >> 15) is byte 2 of the result — where v_cvt_f32_ubyte2 picks it up — and with the weights split
+// into high and low bytes so that two v_dot4_u32_u8 form it: 2 * (3735, 19235, 9798) = 256 * (29, 150, 76) + (46, 70, 140),
+// 2 * 2^14 = 256 * 128.  At most 255 * 65536 + 32768 < 2^24: byte 3 stays zero.
+__device__ __forceinline__ uint32_t gray_x2_16(uint32_t px) {
+    constexpr uint32_t kHi = 29u | (150u << 8) | (76u << 16), kLo = 46u | (70u << 8) | (140u << 16);
+    return __builtin_amdgcn_udot4(px, kLo, __builtin_amdgcn_udot4(px, kHi, 128u, false) << 8, false);
+}
+
 // Every ring has two slots (index t & 1): a value of row t - 2 is read, at the latest, while row t's is formed.
 struct TierState {
     float hx[2][6], q[2][6], rs[2][6];   // per gray row: x-derivative parts, their two-row sums, smoothed values (columns x-1 .. x+4)
     float T[12], X[2][12];               // horizontal 3-sums of xx, xy, yy (see StreamState), integers in f32
     float ctr[2][4], hm[2][4];           // per response row: U~ and its horizontal 3-maxima
     float lf[2], rg[2], trm[2];          // U~ of the lane to the left / right, largest tr of the row's six columns
-    uint32_t raw[2][3];                  // gray dwords (x-4, x, x+4) of the next two rows
+    uint32_t raw[2][3];                  // gray dwords (x-4, x, x+4) of the next two rows; BGR input: the lane's 12 bytes
     float lanelow;                       // certified lower bound of the best response of this lane's pixels (U units)
 };
 
@@ -322,6 +332,9 @@ struct TierArgs {
     uint32_t *count;
     size_t cap;
     int w, h, ys, ye, x, steps;
+    int bstride;                     // BGR input: bytes per row of src
+    uint8_t *gout;                   // BGR input: this frame's gray image (written for the rows [ys, ye))
+    const uint2 *halo;               // BGR input, LDS: per row of the wave's segment the gray pixels left / right of the strip
     uint32_t voff_l, voff_c, voff_r;
     bool edge, left_fix, right_fix, own_lane;
     unsigned long long cand_ok[4];   // lanes whose pixel i is an owned candidate position (1 <= x < w - 1)
@@ -341,6 +354,7 @@ __device__ __forceinline__ void tier_tighten(TierArgs &a, float lanelow, int lan
     float low = a.own_lane ? lanelow : ninf;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) low = fmaxf(low, __shfl_xor(low, off, 64));
+    low = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(low)));   // the wave's bounds live in scalar registers
     if (low > a.lowU) {
         a.lowU = low;
         a.thrU = low > 0.f ? low * a.qf : ninf;
@@ -364,29 +378,67 @@ __device__ __forceinline__ void tier_flush(TierArgs &a, int lane) {
     a.qn = 0;
 }
 
-template <int P>   // P = t % 2
+template <int P, bool BGR>   // P = t % 2; BGR: src is the 3-byte image and the gray rows are formed (and written) here
 __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int lane) {
     constexpr int Q = P ^ 1;
     uint32_t d0 = st.raw[P][0];
-    const uint32_t d1 = st.raw[P][1];
+    uint32_t d1 = st.raw[P][1];
     uint32_t d2 = st.raw[P][2];
-    {   // prefetch two rows ahead into the slot just consumed (see stream_step)
-        const int tn = t + 2 < a.steps ? t + 2 : a.steps - 1;
-        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.w;
-        uint32_t ol = a.voff_l, oc = a.voff_c, orr = a.voff_r;
-        asm volatile("" : "+v"(ol), "+v"(oc), "+v"(orr));
-        st.raw[P][0] = *reinterpret_cast<const uint32_t *>(rowp + ol);
-        st.raw[P][1] = *reinterpret_cast<const uint32_t *>(rowp + oc);
-        st.raw[P][2] = *reinterpret_cast<const uint32_t *>(rowp + orr);
+    float g[8];
+    if constexpr (BGR) {
+        // the lane's 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint32_t u0 = gray_x2_16(d0), u1 = gray_x2_16(__builtin_amdgcn_alignbyte(d1, d0, 3)),
+                       u2 = gray_x2_16(__builtin_amdgcn_alignbyte(d2, d1, 2)), u3 = gray_x2_16(d2 >> 8);
+        {   // Prefetch two rows ahead into the slot just consumed — "consumed" made a fact for the compiler by letting the
+            // addresses depend on the values formed from the old contents: with the loads in front of their last use
+            // (where its scheduler likes them) old and new contents are alive together, the new ones get registers of their
+            // own, and the copy into the slot's at the end of the iteration waits for every load in flight.
+            const int tn = t + 2 < a.steps ? t + 2 : a.steps - 1;
+            const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.bstride;
+            uint32_t oc = a.voff_c;
+            asm volatile("" : "+v"(oc) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+            const uint32_t *vp = reinterpret_cast<const uint32_t *>(rowp + oc);
+            st.raw[P][0] = vp[0];
+            st.raw[P][1] = vp[1];
+            st.raw[P][2] = vp[2];
+        }
+        g[2] = cvt_ubyte<2>(u0); g[3] = cvt_ubyte<2>(u1); g[4] = cvt_ubyte<2>(u2); g[5] = cvt_ubyte<2>(u3);
+        const uint32_t p01 = __builtin_amdgcn_perm(u1, u0, 0x0c0c0602u);
+        d1 = __builtin_amdgcn_perm(u3, __builtin_amdgcn_perm(u2, p01, 0x0c060100u), 0x06020100u);   // the lane's four gray bytes
+        const int gy = a.ys - 3 + t;
+        if (gy >= a.ys && gy < a.ye && a.own_lane) {
+            // Written as an instruction of its own, not as a C++ store: loads and stores share one counter on this chip
+            // and the compiler, which has to assume that they complete out of order relative to each other, would wait for
+            // EVERYTHING in flight (vmcnt(0): the next row's prefetch and this store's acknowledgement) in front of every row.
+            // Unseen by it, the store only makes its waits for the loads longer than they need to be, never too short.
+            const uint8_t *rowp = a.gout + (size_t)gy * a.w;
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(a.x), "v"(d1), "s"(rowp) : "memory");
+        }
+        // the neighbours' bytes; beyond the strip: the two pixels left of it (bytes 2, 3 of the dword a lane 0 wants) and the
+        // two right of it (bytes 0, 1), converted when the wave started
+        const uint2 hv = a.halo[t];
+        const uint32_t gl = hv.x, gr = hv.y;
+        d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)gl, (int)d1, 0x138, 0xf, 0xf, false);   // lane i <- lane i - 1
+        d2 = (uint32_t)__builtin_amdgcn_update_dpp((int)gr, (int)d1, 0x130, 0xf, 0xf, false);   // lane i <- lane i + 1
     }
     if (a.edge) {
         if (a.left_fix) d0 = (d1 & 0x00FF0000u) | ((d1 & 0x0000FF00u) << 16);
         if (a.right_fix) d2 = ((d1 >> 16) & 0xFFu) | (d1 & 0xFF00u);
     }
-    float g[8];
     g[0] = cvt_ubyte<2>(d0); g[1] = cvt_ubyte<3>(d0);
-    g[2] = cvt_ubyte<0>(d1); g[3] = cvt_ubyte<1>(d1); g[4] = cvt_ubyte<2>(d1); g[5] = cvt_ubyte<3>(d1);
+    if constexpr (!BGR) {
+        g[2] = cvt_ubyte<0>(d1); g[3] = cvt_ubyte<1>(d1); g[4] = cvt_ubyte<2>(d1); g[5] = cvt_ubyte<3>(d1);
+    }
     g[6] = cvt_ubyte<0>(d2); g[7] = cvt_ubyte<1>(d2);
+    if constexpr (!BGR) {   // prefetch two rows ahead into the slot just consumed (see the other form above)
+        const int tn = t + 2 < a.steps ? t + 2 : a.steps - 1;
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.w;
+        uint32_t ol = a.voff_l, oc = a.voff_c, orr = a.voff_r;
+        asm volatile("" : "+v"(ol), "+v"(oc), "+v"(orr) : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]));
+        st.raw[P][0] = *reinterpret_cast<const uint32_t *>(rowp + ol);
+        st.raw[P][1] = *reinterpret_cast<const uint32_t *>(rowp + oc);
+        st.raw[P][2] = *reinterpret_cast<const uint32_t *>(rowp + orr);
+    }
     float dy[6];
     {
         float pr[7];
@@ -509,12 +561,19 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
 // Tier 1: U~ for every pixel; the possible pixels go to list[f][0 .. counts[f]) as raw entries (image_common.h; the
 // upper bound in units of c0); low_max[f] collects the certified lower bound of the frame maximum (ordered float, same
 // units) that the waves share, hist[f][] counts the entries by upper bound.
+// BGR: `src` is the 3-byte image (bstride bytes per row, rows and base dword-aligned) and the kernel is cvtColor as well:
+// it forms the gray rows it needs from the lane's own 12 bytes, hands the neighbour pixels across lanes, and writes the
+// rows it owns to gray_out for the stages that follow (blur, exact tier) — bgr2gray's 0.30 ms of pure HBM time are paid
+// here as ≈ 25 vector instructions per row on top of 225, while the kernel's loads wait behind its arithmetic anyway.
+template <bool BGR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void min_eigen_tiered_kernel(
-    const uint8_t *__restrict__ gray, int w, int h, uint32_t *__restrict__ low_max, uint32_t *__restrict__ hist,
+    const uint8_t *__restrict__ src, int bstride, uint8_t *__restrict__ gray_out, int w, int h,
+    uint32_t *__restrict__ low_max, uint32_t *__restrict__ hist,
     double quality, unsigned long long *__restrict__ list, uint32_t *__restrict__ counts, size_t cap, int seg_rows,
     int frames, int strips, int per_frame) {
     __shared__ unsigned long long queue[4][kTQ1];
     __shared__ uint32_t whist[4][kTierBins];
+    __shared__ uint2 halo[BGR ? 4 : 1][BGR ? kTierMaxSteps : 1];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     int f, blk;
@@ -528,7 +587,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     a.steps = a.ye - a.ys + 6;
     a.w = w;
     a.h = h;
-    a.src = gray + (size_t)f * w * h;
+    a.src = src + (size_t)f * h * (BGR ? (size_t)bstride : (size_t)w);
+    a.bstride = bstride;
+    a.gout = BGR ? gray_out + (size_t)f * w * h : nullptr;
     a.queue = queue[wave];
     a.list = list + (size_t)f * cap;
     a.whist = whist[wave];
@@ -548,11 +609,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     a.left_fix = a.x == 0;
     a.right_fix = a.x + 4 == w;
     const int xc = a.x < 0 ? 0 : (a.x > w - 4 ? w - 4 : a.x);
-    a.voff_c = (uint32_t)xc;
-    a.voff_l = (uint32_t)(xc - 4 < 0 ? 0 : xc - 4);
-    a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
+    if constexpr (BGR) {   // the lane's 12 bytes
+        a.voff_c = (uint32_t)(3 * xc);
+    } else {
+        a.voff_c = (uint32_t)xc;
+        a.voff_l = (uint32_t)(xc - 4 < 0 ? 0 : xc - 4);
+        a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
+    }
+    if constexpr (BGR) {
+        // The two gray pixels on either side of the strip, for every row this wave will visit: 4 x steps <= 576 pixels, up to
+        // nine per lane, all loads in flight together while the registers are still free; the rows then fetch their pair of
+        // dwords from LDS.  (On the scalar unit, row by row, the same cost 0.11 ms: 50 scalar instructions per row are a
+        // quarter of a row's issue time, and a wave that is at them is not feeding the vector pipe.)
+        uint8_t *hb = reinterpret_cast<uint8_t *>(halo[wave]);
+        uint32_t v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int idx = lane + 64 * k;
+            const int r = (idx >> 2) < a.steps ? (idx >> 2) : a.steps - 1, j = idx & 3;
+            int px = j < 2 ? x0 - 2 + j : x0 + kSW - 2 + j;
+            px = px < 0 ? 0 : (px > w - 2 ? w - 2 : px);   // out of the image: not used (the mirrored columns come from the lane's own)
+            __builtin_memcpy(&v[k], a.src + (size_t)reflect101(a.ys - 3 + r, h) * bstride + 3 * px, 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int idx = lane + 64 * k;
+            if (idx < 4 * a.steps) hb[(idx >> 2) * 8 + 2 + (idx & 3)] = (uint8_t)(gray_x2_16(v[k]) >> 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        a.halo = halo[wave];
+    }
     const float ninf = -__builtin_inff();
-    const float qf = (float)quality * (1.f - 1.f / 1048576.f);   // threshold bound: quality, a hair low
+    const float qf = __int_as_float(__builtin_amdgcn_readfirstlane(
+        __float_as_int((float)quality * (1.f - 1.f / 1048576.f))));   // threshold bound: quality, a hair low
     a.qn = 0;
 
     TierState st;
@@ -564,10 +654,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         st.trm[k] = 0.f;
-        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
-        st.raw[k][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
-        st.raw[k][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
-        st.raw[k][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+        if constexpr (BGR) {
+            const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * bstride;
+            const uint32_t *vp = reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
+            st.raw[k][0] = vp[0]; st.raw[k][1] = vp[1]; st.raw[k][2] = vp[2];
+        } else {
+            const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
+            st.raw[k][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
+            st.raw[k][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
+            st.raw[k][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
+        }
     }
     // what other waves have certified so far (0 = nothing yet)
     a.qf = qf;
@@ -575,13 +671,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     a.published = low_max[f];
     a.lowU = a.published == 0u ? ninf : ord2f(a.published);
     a.thrU = a.lowU > 0.f ? a.lowU * qf : ninf;
-    for (int t0 = 0; t0 < a.steps; t0 += 2) {
-        tier_step<0>(st, a, t0, lane);
-        if (t0 + 1 < a.steps) tier_step<1>(st, a, t0 + 1, lane);
+    if constexpr (BGR) {
+        // Enter the loop with nothing in flight.  The compiler's wait in front of a row's first use has to hold on every
+        // path to it, and on the path from here the two rows above would be the youngest loads outstanding: it would
+        // wait for everything in every iteration (seen: vmcnt(0) at the loop head, 0.90 instead of 0.7 ms).
+        asm volatile("" : : "v"(st.raw[0][0]), "v"(st.raw[0][1]), "v"(st.raw[0][2]), "v"(st.raw[1][0]), "v"(st.raw[1][1]), "v"(st.raw[1][2]));
+    }
+    // Two rows per iteration, unconditionally (an odd last row follows the loop): with the second one under a condition,
+    // the path around it reaches the loop head with the first row's loads as the youngest in flight, and the wait in front
+    // of their use — one wait for all paths — could not leave the second row's loads outstanding.
+    int t0 = 0;
+    for (; t0 + 1 < a.steps; t0 += 2) {
+        tier_step<0, BGR>(st, a, t0, lane);
+        tier_step<1, BGR>(st, a, t0 + 1, lane);
         if (a.qn >= kTQ1 - 512) tier_flush(a, lane);
         // after the first two tested rows, then every 12 rows: tighten the bounds with what this wave has seen
         if ((t0 % 12) == 10 || t0 == 6) tier_tighten(a, st.lanelow, lane);
     }
+    if (t0 < a.steps) tier_step<0, BGR>(st, a, t0, lane);
     tier_tighten(a, st.lanelow, lane);
     tier_flush(a, lane);
     for (int i = lane; i < kTierBins; i += 64) {   // this wave's share of the frame's histogram
@@ -905,19 +1012,36 @@ size_t vs_response_hist_words(int frames) { return (size_t)frames * kTierBins; }
 
 int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, double quality,
                                   float *eig, const VsCornerCounters &c, unsigned long long *keys,
-                                  unsigned long long *keys2, size_t key_cap, uint32_t n_safe, int *raw_list) {
+                                  unsigned long long *keys2, size_t key_cap, uint32_t n_safe, int *raw_list,
+                                  const VsBgrSource *bgr) {
     int rc;
     const bool fused = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
     *raw_list = fused ? 1 : 0;
+    // the gray image has not been formed yet (bgr != nullptr): the two-tier detector does it on the way when the rows
+    // are dword-aligned, a cvtColor launch in front otherwise
+    static const char *nofuse = getenv("VSLAM_NO_GRAY_FUSION");
+    const bool from_bgr = bgr && fused && !nofuse && bgr->stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr->data) & 3) == 0 &&
+                          vs_div_up(h, vs_stream_segments(h, frames, vs_div_up(w, kSW))) + 6 <= kTierMaxSteps;
+    if (bgr && !from_bgr)
+        if ((rc = vs_launch_bgr2gray(ctx, bgr->data, frames, w, h, bgr->stride, const_cast<uint8_t *>(gray)))) return rc;
     if (fused) {
-        {
+        if (from_bgr) {
             VsProfScope ps(ctx, "min_eigen_kernel");
             const int strips = vs_div_up(w, kSW);
             const int segs = vs_stream_segments(h, frames, strips);
             const int seg_rows = vs_div_up(h, segs);
             const int per_frame = strips * vs_div_up(segs, 4);
-            min_eigen_tiered_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
-                gray, w, h, c.low, c.hist, quality, keys, c.counts, key_cap, seg_rows, frames, strips, per_frame);
+            min_eigen_tiered_kernel<true><<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
+                bgr->data, bgr->stride, const_cast<uint8_t *>(gray), w, h, c.low, c.hist, quality, keys, c.counts, key_cap,
+                seg_rows, frames, strips, per_frame);
+        } else {
+            VsProfScope ps(ctx, "min_eigen_kernel");
+            const int strips = vs_div_up(w, kSW);
+            const int segs = vs_stream_segments(h, frames, strips);
+            const int seg_rows = vs_div_up(h, segs);
+            const int per_frame = strips * vs_div_up(segs, 4);
+            min_eigen_tiered_kernel<false><<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
+                gray, 0, nullptr, w, h, c.low, c.hist, quality, keys, c.counts, key_cap, seg_rows, frames, strips, per_frame);
         }
         // A frame whose maximum response is not positive has no corners (its threshold max * quality lies at or above
         // every response, THRESH_TOZERO clears the image and zeros are not corners); the selection's exact threshold

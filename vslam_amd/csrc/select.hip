@@ -793,7 +793,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h,
                             int max_corners, double quality, double min_distance, int kp_stride,
-                            float *xy, int32_t *n) {
+                            float *xy, int32_t *n, const VsBgrSource *bgr) {
     VS_REQUIRE(ctx, gray && xy && n, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, frames > 0 && w >= 3 && h >= 3, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, max_corners > 0 && max_corners <= kp_stride, VSLAM_ERR_INVALID);
@@ -835,7 +835,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
                                 ? (uint32_t)((unsigned long long)max_corners * (unsigned)ctx->corner_window_pct / 100u) + 128u
                                 : 0xFFFFFFFFu;   // 0: everything
     int raw_list = 0;
-    if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, c, keys, keys2, key_cap, n_safe, &raw_list))) return rc;
+    if ((rc = vs_launch_response_candidates(ctx, gray, frames, w, h, quality, eig, c, keys, keys2, key_cap, n_safe, &raw_list, bgr))) return rc;
     if (ctx->fork_after_eigen) {   // the caller runs an independent stage on the auxiliary stream beside the selection
         VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
