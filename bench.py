@@ -33,14 +33,17 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(kernel, w, h, K, H, M):
+def algorithmic_bytes(kernel, w, h, K, H, M, gray_fused=False):
     """Compulsory HBM bytes PER FRAME PAIR for each kernel (DESIGN.md 'Roofline accounting'):
-    every input read once, every output written once, temporaries not counted."""
+    every input read once, every output written once, temporaries not counted.
+    gray_fused: cvtColor runs inside the detector's first kernel (no bgr2gray launch): that kernel then reads the
+    3-byte image and writes the gray one."""
     px = w * h
     table = {
         "bgr2gray_kernel": 2 * (3 * px + px),
-        "min_eigen_kernel": 2 * (px + 80 * K),        # gray in; out: candidate keys, about 10 per kept keypoint, 8 B each
-                                                      # (the response image itself is not written on this path)
+        # gray in (fused: BGR in, gray out); out: candidate keys, about 10 per kept keypoint, 8 B each
+        # (the response image itself is not written on this path)
+        "min_eigen_kernel": 2 * ((4 * px if gray_fused else px) + 80 * K),
         "corner_exact_kernel": 2 * (80 * K + (K * 8 // 5) * (25 + 8)),   # the list in; 5x5 gray windows of the ~1.6 K evaluated pixels in, their keys out
         "corner_select_kernel": 2 * (K * 8),
         "gaussian7_kernel": 2 * (px + px),
@@ -513,9 +516,10 @@ def main():
         M = float(best[:, 3].mean())
         m_prelim = M   # inlier matches; preliminary matches are >= this
         kernels = []
+        gray_fused = "bgr2gray_kernel" not in rep
         for name, (ms, cnt) in rep.items():
             per_launch_ms = ms / max(cnt, 1)
-            alg = algorithmic_bytes(name, w, h, K, H, m_prelim) * P
+            alg = algorithmic_bytes(name, w, h, K, H, m_prelim, gray_fused) * P
             kernels.append({"kernel": name, "ms_per_launch": per_launch_ms, "launches_per_step": cnt / psteps,
                             "alg_bytes_per_launch": alg,
                             "alg_GBps": alg / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
@@ -538,7 +542,8 @@ def main():
         av = arithmetic_view(top["kernel"], units_of(top["kernel"]), top["ms_per_launch"], full_batch)
         if av:
             result["roofline"]["arithmetic"] = av
-            why = ("a streaming stencil held by its exact f64 box sums and correctly rounded square roots, not by bandwidth"
+            why = ("a streaming stencil (cvtColor, integer Sobel and a certified f32 response for every pixel) held by its vector "
+                   "arithmetic, not by bandwidth"
                    if top["kernel"] == "min_eigen_kernel" else
                    "VALU-bound by construction (SURVEY.md 8d): its compulsory bytes are a rounding error next to its arithmetic")
             result["roofline"]["note"] = (why + ", so the HBM fraction is small by design; `arithmetic` gives its algorithmic op rate "

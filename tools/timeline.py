@@ -12,8 +12,9 @@ for r in rows:
     if m and "at::" not in r["Kernel_Name"] and "pmc_calib" not in r["Kernel_Name"]:
         ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], m.group(1)))
 ks.sort()
-# a step starts at the first bgr2gray after a closing RANSAC kernel (the conversion may come in several pieces)
-starts = [i for i, k in enumerate(ks) if k[3] == "bgr2gray_kernel" and (i == 0 or not ks[i - 1][3].startswith(("bgr2gray", "gaussian7", "rbrief_rotate", "ransac_mt")))]
+# a step starts at its first image kernel (cvtColor, or the detector that contains it) after a closing RANSAC kernel
+FIRST = ("bgr2gray_kernel", "min_eigen_tiered_kernel", "min_eigen_kernel")
+starts = [i for i, k in enumerate(ks) if k[3] in FIRST and i > 0 and ks[i - 1][3].startswith(("ransac_finish", "ransac_select", "ransac_mt"))]
 s, e = starts[-2], starts[-1]
 t0 = ks[s][0]
 for st, en, q, name in ks[s:e + 1]:

@@ -321,6 +321,7 @@ struct TierState {
     float ctr[2][4], hm[2][4];           // per response row: U~ and its horizontal 3-maxima
     float lf[2], rg[2], trm[2];          // U~ of the lane to the left / right, largest tr of the row's six columns
     uint32_t raw[2][3];                  // gray dwords (x-4, x, x+4) of the next two rows; BGR input: the lane's 12 bytes
+    uint32_t halo;                       // BGR input: the next row's pixels beside the strip
     float lanelow;                       // certified lower bound of the best response of this lane's pixels (U units)
 };
 
@@ -334,7 +335,7 @@ struct TierArgs {
     int w, h, ys, ye, x, steps;
     int bstride;                     // BGR input: bytes per row of src
     uint8_t *gout;                   // BGR input: this frame's gray image (written for the rows [ys, ye))
-    const uint2 *halo;               // BGR input, LDS: per row of the wave's segment the gray pixels left / right of the strip
+    const uint32_t *halo;            // BGR input, LDS: per row of the wave's segment the gray pixels left / right of the strip
     uint32_t voff_l, voff_c, voff_r;
     bool edge, left_fix, right_fix, own_lane;
     unsigned long long cand_ok[4];   // lanes whose pixel i is an owned candidate position (1 <= x < w - 1)
@@ -416,8 +417,10 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
         }
         // the neighbours' bytes; beyond the strip: the two pixels left of it (bytes 2, 3 of the dword a lane 0 wants) and the
         // two right of it (bytes 0, 1), converted when the wave started
-        const uint2 hv = a.halo[t];
-        const uint32_t gl = hv.x, gr = hv.y;
+        // (one dword per row: bytes 2, 3 = the left pair, bytes 0, 1 = the right pair — each consumer looks at its own half;
+        // read one row ahead, or every row would wait out the LDS latency in front of the two moves below)
+        const uint32_t gl = st.halo, gr = st.halo;
+        st.halo = a.halo[t + 1];
         d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)gl, (int)d1, 0x138, 0xf, 0xf, false);   // lane i <- lane i - 1
         d2 = (uint32_t)__builtin_amdgcn_update_dpp((int)gr, (int)d1, 0x130, 0xf, 0xf, false);   // lane i <- lane i + 1
     }
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int frames, int strips, int per_frame) {
     __shared__ unsigned long long queue[4][kTQ1];
     __shared__ uint32_t whist[4][kTierBins];
-    __shared__ uint2 halo[BGR ? 4 : 1][BGR ? kTierMaxSteps : 1];
+    __shared__ uint32_t halo[BGR ? 4 : 1][BGR ? kTierMaxSteps + 1 : 1];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     int f, blk;
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const int idx = lane + 64 * k;
-            if (idx < 4 * a.steps) hb[(idx >> 2) * 8 + 2 + (idx & 3)] = (uint8_t)(gray_x2_16(v[k]) >> 16);
+            if (idx < 4 * a.steps) hb[(idx >> 2) * 4 + ((idx + 2) & 3)] = (uint8_t)(gray_x2_16(v[k]) >> 16);   // j = 0, 1 -> bytes 2, 3; j = 2, 3 -> bytes 0, 1
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -647,6 +650,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     TierState st;
     st.lanelow = ninf;
+    st.halo = 0u;
+    if constexpr (BGR) st.halo = a.halo[0];
 #pragma unroll
     for (int i = 0; i < 12; i++) st.T[i] = st.X[0][i] = st.X[1][i] = 0.f;
 #pragma unroll
