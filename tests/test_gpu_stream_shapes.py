@@ -85,3 +85,42 @@ def test_describe_other_rotations_and_wide_patterns(ctx, oracle, angle_deg, scal
         rd, keep = oracle.orb_describe(blur[f], pts[f, :n[f]], ca, sa, pat)
         assert n_out[f] == len(keep), f
         assert np.array_equal(desc[f, :len(keep)], rd), f
+
+
+# The detector's first kernel is cvtColor as well when the rows are dword-aligned (response.hip: the BGR form of
+# min_eigen_tiered_kernel): strips that end inside / at / beyond the image, one-strip and many-strip widths, heights of one
+# and several row segments (a segment's first rows convert rows of the segment above again), padded rows, and rows whose
+# padding breaks the alignment (cvtColor then is a launch of its own).
+BGR_SHAPES = [(64, 64, 0), (252, 140, 0), (256, 91, 0), (260, 136, 4), (264, 181, 0), (516, 271, 8), (772, 96, 0), (1028, 70, 0),
+              (1924, 75, 0), (260, 136, 2), (516, 100, 1)]
+
+
+@pytest.mark.parametrize("w,h,pad", BGR_SHAPES)
+def test_extract_from_bgr_on_seams(ctx, oracle, w, h, pad):
+    rng = np.random.default_rng(4000 + w + h + pad)
+    n = 3
+    bgr = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    for f in range(n):
+        for _ in range(max(1, w * h // 500)):
+            x, y = rng.integers(0, w), rng.integers(0, h)
+            bgr[f, y:y + rng.integers(2, 12), x:x + rng.integers(2, 12)] = rng.integers(0, 256, 3)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    maxc = 400
+    if pad:
+        rows = np.zeros((n, h, 3 * w + pad), dtype=np.uint8)
+        rows[:, :, :3 * w] = bgr.reshape(n, h, 3 * w)
+        rows[:, :, 3 * w:] = rng.integers(0, 256, (n, h, pad), dtype=np.uint8)   # the padding is not to be looked at
+        out = ctx.extract_features(torch.from_numpy(rows).cuda(), maxc, ca, sa, torch.from_numpy(pat).cuda(), width=w)
+    else:
+        out = ctx.extract_features(torch.from_numpy(bgr).cuda(), maxc, ca, sa, torch.from_numpy(pat).cuda())
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for f in range(n):
+        r = oracle.extract_features(bgr[f], maxc, ca, sa, pat)
+        assert out["n_detected"][f] == r["n_detected"], (w, h, pad, f)
+        k = r["n"]
+        assert out["n"][f] == k, (w, h, pad, f)
+        assert np.array_equal(out["xy"][f, :k], r["xy"]), (w, h, pad, f)
+        assert np.array_equal(out["desc"][f, :k], r["desc"]), (w, h, pad, f)
+        assert np.array_equal(out["nodes"][f, :k], r["nodes"]), (w, h, pad, f)

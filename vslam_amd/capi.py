@@ -293,9 +293,16 @@ class Context:
         p.d_pattern = pattern.data_ptr()
         return p
 
-    def extract_features(self, bgr, max_corners, cos_a, sin_a, pattern, kp_stride=None, out=None):
+    def extract_features(self, bgr, max_corners, cos_a, sin_a, pattern, kp_stride=None, out=None, width=None):
+        """bgr: (F, H, W, 3), or rows with padding as (F, H, row_bytes) together with `width`."""
         torch = self.torch
-        F, H, W, _ = bgr.shape
+        if bgr.dim() == 3:
+            F, H, row_bytes = bgr.shape
+            W = int(width)
+            assert row_bytes >= 3 * W
+        else:
+            F, H, W, _ = bgr.shape
+            row_bytes = 3 * W
         K = kp_stride or max_corners
         self._dev(bgr, torch.uint8, "bgr"); self._dev(pattern, torch.int8, "pattern")
         dev = bgr.device
@@ -307,7 +314,7 @@ class Context:
                        n_detected=torch.zeros((F,), dtype=torch.int32, device=dev))
         p = self._params(max_corners, cos_a, sin_a, pattern)
         self._check(self.lib.vslam_extract_features(self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H),
-                                                    C.c_int(3 * W), C.byref(p), C.c_int(K), _ptr(out["xy"]),
+                                                    C.c_int(row_bytes), C.byref(p), C.c_int(K), _ptr(out["xy"]),
                                                     _ptr(out["desc"]), _ptr(out["nodes"]), _ptr(out["n"]),
                                                     _ptr(out["n_detected"])))
         return out
