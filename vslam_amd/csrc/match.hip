@@ -281,6 +281,11 @@ __global__ __launch_bounds__(64 * kMQ / (32 * RT)) void match_knn2_mfma_kernel(
             const v4i bv = *reinterpret_cast<const v4i *>(src + 32 * ks);
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt][ks], bv, acc[rt], 0, 0, 0);
+            // The first step's accumulator is the constant 0, so its 16 result registers are new, and with bv dead behind the
+            // multiply this compiler lets them start on bv's four (8-wave shape: v_mfma v[0:15], v[16:19], v[0:3], 0).  No
+            // wrong result was ever seen with it, but an instruction that overwrites an operand it may still be reading is
+            // not something to rely on: bv stays alive across the multiply.
+            if (ks == 0) asm volatile("" : : "v"(bv));
         }
         // key = (|b| + bias - 2 a.b) << 16 | train index = base - (a.b << 17): one multiply-add per result
         const int base = (int)(((s_pb[buf][r] + kMBias) << 16) | (uint32_t)(tile * kMT + r));
