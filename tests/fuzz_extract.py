@@ -66,6 +66,27 @@ def run(ctx, o, seed, cases=None, seconds=None):
             for f in range(n):
                 rd, keep = o.orb_describe(bl[f], pts[f], ca, sa, pat)
                 assert no[f] == len(keep) and np.array_equal(de[f, :len(keep)], rd), ("descriptors", w, h, f)
+        if w >= 4 and h >= 4 and rng.random() < 0.5:
+            # the whole of extract_features from 3-byte rows (cvtColor inside the detector when the rows are dword-aligned,
+            # a launch of its own otherwise): colours whose gray values are the content above plus a colour cast, rows
+            # with random padding
+            cast = rng.integers(-40, 41, (n, h, w, 3))
+            bgr = np.clip(g[..., None].astype(np.int64) + cast, 0, 255).astype(np.uint8)
+            pad = int(rng.choice([0, 0, 4, 8, 1, 2, 3]))
+            rows = np.zeros((n, h, 3 * w + pad), dtype=np.uint8)
+            rows[:, :, :3 * w] = bgr.reshape(n, h, 3 * w)
+            if pad:
+                rows[:, :, 3 * w:] = rng.integers(0, 256, (n, h, pad), dtype=np.uint8)
+            kc = min(maxc, 2000)
+            out = ctx.extract_features(torch.from_numpy(rows).cuda(), kc, ca, sa, dpat, width=w)
+            ctx.synchronize()
+            out = {k: v.cpu().numpy() for k, v in out.items()}
+            for f in range(n):
+                r = o.extract_features(bgr[f], kc, ca, sa, pat)
+                k = r["n"]
+                assert out["n_detected"][f] == r["n_detected"] and out["n"][f] == k, ("bgr counts", w, h, pad, kind, kc, f)
+                assert np.array_equal(out["xy"][f, :k], r["xy"]) and np.array_equal(out["desc"][f, :k], r["desc"]), ("bgr", w, h, pad, kind, f)
+                assert np.array_equal(out["nodes"][f, :k], r["nodes"]), ("bgr tree", w, h, pad, kind, f)
         done += 1
         if seconds is not None and done % 100 == 0:   # a long run says so as it goes
             print("fuzz_extract: %d cases ok, %.0f s" % (done, time.time() - t0), flush=True)
