@@ -10,10 +10,12 @@
 // pt_index column, int32 [n] — 4 B/node instead of 24 — and child links are arithmetic.
 //
 // Build: one workgroup per frame.  (x, y, index) triples live in LDS; the recursion is run level
-// by level (all subtrees of one depth are independent), one lane per subtree, each lane replaying
-// libstdc++'s introselect step for step (introselect.h) so tied coordinates land exactly where
-// std::nth_element puts them.  The top levels are serial by nature (depth 0 is one 2000-element
-// selection); 512 frames per batch keep the other CUs busy.
+// by level (all subtrees of one depth are independent): a wave per subtree while the subtrees have
+// 48 points or more (introselect.h: the partition as two ballot scans and a parallel swap), a lane
+// per subtree below — either way libstdc++'s introselect replayed step for step, so tied
+// coordinates land exactly where std::nth_element puts them.  The top levels are serial by nature
+// (depth 0 is one 2000-element selection); 512 frames per batch keep the other CUs busy, and a
+// single frame gets a 16-wave workgroup (see the launcher).
 //
 // Query: one lane per query, explicit stack in LDS, hits appended in visit order (node, left,
 // right), which is the order vslam.cpp:150-158 observes through its `break`.
@@ -22,7 +24,6 @@
 
 namespace {
 
-constexpr int kBuildThreads = 256;
 
 struct Triple {
     float x, y;
@@ -54,9 +55,9 @@ struct LdsStore {
     __device__ bool less(float a, float b) const { return a < b; }
 };
 
-constexpr int kWaveMinLen = 48;   // shorter ranges: one lane per subtree is cheaper than a wave each
-
-__global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float *__restrict__ xy,
+// T = threads per workgroup; ranges shorter than MINLEN: one lane per subtree is cheaper than a wave each
+template <int T, int MINLEN>
+__global__ __launch_bounds__(T) void kdtree_build_kernel(const float *__restrict__ xy,
                                                                      const int32_t *__restrict__ n_arr,
                                                                      int kp_stride,
                                                                      int32_t *__restrict__ nodes) {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float
     int *sr = sl + kp_stride + 1;
     const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)b * kp_stride;
     int32_t *out = nodes + (size_t)b * kp_stride;
-    for (int i = tid; i < n; i += kBuildThreads) {
+    for (int i = tid; i < n; i += T) {
         const float2 p = P[i];
         kx[i] = p.x;
         ky[i] = p.y;
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(kBuildThreads) void kdtree_build_kernel(const float
     const int wave = tid >> 6, lane = tid & 63;
     for (int depth = 0; depth < height; depth++) {
         const int tasks = 1 << depth;
-        const bool by_wave = (n >> depth) >= kWaveMinLen;   // subtree sizes at this depth are n/2^depth (+-1)
-        const int step = by_wave ? kBuildThreads / 64 : kBuildThreads;
+        const bool by_wave = (n >> depth) >= MINLEN;   // subtree sizes at this depth are n/2^depth (+-1)
+        const int step = by_wave ? T / 64 : T;
         for (int t = by_wave ? wave : tid; t < tasks; t += step) {
             int first = 0, last = n, pos = 0;
             for (int bit = depth - 1; bit >= 0 && last > first; bit--) {
@@ -276,13 +277,24 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
     const size_t lds = (size_t)kp_stride * 20 + 8;
     VS_REQUIRE(ctx, lds <= 160 * 1024 - 512, VSLAM_ERR_CAPACITY);
-    if (!ctx->attr_done["kdtree_build"]) {
-        VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kdtree_build_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-        ctx->attr_done["kdtree_build"] = true;
-    }
+    // Workgroup size by batch: with few trees in flight (the one-frame-at-a-time drop-in use) sixteen waves take the 8, 16
+    // and 32 subtrees of depths 3-5 in one or two rounds instead of up to eight (one 2000-point tree: 0.24 -> 0.17 ms);
+    // beside the matcher of a large batch the extra waves cost the step more than the build gains (2.92 -> 3.07 ms at C3).
+    static const char *shape_env = getenv("VSLAM_KD_THREADS");   // 256 / 1024 force one (A/B timing)
+    const int threads = shape_env ? atoi(shape_env) : (batch <= 32 ? 1024 : 256);
     VsProfScope ps(ctx, "kdtree_build_kernel");
-    kdtree_build_kernel<<<batch, kBuildThreads, lds, ctx->stream>>>(xy, n, kp_stride, nodes);
+#define VS_KD_LAUNCH(T, M)                                                                                                  \
+    do {                                                                                                                    \
+        if (!ctx->attr_done["kdtree_build" #T "_" #M]) {                                                                    \
+            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kdtree_build_kernel<T, M>),                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));                 \
+            ctx->attr_done["kdtree_build" #T "_" #M] = true;                                                                \
+        }                                                                                                                   \
+        kdtree_build_kernel<T, M><<<batch, T, lds, ctx->stream>>>(xy, n, kp_stride, nodes);                                 \
+    } while (0)
+    if (threads == 1024) VS_KD_LAUNCH(1024, 48);
+    else VS_KD_LAUNCH(256, 48);
+#undef VS_KD_LAUNCH
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }
