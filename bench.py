@@ -407,13 +407,17 @@ def main():
     lo, hi = shard.shard_range(world * P, rank, world)          # this rank's slice of the global batch
     seeds = torch.from_numpy(shard.pair_seeds(seed, lo, hi).view(np.int32)).to(dev)
     out = None
-    gathered = torch.empty((world * P, shard.record_words(K)), dtype=torch.int32, device=dev) if multi else None
-    rec_buf = torch.empty((P, shard.record_words(K)), dtype=torch.int32, device=dev) if multi else None
+    # Two sets of record buffers: the gather of step k runs on the process group's own stream while step k + 1 computes
+    # (nothing in a step reads the gathered records); a set is reused only after its gather has completed.
+    gathered = [torch.empty((world * P, shard.record_words(K)), dtype=torch.int32, device=dev) for _ in range(2)] if multi else None
+    rec_buf = [torch.empty((P, shard.record_words(K)), dtype=torch.int32, device=dev) for _ in range(2)] if multi else None
+    gather_work = [None, None]
+    steps_done = 0
     if multi and dist.get_backend() == "nccl":
         # set-up, not a step: the RCCL communicator is created by the first collective (seconds); keep that out of the
         # steps even when the caller asks for no warm-up
-        rec_buf.zero_()
-        dist.all_gather_into_tensor(gathered, rec_buf)
+        rec_buf[0].zero_()
+        dist.all_gather_into_tensor(gathered[0], rec_buf[0])
         torch.cuda.synchronize(dev)
 
     if lanes > 1:   # lane l owns pairs [l*PL, (l+1)*PL): its "last" and "current" frames made contiguous
@@ -423,7 +427,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     def step():
-        nonlocal out
+        nonlocal out, steps_done
         if lanes > 1:
             for l in range(lanes):
                 lane_out[l] = lane_ctx[l].frontend_pairs(lane_bgr[l], PL, K, ca, sa, pat, lane_seeds[l], H, thr, out=lane_out[l])
@@ -434,11 +438,15 @@ def main():
         out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
         if multi:
             # the only exchange on the path: fixed-size per-pair result records to every rank
-            rec = ctx.pack_records(out["F"], out["best"], out["matches"], out=rec_buf)
+            i = steps_done & 1
+            steps_done += 1
+            if gather_work[i] is not None:
+                gather_work[i].wait()   # a stream-side wait for the gather of two steps ago: long done
+            rec = ctx.pack_records(out["F"], out["best"], out["matches"], out=rec_buf[i])
             if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(gathered, rec)   # = shard.gather_records for world > 1
+                gather_work[i] = dist.all_gather_into_tensor(gathered[i], rec, async_op=True)   # = shard.gather_records for world > 1
             else:
-                gathered.copy_(shard.gather_records(rec.cpu(), world, n_items=world * P))
+                gathered[i].copy_(shard.gather_records(rec.cpu(), world, n_items=world * P))
 
     if args.pmc_calibrate and rank == 0:
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
@@ -457,6 +465,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    for wk in gather_work:
+        if wk is not None:
+            wk.wait()   # the last steps' gathers belong to the timed region
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
