@@ -99,3 +99,16 @@ def test_cheap_response_is_within_its_certified_margin(oracle):
         assert not (certain & inner & (max8(eig) > eig)).any(), name      # a certain maximum is a maximum
         assert (U + m2)[np.unravel_index(np.argmax(eig), eig.shape)] >= (U - m2 / 2).max(), name   # the maximum queues
     assert worst > 0.0
+
+
+def test_gray_from_two_byte_dot_products():
+    """response.hip (gray_x2_16): cvtColor's (3735 b + 19235 g + 9798 r + 2^14) >> 15 formed as two 4 x u8 dot products
+    with the DOUBLED weights split into bytes, 256 * (29, 150, 76) + (46, 70, 140), and 2 * 2^14 = 256 * 128 as the first
+    one's addend: the gray value is byte 2 of the sum and byte 3 stays zero — for every (b, g, r)."""
+    b, g, r = np.meshgrid(np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), indexing="ij")
+    ref = (3735 * b + 19235 * g + 9798 * r + (1 << 14)) >> 15
+    hi = 29 * b + 150 * g + 76 * r + 128
+    s = 46 * b + 70 * g + 140 * r + (hi << 8)
+    assert int(s.max()) < (1 << 24)
+    assert np.array_equal((s >> 16) & 0xFF, ref)
+    assert np.array_equal(s >> 24, np.zeros_like(s))
