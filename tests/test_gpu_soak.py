@@ -109,3 +109,27 @@ def test_hard_regime_pairs_bit_exact(ctx, w, h, K, H, P, seed):
             assert out["F"][p].tobytes() == m["F"].tobytes(), p
         outlier_share.append(1.0 - k / max(m["prelim"], 1))
     assert np.mean(outlier_share) > 0.25, outlier_share     # the regime really is the harder one
+
+
+@pytest.mark.parametrize("w,h,pad,maxc", [(3840, 2160, 0, 5000), (4096, 1200, 4, 3000), (2560, 1440, 0, 8000), (1284, 2200, 0, 2000)])
+def test_large_frames_from_bgr_rows(ctx, oracle, w, h, pad, maxc):
+    """Frames well beyond the bench shapes (4K: 15 column strips, 24 row segments per frame; a 4096-wide one with padded rows;
+    8000 corners) through the whole of extract_features, against the oracle."""
+    rng = np.random.default_rng(w + h)
+    n = 2
+    g = rng.integers(0, 256, (n, h // 8 + 1, w // 8 + 1), dtype=np.uint8)
+    g = np.kron(g, np.ones((8, 8), np.uint8))[:, :h, :w]      # a blocky texture: real corners
+    bgr = np.clip(g[..., None].astype(np.int64) + rng.integers(-6, 7, (n, h, w, 3)), 0, 255).astype(np.uint8)
+    rows = np.zeros((n, h, 3 * w + pad), np.uint8)
+    rows[:, :, :3 * w] = bgr.reshape(n, h, 3 * w)
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    out = ctx.extract_features(torch.from_numpy(rows).cuda(), maxc, ca, sa, torch.from_numpy(pat).cuda(), width=w)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for f in range(n):
+        r = oracle.extract_features(bgr[f], maxc, ca, sa, pat)
+        k = r["n"]
+        assert out["n_detected"][f] == r["n_detected"] and out["n"][f] == k, (w, h, f)
+        assert np.array_equal(out["xy"][f, :k], r["xy"]) and np.array_equal(out["desc"][f, :k], r["desc"]), (w, h, f)
+        assert np.array_equal(out["nodes"][f, :k], r["nodes"]), (w, h, f)
