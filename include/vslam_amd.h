@@ -165,7 +165,9 @@ int vslam_ransac_evaluate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2
 /* Replaces construct_kdtree(frame_kdtree&, points), src/KDTree.cpp:107-143.  The tree is the
  * reference's pre-order node array reduced to its pt_index column: d_nodes [batch][kp_stride].
  * Child positions are implicit (left subtree len/2 nodes, right len - len/2 - 1).  Tie placement
- * reproduces libstdc++'s std::nth_element (introselect) exactly.                             */
+ * reproduces libstdc++'s std::nth_element (introselect) exactly.  A tree is built in one workgroup's
+ * LDS (20 bytes per slot): kp_stride <= 8160, VSLAM_ERR_CAPACITY beyond — which is also the limit of
+ * vslam_extract_features / vslam_frontend_* when they are asked for the trees (d_nodes != NULL).  */
 int vslam_kdtree_build(vslam_ctx *ctx, const float *d_xy, const int32_t *d_n, int batch,
                        int kp_stride, int32_t *d_nodes);
 /* Replaces radius_search(frame_kdtree, points, query, radius), src/KDTree.cpp:145-171.
