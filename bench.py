@@ -433,7 +433,9 @@ def main():
                 lane_out[l] = lane_ctx[l].frontend_pairs(lane_bgr[l], PL, K, ca, sa, pat, lane_seeds[l], H, thr, out=lane_out[l])
             for l in range(lanes):
                 lane_ctx[l].synchronize()
-            out = {k: torch.cat([lo[k] for lo in lane_out]) for k in ("best", "n", "F", "matches")}
+            out = {k: torch.cat([lo[k] for lo in lane_out]) for k in ("best", "F", "matches")}
+            # per-frame counts: a lane holds [its last frames, its current frames]; the batch layout is [all last, all current]
+            out["n"] = torch.cat([lo["n"][:PL] for lo in lane_out] + [lo["n"][PL:] for lo in lane_out])
             return
         out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
         if multi:
