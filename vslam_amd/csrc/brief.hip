@@ -332,10 +332,24 @@ __global__ __launch_bounds__(kKT) void rbrief_tile_kernel(const uint8_t *__restr
     const int pitch = staged ? tw + 2 * kRMax + 16 : w;   // bytes; a multiple of 16 when staged
     const uint8_t *img = blurred + (size_t)f * w * h;
     const uint32_t magic = (65536u + (uint32_t)nc - 1u) / (uint32_t)nc;   // i / nc == (i * magic) >> 16 for the i that occur (< 8000)
-    for (int i = tid; staged && i < nr * nc; i += kKT) {
-        const int r = (int)(((uint32_t)i * magic) >> 16), c = i - r * nc;
-        *reinterpret_cast<uint4 *>(s_tile_px + r * pitch + 16 * c) =
-            *reinterpret_cast<const uint4 *>(img + (size_t)(y0 + r) * w + x0 + 16 * c);
+    // eight pieces per thread in flight (a 128 x 128 tile with its margins is 7.5 per thread): one piece per trip of a plain
+    // loop is a load, a wait and a store, i.e. eight memory round trips in a row in front of the barrier
+    constexpr int kStageDepth = 8;
+    for (int i0 = tid; staged && i0 < nr * nc; i0 += kKT * kStageDepth) {
+        uint4 v[kStageDepth];
+#pragma unroll
+        for (int u = 0; u < kStageDepth; u++) {
+            const int i = min(i0 + kKT * u, nr * nc - 1);   // unconditional loads (a load under a condition is waited for at its join)
+            const int r = (int)(((uint32_t)i * magic) >> 16), c = i - r * nc;
+            v[u] = *reinterpret_cast<const uint4 *>(img + (size_t)(y0 + r) * w + x0 + 16 * c);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // or the scheduler pairs every load with its store again
+#pragma unroll
+        for (int u = 0; u < kStageDepth; u++) {
+            const int i = min(i0 + kKT * u, nr * nc - 1);   // the surplus writes the last piece again: no branches here either
+            const int r = (int)(((uint32_t)i * magic) >> 16), c = i - r * nc;
+            *reinterpret_cast<uint4 *>(s_tile_px + r * pitch + 16 * c) = v[u];
+        }
     }
     const int slot = tid >> 5, l32 = tid & 31;
     int off[16];   // this lane's 16 sample offsets in the staged tile
@@ -352,20 +366,29 @@ __global__ __launch_bounds__(kKT) void rbrief_tile_kernel(const uint8_t *__restr
     const int2 *TK = reinterpret_cast<const int2 *>(tile_kp) + (size_t)f * kp_stride;
     int2 ent = k0 + slot < k1 ? TK[k0 + slot] : make_int2(0, 0);   // requested before the tile is waited for
     __syncthreads();
-    for (int k = k0 + slot; k < k1; k += kKT / 32) {
-        const int2 cur = ent;
-        if (k + kKT / 32 < k1) ent = TK[k + kKT / 32];   // the next one is in flight while this one is sampled
-        const int kx = cur.x & 0xFFFF, ky = cur.x >> 16, kp = cur.y;
-        const uint8_t *pb = staged ? s_tile_px + (ky - y0) * pitch + (kx - x0) : img + (size_t)ky * w + kx;
-        uint32_t val = 0;
+    // Two copies of the loop, one per address space: with one pointer that is either into the tile or into the image the
+    // samples are FLAT loads — a 64-bit address each, the slow path to LDS, and a wait that covers the list entry in flight
+    // as well — instead of ds_read_u8 at a 32-bit address.
+    auto describe = [&](auto sample_base) {
+        for (int k = k0 + slot; k < k1; k += kKT / 32) {
+            const int2 cur = ent;
+            if (k + kKT / 32 < k1) ent = TK[k + kKT / 32];   // the next one is in flight while this one is sampled
+            const int kx = cur.x & 0xFFFF, ky = cur.x >> 16, kp = cur.y;
+            const auto pb = sample_base(kx, ky);
+            uint32_t val = 0;
 #pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
-            const int t0 = pb[off[2 * bit]];
-            const int t1 = pb[off[2 * bit + 1]];
-            val |= (uint32_t)(t0 < t1) << bit;
+            for (int bit = 0; bit < 8; bit++) {
+                const int t0 = pb[off[2 * bit]];
+                const int t1 = pb[off[2 * bit + 1]];
+                val |= (uint32_t)(t0 < t1) << bit;
+            }
+            desc[((size_t)f * kp_stride + kp) * VSLAM_DESC_BYTES + l32] = (uint8_t)val;
         }
-        desc[((size_t)f * kp_stride + kp) * VSLAM_DESC_BYTES + l32] = (uint8_t)val;
-    }
+    };
+    if (staged)
+        describe([&](int kx, int ky) { return s_tile_px + (ky - y0) * pitch + (kx - x0); });
+    else
+        describe([&](int kx, int ky) { return img + (size_t)ky * w + kx; });
 }
 
 }  // namespace

@@ -441,7 +441,11 @@ __device__ __forceinline__ int nms_collect_disc(const uint32_t *offs, const uint
 // One visit of window entry i through the table: 1 accepted, 2 rejected, 0 still blocked by an undecided
 // better-ranked neighbour.  Statuses are read as they are at this moment (other waves publish theirs
 // without a barrier); they only ever go from undecided to decided, so a stale read costs a later visit.
-__device__ __forceinline__ int nms_visit_lds(const volatile uint32_t *offs, const uint32_t *slot32, uint32_t smask,
+// The statuses other waves publish are read through a VOLATILE pointer, and it has to say "LDS" itself: the compiler's
+// address-space inference leaves volatile accesses alone, and through a generic pointer every poll was a flat_load with
+// system scope (49 of them in this file) instead of a ds_read.
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+__device__ __forceinline__ int nms_visit_lds(const lds_vu32 *offs, const uint32_t *slot32, uint32_t smask,
                                              int hshift, int w, int h, uint32_t i, int R, float min_dist_sq) {
     const uint32_t off = offs[i] & kOffMask;
     const int y = off / w, x = off - y * w;
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 // wave therefore polls on its own, without workgroup barriers (statuses live in LDS, every wave of the
                 // workgroup is resident, and the rank order makes the dependency graph acyclic).
                 {
-                    volatile uint32_t *voffs = offs;
+                    lds_vu32 *voffs = (lds_vu32 *)offs;
                     int spins = 0;
                     while (__any(pend != 0)) {
                         int k = 0;
