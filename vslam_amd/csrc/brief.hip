@@ -305,8 +305,10 @@ __global__ __launch_bounds__(kKT) void rbrief_lds_kernel(const uint8_t *__restri
 // average.  Here a workgroup owns one kTW x kTH tile of the image: it loads the tile plus a margin of kRMax pixels once
 // (16-byte pieces, coalesced rows) and describes every keypoint that keypoint_border_kernel filed under the tile, eight
 // at a time, from LDS; the list entry of the next keypoint is in flight while one is sampled.  Same samples, same
-// comparisons, same bytes.  0.29 -> 0.215 ms at C3 (128 x 128 tiles; 64 x 64: 0.30, 256 x 128: 0.25); what is left is the
-// 16 byte reads per lane and keypoint from LDS, 60 % of whose cycles are bank conflicts (random positions in the patch).
+// comparisons, same bytes.  0.29 -> 0.215 ms at C3, and 0.19 once the samples were LDS reads (see the two loops at the end)
+// and the staging loads were in flight together (128 x 128 tiles; 64 x 64: 0.33, 128 x 64: 0.23, 256 x 128: 0.19); what is
+// left is the 16 byte reads per lane and keypoint from LDS at random positions in the patch (bank conflicts) and the
+// workgroup's chain of staging, barrier and four or five trips of entry -> samples -> store.
 __global__ __launch_bounds__(kKT) void rbrief_tile_kernel(const uint8_t *__restrict__ blurred, int w, int h,
                                                           int kp_stride,
                                                           const int32_t *__restrict__ table, const int32_t *__restrict__ tile_start,
