@@ -70,3 +70,36 @@ def test_a_rank_slice_equals_the_full_batch(ctx):
         part = run(ctx, np.concatenate([bgr[lo:hi], bgr[P + lo:P + hi]]), shard.pair_seeds(0x5EED0003, lo, hi))
         for p in range(lo, hi):
             assert record(part, p - lo, hi - lo) == record(full, p, P), (rank, p)
+
+
+def test_contexts_in_flight_agree(ctx):
+    """Three contexts (own streams and workspaces) given different batches back to back, no host wait in between, twice
+    around: every batch's records equal the ones the session context computes for it alone.  Guards against state shared
+    between contexts (static launcher state, tables, counters) now that DESIGN.md recommends keeping batches in flight."""
+    from vslam_amd import Context
+    P = 4
+    batches = []
+    for s in range(3):
+        bgr = synth.frames_numpy(0xF117 + s, P, W, H)
+        seeds = shard.pair_seeds(0xF117 + s, 0, P)
+        batches.append((bgr, seeds))
+    alone = [run(ctx, bgr, seeds) for bgr, seeds in batches]
+    pat = torch.from_numpy(synth.brief_pattern()).cuda()
+    ca, sa = synth.keypoint_rotation()
+    cs = [Context(0, use_torch_stream=False) for _ in range(3)]
+    dev_in = [(torch.from_numpy(bgr).cuda(), torch.from_numpy(seeds.view(np.int32)).cuda()) for bgr, seeds in batches]
+    torch.cuda.synchronize()
+    outs = [None] * 3
+    try:
+        for rnd in range(2):
+            for i in range(3):
+                outs[i] = cs[i].frontend_pairs(dev_in[i][0], P, K, ca, sa, pat, dev_in[i][1], HYP, THR, out=outs[i])
+        for c in cs:
+            c.synchronize()
+        for i in range(3):
+            got = {k: v.cpu().numpy() for k, v in outs[i].items()}
+            for p in range(P):
+                assert record(got, p, P) == record(alone[i], p, P), (i, p)
+    finally:
+        for c in cs:
+            c.close()
