@@ -18,7 +18,7 @@ def main():
     pairs, width, height = 2, 640, 480
     ctx = Context(0)                                            # raises if there is no MI355X / no built library
     bgr = torch.from_numpy(synth.frames_numpy(7, pairs, width, height)).cuda()   # frames [0, P) last, [P, 2P) current
-    pattern = torch.from_numpy(synth.brief_pattern()).cuda()    # 256 x 4 int8 rBRIEF test pairs (stand-in table)
+    pattern = torch.from_numpy(synth.brief_pattern()).cuda()    # 256 x 4 int8 rBRIEF test pairs: ORB's learned table (None would mean the same)
     cos_a, sin_a = synth.keypoint_rotation()                    # cv::KeyPoint's default angle, -1 degree
     seeds = torch.from_numpy(shard.pair_seeds(1234, 0, pairs).view(np.int32)).cuda()
     out = ctx.frontend_pairs(bgr, pairs, 500, cos_a, sin_a, pattern, seeds, hyp=512, threshold=10.0)

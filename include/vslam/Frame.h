@@ -42,9 +42,9 @@ struct Settings {
     double quality = 0.01;
     double min_distance = 3.0;
     float keypoint_angle_deg = -1.0f;   // cv::KeyPoint(p, 20) default angle
-    // 256 x (x0,y0,x1,y1) int8.  OpenCV's learned bit_pattern_31_ lives inside OpenCV and is not
-    // reachable through its API; load it from a file (env VSLAM_BRIEF_PATTERN, 1024 raw int8) to get
-    // OpenCV-compatible descriptors, otherwise a built-in seeded pattern is used.
+    // 256 x (x0,y0,x1,y1) int8 rBRIEF test pairs.  Left empty (the default) the adapters describe with ORB's learned
+    // table (vslam_brief_pattern_31(), OpenCV's bit_pattern_31_: what cv::ORB::compute samples, src/Frame.cpp:57,68);
+    // another table can be set here or loaded from a file (env VSLAM_BRIEF_PATTERN, 1024 raw int8).
     std::vector<s8> brief_pattern;
 };
 Settings &settings();

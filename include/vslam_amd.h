@@ -51,6 +51,10 @@ int vslam_ctx_synchronize(vslam_ctx *ctx);
 int vslam_ctx_wait(vslam_ctx *ctx);
 const char *vslam_last_error(vslam_ctx *ctx);
 const char *vslam_version(void);
+/* ORB's learned rBRIEF test pairs (OpenCV `bit_pattern_31_`, the table behind cv::ORB::compute, src/Frame.cpp:57,68):
+ * HOST pointer to 256 x (x0, y0, x1, y1) int8, static storage.  Every d_pattern argument below accepts NULL for a
+ * device copy of this table that the context keeps; other tables (tests, wider patches) are passed explicitly.       */
+const int8_t *vslam_brief_pattern_31(void);
 /* Context options.
  *   VSLAM_OPT_RANSAC_ALL_SUMS  0 (default): vslam_ransac_* compute what find_fundamental's accept rule can observe
  *       (src/RansacFilter.cpp:59: a hypothesis matters only if its inlier count is the pair's maximum, and its
@@ -203,8 +207,9 @@ typedef struct vslam_extract_params {
     double quality;          /* 0.01                                                           */
     double min_distance;     /* 3                                                              */
     float cos_a, sin_a;      /* steered-BRIEF rotation; KeyPoint(p,20) has angle -1 deg        */
-    const int8_t *d_pattern; /* DEVICE [256][4] int8 (x0,y0,x1,y1): OpenCV's learned table is an
-                                input, it is not redistributable from memory                  */
+    const int8_t *d_pattern; /* DEVICE [256][4] int8 (x0,y0,x1,y1) rBRIEF test pairs; NULL = ORB's
+                                learned table (vslam_brief_pattern_31), what cv::ORB::compute
+                                samples (src/Frame.cpp:57,68)                                  */
 } vslam_extract_params;
 
 /* Replaces extract_features(Frame&), src/Frame.cpp:53-80, for a batch of BGR frames:

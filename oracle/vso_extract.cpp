@@ -19,8 +19,8 @@
 //                         (18,34,48,56,48,34,18), Q16 accumulate, round half up.
 //   ORB::compute          orb.cpp: runByImageBorder(edgeThreshold 31), one level, steered BRIEF
 //                         x = px*a - py*b, y = px*b + py*a, cvRound, t0 < t1, WTA_K = 2.
-//                         The 256-pair learned pattern is data inside OpenCV and is NOT available
-//                         here: it is an INPUT table.
+//                         The 256-pair learned pattern is an INPUT table here; the tests pass
+//                         ORB's own (tests/golden/brief_pattern_31.npy) unless they say otherwise.
 #include "vso.h"
 
 #include <algorithm>

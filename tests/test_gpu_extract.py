@@ -1,4 +1,6 @@
 """HIP extraction kernels vs the oracle, stage by stage and end to end (all bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -144,6 +146,32 @@ def test_extract_features_end_to_end(ctx, oracle, w, h, maxc):
         assert np.array_equal(out["xy"][f, :k], ref["xy"]), f
         assert np.array_equal(out["desc"][f, :k], ref["desc"]), f
         assert np.array_equal(out["nodes"][f, :k], ref["nodes"]), f
+
+
+def test_null_pattern_means_orbs_learned_table(ctx, oracle):
+    """A NULL d_pattern is the default: ORB's learned table (vslam_brief_pattern_31), i.e. what cv::ORB::compute samples
+    (src/Frame.cpp:57,68) -- in extract_features, in orb_describe and in the grid extractor."""
+    w, h, maxc = 320, 240, 300
+    bgr = frames_for(w, h, 77)
+    pat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "brief_pattern_31.npy"))
+    ca, sa = synth.keypoint_rotation()
+    t = torch.from_numpy(bgr).cuda()
+    out = ctx.extract_features(t, maxc, ca, sa, None)
+    ctx.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for f in range(bgr.shape[0]):
+        ref = oracle.extract_features(bgr[f], maxc, ca, sa, pat)
+        k = ref["n"]
+        assert out["n"][f] == k and np.array_equal(out["desc"][f, :k], ref["desc"]), f
+    blur = ctx.gaussian7(ctx.bgr2gray(t))
+    xy = torch.from_numpy(out["xy"]).cuda(); n = torch.from_numpy(out["n"]).cuda()
+    a = ctx.orb_describe(blur, xy, n, ca, sa, None)
+    b = ctx.orb_describe(blur, xy, n, ca, sa, torch.from_numpy(pat).cuda())
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    ga = ctx.extract_features_grid(t.clone(), 2, 2, None, 4096)
+    gb = ctx.extract_features_grid(t.clone(), 2, 2, torch.from_numpy(pat).cuda(), 4096)
+    ctx.synchronize()
+    assert all(torch.equal(ga[k], gb[k]) for k in ga) and int(ga["n"].min()) > 50
 
 
 def test_frontend_pairs_end_to_end(ctx, oracle):

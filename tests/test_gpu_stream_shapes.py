@@ -65,14 +65,16 @@ def test_corners_on_strip_seam_columns(ctx, oracle):
             assert np.array_equal(xy[f, :n[f]], ref), (maxc, f)
 
 
-@pytest.mark.parametrize("angle_deg,scale", [(45.0, 1.15), (-133.0, 1.0), (0.0, 1.0), (0.0, 1.9), (10.0, 1.7)])
-def test_describe_other_rotations_and_wide_patterns(ctx, oracle, angle_deg, scale):
+@pytest.mark.parametrize("angle_deg,scale,table", [(45.0, 1.15, "orb"), (-133.0, 1.0, "orb"), (0.0, 1.0, "synthetic"),
+                                                   (0.0, 1.9, "orb"), (10.0, 1.7, "synthetic"), (45.0, 1.15, "synthetic")])
+def test_describe_other_rotations_and_wide_patterns(ctx, oracle, angle_deg, scale, table):
     """45 degrees stretches a +-15 pattern to +-21 (the widest staged patch); patterns scaled to +-25 exceed the
     staged patch and are sampled from the image directly (still inside the 31-pixel keypoint border)."""
     w, h = 320, 240
     gray = textured(w, h, 99)
     blur = ctx.gaussian7(torch.from_numpy(gray).cuda())
-    pat = np.clip(np.rint(synth.brief_pattern().astype(np.float32) * scale), -29, 29).astype(np.int8)
+    base = synth.brief_pattern() if table == "orb" else synth.synthetic_pattern()
+    pat = np.clip(np.rint(base.astype(np.float32) * scale), -29, 29).astype(np.int8)
     ca, sa = synth.keypoint_rotation(angle_deg)
     rng = np.random.default_rng(3)
     K = 700

@@ -52,15 +52,13 @@ def test_extraction_matches_opencv(oracle):
         assert np.array_equal(bits(oracle.min_eigen(gray)), bits(D[f"cv_eig{f}"])), "cornerMinEigenVal"
         assert np.array_equal(oracle.good_features(gray, 150), D[f"cv_corners{f}"]), "goodFeaturesToTrack"
         assert np.array_equal(oracle.gaussian7(gray), D[f"cv_blur{f}"]), "GaussianBlur 7x7 sigma 2"
-        # which keypoints ORB::compute keeps (border filter) does not depend on the bit pattern; the descriptors do:
-        # they can be compared once OpenCV's learned pattern is supplied (VSLAM_BRIEF_PATTERN, 1024 int8)
-        pat_path = os.environ.get("VSLAM_BRIEF_PATTERN")
-        pat = np.fromfile(pat_path, np.int8).reshape(256, 4) if pat_path else G["e_pattern"]
+        # the golden pattern is ORB's learned table since round 4 (tests/golden/brief_pattern_31.npy), so the
+        # descriptors are comparable with what OpenCV's own ORB::compute returned
+        pat = G["e_pattern"]
         ca, sa = map(float, G["e_rot"])
         e = oracle.extract_features(bgr[f], 150, ca, sa, pat)
         assert np.array_equal(e["xy"], D[f"cv_kept_xy{f}"]), "ORB::compute border filter"
-        if pat_path:
-            assert np.array_equal(e["desc"], D[f"cv_desc{f}"]), "rBRIEF descriptors"
+        assert np.array_equal(e["desc"], D[f"cv_desc{f}"]), "rBRIEF descriptors"
 
 
 def test_matching_matches_opencv(oracle):

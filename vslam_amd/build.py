@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvslam_amd.so")
 SOURCES = ["capi.hip", "match.hip", "ransac.hip", "kdtree.hip", "gray.hip", "response.hip", "select.hip", "blur.hip",
            "brief.hip", "orb_grid.hip", "pose.hip", "assoc.hip"]
-HEADERS = ["ctx.h", "introselect.h", "image_common.h", os.path.join("..", "..", "include", "vslam_amd.h")]
+HEADERS = ["ctx.h", "introselect.h", "image_common.h", os.path.join("..", "..", "include", "vslam_amd.h"),
+           os.path.join("..", "..", "include", "vslam_brief_pattern_31.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
 # Per-file additions.  response.hip: the SLP vectoriser pairs the stencil's float operations into v_pk_* forms whose
 # operands it then has to assemble with v_mov (a packed op issues for two slots, so the copies are a net loss: min_eigen

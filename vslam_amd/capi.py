@@ -17,7 +17,7 @@ ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE
 # every symbol include/vslam_amd.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
     "vslam_ctx_create", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_set_option", "vslam_ctx_synchronize", "vslam_ctx_wait",
-    "vslam_last_error", "vslam_version", "vslam_dev_alloc", "vslam_dev_free", "vslam_copy_h2d",
+    "vslam_last_error", "vslam_version", "vslam_brief_pattern_31", "vslam_dev_alloc", "vslam_dev_free", "vslam_copy_h2d",
     "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
@@ -290,7 +290,7 @@ class Context:
         p.min_distance = min_distance
         p.cos_a = cos_a
         p.sin_a = sin_a
-        p.d_pattern = pattern.data_ptr()
+        p.d_pattern = pattern.data_ptr() if pattern is not None else None   # NULL: ORB's learned table
         return p
 
     def extract_features(self, bgr, max_corners, cos_a, sin_a, pattern, kp_stride=None, out=None, width=None):

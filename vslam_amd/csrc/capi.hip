@@ -1,6 +1,7 @@
 // C ABI (include/vslam_amd.h): context, memory, event timing, and the entry points that chain
 // the stage launchers.  No CPU fallback anywhere: every entry point needs a live HIP device.
 #include "ctx.h"
+#include "../../include/vslam_brief_pattern_31.h"
 #include <cstdlib>
 
 #include <cstring>
@@ -22,6 +23,17 @@ int vs_arena_get(vslam_ctx *ctx, const char *name, size_t bytes, void **out) {
         buf.bytes = bytes;
     }
     *out = buf.ptr;
+    return VSLAM_OK;
+}
+
+// ORB's learned rBRIEF table (include/vslam_brief_pattern_31.h) on the device: what a NULL d_pattern means
+static int vs_default_pattern(vslam_ctx *ctx, const int8_t **out) {
+    const bool fresh = ctx->arena.find("ctx.brief_pattern_31") == ctx->arena.end();
+    void *p = nullptr;
+    int rc = vs_arena_get(ctx, "ctx.brief_pattern_31", 1024, &p);
+    if (rc) return rc;
+    if (fresh) VS_HIP(ctx, hipMemcpyAsync(p, vslam_brief_pattern_31_table, 1024, hipMemcpyHostToDevice, ctx->stream));
+    *out = (const int8_t *)p;
     return VSLAM_OK;
 }
 
@@ -109,6 +121,7 @@ int vslam_debug_stream_copy(vslam_ctx *ctx, const void *d_src, void *d_dst, size
 }
 
 const char *vslam_version(void) { return "vslam_amd 0.1 (gfx950)"; }
+const int8_t *vslam_brief_pattern_31(void) { return vslam_brief_pattern_31_table; }
 
 int vslam_ctx_create(int device, vslam_ctx **out) {
     if (!out) return VSLAM_ERR_INVALID;
@@ -429,6 +442,8 @@ int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int
                        float sin_a, const int8_t *d_pattern, float *d_xy_out, uint8_t *d_desc,
                        int32_t *d_n_out) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    if (!d_pattern)
+        if (int rc = vs_default_pattern(ctx, &d_pattern)) return rc;
     return vs_launch_orb_describe(ctx, d_blurred, frames, width, height, d_xy_in, d_n_in, kp_stride,
                                   cos_a, sin_a, d_pattern, d_xy_out, d_desc, d_n_out);
 }
@@ -453,7 +468,12 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     if (!ctx) return VSLAM_ERR_INVALID;
     VsTableGuard table_guard{ctx};
     VS_REQUIRE(ctx, d_bgr && params && d_xy && d_desc && d_n, VSLAM_ERR_INVALID);
-    VS_REQUIRE(ctx, params->d_pattern, VSLAM_ERR_INVALID);
+    vslam_extract_params with_table;
+    if (!params->d_pattern) {   // the default: ORB's learned table
+        with_table = *params;
+        if (int prc = vs_default_pattern(ctx, &with_table.d_pattern)) return prc;
+        params = &with_table;
+    }
     VS_REQUIRE(ctx, params->max_corners > 0 && params->max_corners <= kp_stride, VSLAM_ERR_INVALID);
     const size_t px = (size_t)frames * width * height;
     uint8_t *gray = nullptr, *blur = nullptr;
@@ -503,6 +523,8 @@ int vslam_extract_features_grid(vslam_ctx *ctx, uint8_t *d_bgr, int frames, int 
                                 int nrows, int ncols, const int8_t *d_pattern, int kp_stride, float *d_xy,
                                 uint8_t *d_desc, float *d_angle_octave, int32_t *d_n) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    if (!d_pattern)
+        if (int rc = vs_default_pattern(ctx, &d_pattern)) return rc;
     return vs_launch_extract_grid(ctx, d_bgr, frames, width, height, row_stride, nrows, ncols, d_pattern, kp_stride,
                                   d_xy, d_desc, d_angle_octave, d_n);
 }

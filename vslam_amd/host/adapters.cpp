@@ -428,14 +428,9 @@ const std::vector<s8> &pattern() {
         st.brief_pattern.assign(raw.begin(), raw.end());
         return st.brief_pattern;
     }
-    // built-in seeded stand-in (NOT OpenCV's learned table): Gaussian offsets, sigma 31/5, clipped to +-13
-    std::mt19937 g(0xB21EF);
-    std::normal_distribution<float> nd(0.f, 31.f / 5.f);
-    st.brief_pattern.resize(1024);
-    for (auto &v : st.brief_pattern) {
-        float x = std::nearbyint(nd(g));
-        v = (s8)(x < -13 ? -13 : (x > 13 ? 13 : x));
-    }
+    // the default: ORB's learned table, what cv::ORB::compute samples (src/Frame.cpp:57,68)
+    const int8_t *t = vslam_brief_pattern_31();
+    st.brief_pattern.assign(t, t + 1024);
     return st.brief_pattern;
 }
 

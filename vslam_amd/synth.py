@@ -52,11 +52,17 @@ def two_view_points(seed, k, width, height, inlier_frac=0.7, noise_px=0.5, integ
     return p1.astype(np.float32), p2.astype(np.float32), ~outl
 
 
-def brief_pattern(seed=0xB21EF):
-    """256 x (x0,y0,x1,y1) int8 test pattern inside the 31x31 patch.  OpenCV's learned table
-    (bit_pattern_31_) is data compiled into OpenCV and is not available here; this seeded
-    Gaussian pattern (sigma = patch/5, clipped to +-13 so a rotated sample stays inside the
-    31-px border) stands in and is labelled synthetic everywhere it is used."""
+def brief_pattern():
+    """ORB's learned rBRIEF table (OpenCV `bit_pattern_31_`, what cv::ORB::compute samples: src/Frame.cpp:57,68):
+    256 x (x0, y0, x1, y1) int8.  Shipped as data (`brief_pattern_31.npy`, written by tools/make_brief_pattern.py);
+    the same bytes are compiled into the library (`vslam_brief_pattern_31()`, the meaning of a NULL d_pattern)."""
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "brief_pattern_31.npy")).copy()
+
+
+def synthetic_pattern(seed=0xB21EF):
+    """A seeded Gaussian 256 x (x0,y0,x1,y1) int8 pattern (sigma = patch/5, clipped to +-13): NOT ORB's table.  For
+    tests that want descriptors under other tables than the default one."""
     rng = np.random.default_rng(seed)
     p = np.clip(np.rint(rng.normal(0, 31 / 5.0, size=(256, 4))), -13, 13).astype(np.int8)
     same = (p[:, 0] == p[:, 2]) & (p[:, 1] == p[:, 3])
