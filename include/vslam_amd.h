@@ -86,6 +86,11 @@ const int8_t *vslam_brief_pattern_31(void);
  *       whose selection needs more than were evaluated is redone with all of them, so the value changes speed, never
  *       results (0 = always everything; a small value forces the redo: a test knob).                              */
 #define VSLAM_OPT_CORNER_WINDOW_PCT 5
+/*   VSLAM_OPT_RANSAC_MIN_ITEMS  8 (default) .. 0: RansacFilter::min_items.  initialize_sets draws min_items indices
+ *       without replacement into sets that are 8 wide whatever min_items is (src/RansacFilter.cpp:17,22): entries
+ *       min_items .. 7 stay 0 and find_fundamental uses all 8 (:49-53).  Values above 8 overrun the set in the
+ *       reference and are rejected here.                                                                          */
+#define VSLAM_OPT_RANSAC_MIN_ITEMS 6
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

@@ -3,7 +3,7 @@
 // raw file, and dumps everything it computed so the Python test can compare with the oracle.
 //
 // usage: adapter_demo <in.bin> <out.bin>
-//   in : int32 w, h, max_corners, hyp, seed ; then 2 BGR frames (h*w*3 bytes each) ; 1024 int8 pattern
+//   in : int32 w, h, max_corners, hyp, seed ; then 2 BGR frames (h*w*3 bytes each) ; optionally a 1024 int8 pattern
 //   out: flat int32/float32 records, see the writes below
 #include <cmath>
 #include <cstdio>
@@ -27,8 +27,11 @@ int main(int argc, char **argv) {
         b.resize((size_t)w * h * 3);
         if (fread(b.data(), 1, b.size(), fi) != b.size()) return 3;
     }
-    vslam::settings().brief_pattern.resize(1024);
-    if (fread(vslam::settings().brief_pattern.data(), 1, 1024, fi) != 1024) return 3;
+    // an optional 1024-byte table after the frames; without one the adapters' default is used: ORB's learned table
+    {
+        std::vector<s8> table(1024);
+        if (fread(table.data(), 1, 1024, fi) == 1024) vslam::settings().brief_pattern = table;
+    }
     fclose(fi);
     vslam::settings().max_corners = maxc;
 
@@ -223,6 +226,24 @@ int main(int argc, char **argv) {
         cv::Point2f pp(3.f, 4.f);
         ok &= (ABS(neg) == 2.5f && P(pp, 1) == 4.f) ? 1 : 0;
         wr_i(fo, ok);
+    }
+    // --- RansacFilter(min_items < 8): 5 indices drawn into 8-wide sets (src/RansacFilter.cpp:17,22), then the hypothesis loop
+    {
+        RansacFilter rf5(5, 64, 10);
+        rf5.set_seed(0xABCD);
+        std::vector<bool> in5;
+        cv::Mat F5;
+        rf5.find_fundamental(frames[0].points, frames[1].points, matches, in5, F5);
+        wr(fo, F5.ptr<float>(), 36);
+        int cnt = 0;
+        for (size_t k = 0; k < in5.size(); k++) cnt += in5[k] ? 1 : 0;
+        wr_i(fo, cnt);
+        int threw = 0;
+        try {
+            RansacFilter rf9(9, 64, 10);
+            rf9.find_fundamental(frames[0].points, frames[1].points, matches, in5, F5);
+        } catch (const std::invalid_argument &) { threw = 1; }
+        wr_i(fo, threw);
     }
     fclose(fo);
     for (auto &fr : frames) free(fr.kdtree.root);    // src/vslam.cpp:295-297

@@ -26,8 +26,7 @@ def test_cpp_surfaces_match_oracle(oracle, tmp_path):
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
         f.write(struct.pack("5i", w, h, maxc, H, seed))
-        f.write(bgr.tobytes())
-        f.write(pat.tobytes())
+        f.write(bgr.tobytes())       # no table follows: the adapters' default, ORB's learned table (= pat), is what is checked
     subprocess.run([exe, fin, fout], check=True, timeout=120)
     buf = open(fout, "rb").read()
     off = 0
@@ -106,4 +105,10 @@ def test_cpp_surfaces_match_oracle(oracle, tmp_path):
     take(np.int32, 1)                      # whether malloc really handed the old address back (usually 1; informational)
     # node-pointer overloads == device entry points; ABS / P macros
     assert int(take(np.int32, 1)[0]) == 1
+    # RansacFilter(5, 64, 10): sets of 5 drawn indices + three zeros, the reference's hypothesis loop on them
+    sets5 = oracle.ransac_sets(0xABCD, k, 64, min_items=5)
+    r5 = oracle.find_fundamental(ex[0]["xy"], ex[1]["xy"], matches, sets5, 10.0)
+    assert np.array_equal(take(np.float32, 9).view(np.uint32), r5["F"].view(np.uint32))
+    assert int(take(np.int32, 1)[0]) == r5["count"]
+    assert int(take(np.int32, 1)[0]) == 1          # min_items = 9 overruns the sets in the reference: refused
     assert off == len(buf)

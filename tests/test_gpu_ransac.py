@@ -71,6 +71,50 @@ def test_sets_bit_exact(ctx, oracle, H):
             assert not got[b].any()
 
 
+@pytest.mark.parametrize("mi", [0, 1, 5, 7])
+def test_sets_with_fewer_than_eight_items(ctx, oracle, mi):
+    """RansacFilter(min_items < 8): the reference draws min_items indices into 8-wide sets (src/RansacFilter.cpp:17,22);
+    entries min_items .. 7 stay 0 and the generator advances min_items outputs per set.  Then the whole of
+    find_fundamental on such sets (every hypothesis also uses match 0, :49-53)."""
+    H = 96
+    ms = [8, 9, 150, 4000, 5, 3]
+    seeds = [11, 0x5EED0002, 12345, 0xFFFFFFFF, 77, 9]
+    s = torch.tensor(np.array(seeds, dtype=np.uint32).view(np.int32)).cuda()
+    m = torch.tensor(ms, dtype=torch.int32).cuda()
+    ctx.set_option(ctx.OPT_RANSAC_MIN_ITEMS, mi)
+    ctx.set_option(ctx.OPT_RANSAC_MIN_MATCHES, max(mi, 1))
+    try:
+        got = ctx.ransac_sets(s, m, H).cpu().numpy()
+        for b, (n, sd) in enumerate(zip(ms, seeds)):
+            if n >= mi and mi > 0:
+                assert np.array_equal(got[b], oracle.ransac_sets(sd, n, H, min_items=mi)), (mi, b)
+            else:
+                assert not got[b].any()
+            assert not got[b][:, mi:].any()
+        K, W, Hh = 160, 640, 480
+        sizes = [150, 40, 9] + ([6] if mi <= 5 else [])       # 6 matches: legal in the reference when min_items <= 6
+        xy1, xy2, pairs, mm = _batch(900 + mi, sizes, K, W, Hh)
+        sd2 = np.arange(5, 5 + len(sizes)).astype(np.uint32)
+        sets = ctx.ransac_sets(torch.from_numpy(sd2.view(np.int32)).cuda(), torch.from_numpy(mm).cuda(), H)
+        r = ctx.ransac_fundamental(torch.from_numpy(xy1).cuda(), torch.from_numpy(xy2).cuda(), torch.from_numpy(pairs).cuda(),
+                                   torch.from_numpy(mm).cuda(), sets, 10.0)
+        ctx.synchronize()
+        r = {k: v.cpu().numpy() for k, v in r.items()}
+        sets = sets.cpu().numpy()
+        for b in range(len(sizes)):
+            n = int(mm[b])
+            if mi > 0:
+                assert np.array_equal(sets[b], oracle.ransac_sets(int(sd2[b]), n, H, min_items=mi)), (mi, b)
+            ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], 10.0)
+            assert r["best"][b, 0] == ref["winner"] and r["best"][b, 1] == ref["count"], (mi, b)
+            if ref["winner"] >= 0:
+                assert np.array_equal(r["F"][b].view(np.uint32), ref["F"].view(np.uint32)), (mi, b)
+                assert np.array_equal(r["mask"][b, :n] != 0, ref["mask"][:n] != 0), (mi, b)
+    finally:
+        ctx.set_option(ctx.OPT_RANSAC_MIN_ITEMS, 8)
+        ctx.set_option(ctx.OPT_RANSAC_MIN_MATCHES, 8)
+
+
 def _zero_shift_rejections(seed, n, H):
     """Raw outputs that Lemire's test rejects if no earlier output was rejected (exact for the first one, which is all
     that is needed to know that a stream has rejections at all)."""

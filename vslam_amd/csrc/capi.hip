@@ -234,6 +234,11 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
         ctx->ransac_min_matches = value;
         return VSLAM_OK;
     }
+    if (option == VSLAM_OPT_RANSAC_MIN_ITEMS) {
+        VS_REQUIRE(ctx, value >= 0 && value <= VSLAM_SET_SIZE, VSLAM_ERR_INVALID);
+        ctx->ransac_min_items = value;
+        return VSLAM_OK;
+    }
     if (option == VSLAM_OPT_RANSAC_SOLVER) {
         VS_REQUIRE(ctx, value == 0 || value == 1, VSLAM_ERR_INVALID);
         ctx->ransac_solver = value;

@@ -42,6 +42,7 @@ struct vslam_ctx {
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     bool rbrief_table_ready = false; // transient: the rotated rBRIEF table of the coming describe call is already queued
     int ransac_min_matches = VSLAM_SET_SIZE;   // VSLAM_OPT_RANSAC_MIN_MATCHES
+    int ransac_min_items = VSLAM_SET_SIZE;     // VSLAM_OPT_RANSAC_MIN_ITEMS: indices drawn per 8-wide set
     int ransac_solver = 0;                      // VSLAM_OPT_RANSAC_SOLVER: 0 exact Jacobi replay, 1 Gram / MFMA (not bit-exact)
     int match_shape = 0;                        // VSLAM_OPT_MATCH_SHAPE: 0 by size, 1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows
     int corner_window_pct = 135;                // VSLAM_OPT_CORNER_WINDOW_PCT

@@ -95,7 +95,9 @@ __global__ __launch_bounds__(kSetThreads) void ransac_mt_kernel(const uint32_t *
 // one for about one pair in a hundred.  Then draws -> indices without replacement: available[r] = available.back();
 // pop_back() (RansacFilter.cpp:26-31) tracked as a <= 8-entry sparse overlay on the identity array.
 constexpr int kMapThreads = 1024;
-__global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *__restrict__ m_arr, int hyp, int nblk,
+// mi = RansacFilter::min_items: the reference draws min_items indices into sets that are 8 wide whatever min_items is
+// (src/RansacFilter.cpp:17,22): entries mi .. 7 stay 0, and a hypothesis consumes mi raw outputs (+ rejections).
+__global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *__restrict__ m_arr, int hyp, int nblk, int mi,
                                                                  const uint32_t *__restrict__ raw, int32_t *__restrict__ sets,
                                                                  uint32_t *__restrict__ draws, int32_t *__restrict__ errflag) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -103,9 +105,9 @@ __global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *
     int32_t *S = sets + (size_t)b * hyp * VSLAM_SET_SIZE;
     uint32_t *D = draws + (size_t)b * hyp * VSLAM_SET_SIZE;
     const uint32_t *R = raw + (size_t)b * nblk * kMtN;
-    const int total = hyp * VSLAM_SET_SIZE, avail = nblk * kMtN;
-    if (n < VSLAM_SET_SIZE) {   // reference: UB (distribution over (0,-1)); defined here as zeros
-        for (int i = tid; i < total; i += kMapThreads) S[i] = 0;
+    const int total = hyp * mi, avail = nblk * kMtN;
+    if (n < mi || n < 1 || mi == 0) {   // n < mi is UB in the reference (distribution over (0,-1)); defined here as zeros
+        for (int i = tid; i < hyp * VSLAM_SET_SIZE; i += kMapThreads) S[i] = 0;
         return;
     }
     __shared__ int s_first;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *
         }
         for (int t = lo + tid; t < total + rej; t += kMapThreads) {
             const int d = t - rej;
-            const uint32_t range = (uint32_t)(n - (d & 7));
+            const uint32_t range = (uint32_t)(n - (mi == VSLAM_SET_SIZE ? (d & 7) : d % mi));
             const uint64_t prod = (uint64_t)R[t] * (uint64_t)range;
             const uint32_t low = (uint32_t)prod;
             if (low < range && low < (0u - range) % range) atomicMin(&s_first, t);   // rejected: consumed, yields no draw
@@ -140,7 +142,11 @@ __global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *
         int cnt = 0, size = n;
 #pragma unroll
         for (int j = 0; j < VSLAM_SET_SIZE; j++) {
-            const int r = (int)D[(size_t)h * VSLAM_SET_SIZE + j];
+            if (j >= mi) {
+                S[(size_t)h * VSLAM_SET_SIZE + j] = 0;
+                continue;
+            }
+            const int r = (int)D[(size_t)h * mi + j];
             int v = r, lv = size - 1, slot = -1;
 #pragma unroll
             for (int k = 0; k < VSLAM_SET_SIZE; k++) {
@@ -2195,7 +2201,8 @@ int vs_launch_ransac_map(vslam_ctx *ctx, const int32_t *m, int batch, int hyp, c
     int rc = vs_device_errflag(ctx, &flag);
     if (rc) return rc;
     VsProfScope ps(ctx, "ransac_sets_kernel");
-    ransac_map_kernel<<<batch, kMapThreads, 0, ctx->stream>>>(m, hyp, vs_mt_blocks(hyp), raw, sets, draws, flag);
+    ransac_map_kernel<<<batch, kMapThreads, 0, ctx->stream>>>(m, hyp, vs_mt_blocks(hyp), ctx->ransac_min_items, raw, sets, draws,
+                                                              flag);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }

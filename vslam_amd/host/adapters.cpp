@@ -629,15 +629,31 @@ u32 RansacFilter::next_seed() {
 }
 
 namespace {
+// The reference draws min_items indices into sets that are 8 wide whatever min_items is (src/RansacFilter.cpp:17,22):
+// min_items < 8 leaves the other entries 0 (so every hypothesis also uses match 0), min_items > 8 writes past the set
+// (undefined), and fewer matches than min_items builds a distribution over (0, -1) (:24, undefined).
+int drawn_items(const RansacFilter &rf) { return rf.min_items < 0 ? 0 : rf.min_items; }
 void require_sets(const RansacFilter &rf, int n_matches) {
-    if (rf.min_items != VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: the device path draws 8-subsets (min_items == 8)");
-    if (n_matches < VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: fewer than 8 matches (undefined in the reference)");
+    if (rf.min_items > VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: min_items > 8 overruns the 8-wide sets (undefined in the reference)");
+    if (n_matches < std::max(drawn_items(rf), 1)) throw std::invalid_argument("RansacFilter: fewer matches than min_items (undefined in the reference)");
 }
+// the context's set-drawing and minimum-match options follow the filter for the duration of one adapter call
+struct FilterOptions {
+    explicit FilterOptions(const RansacFilter &rf) {
+        check(vslam_ctx_set_option(ctx(), VSLAM_OPT_RANSAC_MIN_ITEMS, drawn_items(rf)), "set_option");
+        check(vslam_ctx_set_option(ctx(), VSLAM_OPT_RANSAC_MIN_MATCHES, std::max(drawn_items(rf), 1)), "set_option");
+    }
+    ~FilterOptions() {
+        vslam_ctx_set_option(ctx(), VSLAM_OPT_RANSAC_MIN_ITEMS, VSLAM_SET_SIZE);
+        vslam_ctx_set_option(ctx(), VSLAM_OPT_RANSAC_MIN_MATCHES, VSLAM_SET_SIZE);
+    }
+};
 }  // namespace
 
 void RansacFilter::initialize_sets(const int n_matches) {
     require_sets(*this, n_matches);
     Lock lk(g_mu);
+    FilterOptions opts(*this);
     const size_t H = (size_t)max_iterations;
     Layout in, res, work;
     const size_t o_seed = in.add(4), o_m = in.add(4);
@@ -660,6 +676,7 @@ void RansacFilter::find_fundamental(const std::vector<cv::Point2f> &p1, const st
     const int H = max_iterations, M = (int)matches.size();
     require_sets(*this, M);   // initialize_sets(matches.size()), src/RansacFilter.cpp:38
     Lock lk(g_mu);
+    FilterOptions opts(*this);
     const int stride = (int)std::max(std::max(p1.size(), p2.size()), (size_t)M);
     Layout in, res, work;
     const size_t o_seed = in.add(4), o_m = in.add(4), o_xy1 = in.add(8 * (size_t)stride), o_xy2 = in.add(8 * (size_t)stride),
@@ -862,8 +879,9 @@ void match_features(const Frame &frame1, const Frame &frame2, RansacFilter &rf,
     const int n1 = (int)frame1.points.size(), n2 = (int)frame2.points.size();
     if (frame1.descriptors.rows != n1 || frame2.descriptors.rows != n2)
         throw std::invalid_argument("match_features: descriptors and points disagree");
-    if (rf.min_items != VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: the device path draws 8-subsets (min_items == 8)");
+    if (rf.min_items > VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: min_items > 8 overruns the 8-wide sets (undefined in the reference)");
     Lock lk(g_mu);
+    FilterOptions opts(rf);
     const int K = std::max(std::max(n1, n2), 1), H = rf.max_iterations;
     // knnMatch + ratio (src/Frame.cpp:83-94), then rf.find_fundamental (:97) with rf's seed, iterations and threshold,
     // then the inlier filter (:98-102) — one upload, the kernels chained on the device, one download
@@ -897,7 +915,8 @@ void match_features(const Frame &frame1, const Frame &frame2, RansacFilter &rf,
                                    c.work<float>(o_sum)),
           "ransac_fundamental");
     c.download();
-    if (*c.hout<int32_t>(o_m) < VSLAM_SET_SIZE) throw std::invalid_argument("RansacFilter: fewer than 8 matches (undefined in the reference)");
+    if (*c.hout<int32_t>(o_m) < std::max(drawn_items(rf), 1))
+        throw std::invalid_argument("RansacFilter: fewer matches than min_items (undefined in the reference)");
     vslam::detail::RansacAccess::store_sets(rf, c.hout<int32_t>(o_sets));
     const int32_t *best = c.hout<int32_t>(o_best);
     if (best[0] < 0) return;   // nothing accepted: F untouched, no inliers (src/RansacFilter.cpp:59-65, src/Frame.cpp:98)
