@@ -640,7 +640,7 @@ def main():
                                         "what": "VSLAM_OPT_RANSAC_ALL_SUMS: no bail-out, no screen: the count and residual sum of every hypothesis"}
             ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
             if kind != args.data:   # the timed batch itself was checked above; check this regime's output too
-                nchk = min(P, 4)
+                nchk = min(P, 24)
                 _, par = oracle_on_frames(frames[:nchk].cpu().numpy(), frames[P:P + nchk].cpu().numpy(),
                                           shard.pair_seeds(seed, lo, hi)[:nchk], K, H, thr, ho, 0, args.workload + ", " + kind + " data")
                 entry["parity_in_bench"] = par

@@ -169,6 +169,23 @@ int main(int argc, char **argv) {
         bool had7 = false;
         for (usize v : before) had7 |= v == 7;
         ok &= had7 ? 1 : 0;
+        // (0) the same kind of edit IN PLACE, on the vector the single-query table belongs to: the probe finds point 7 filed
+        // under a cell it no longer lies in and the query is answered by the device walk over the current coordinates;
+        // moved back, the answers are the original ones again
+        {
+            const cv::Point2f keep = pts[7];
+            pts[7] = cv::Point2f(keep.x + 300.f, keep.y + 200.f);
+            std::vector<usize> walked;
+            radius_search(t1.root, pts, q, walked, 2.f, 4.f, 0);
+            ok &= radius_search(t1, pts, q, 2) == walked ? 1 : 0;
+            const cv::Point2f q_new(pts[7].x + 0.5f, pts[7].y);        // where the point went: a cell nothing was filed under
+            walked.clear();
+            radius_search(t1.root, pts, q_new, walked, 2.f, 4.f, 0);
+            for (int rep = 0; rep < 300; rep++) (void)radius_search(t1, pts, q_new, 2);   // past the periodic full validation
+            ok &= radius_search(t1, pts, q_new, 2) == walked ? 1 : 0;
+            pts[7] = keep;
+            ok &= radius_search(t1, pts, q, 2) == before ? 1 : 0;
+        }
         // (1) move point 7 far away without rebuilding: the reference's search would now test the moved coordinates
         std::vector<cv::Point2f> moved = pts;
         moved[7] = cv::Point2f(pts[7].x + 500.f, pts[7].y + 500.f);

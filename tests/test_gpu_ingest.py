@@ -114,6 +114,32 @@ def test_capture_loop_records(oracle, tmp_path, monkeypatch):
     assert pairs == 0 and len((tmp_path / "none.bin").read_bytes()) == 40
 
 
+def test_capture_loop_from_a_pipe(tmp_path):
+    """A FIFO has no size and cannot be read at offsets: the loop streams it frame by frame and writes the same records as
+    from the regular file (a trailing partial frame is dropped there too)."""
+    import threading
+    clip = video(7, 93)
+    blob = clip.tobytes() + b"\x01" * 77
+    vid = tmp_path / "clip.bgr"
+    vid.write_bytes(blob)
+    assert run_sequence(vid, tmp_path / "file.bin", 3, 5) == (7, 6)
+    for batch in (3, 4):                       # 4: the stream ends exactly where a batch does
+        fifo = tmp_path / f"clip{batch}.fifo"
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(fifo, "wb") as f:
+                for i in range(0, len(blob), 100000):
+                    f.write(blob[i:i + 100000])
+        t = threading.Thread(target=feed)
+        t.start()
+        try:
+            assert run_sequence(fifo, tmp_path / f"pipe{batch}.bin", batch, 5) == (7, 6)
+        finally:
+            t.join(timeout=30)
+        assert (tmp_path / f"pipe{batch}.bin").read_bytes() == (tmp_path / "file.bin").read_bytes()
+
+
 def test_blank_frames_give_empty_records_whatever_the_batch(tmp_path, monkeypatch):
     """A dark / blank frame yields no corners, so both pairs it takes part in have fewer than 8 matches: winner -1,
     no matches, and F all zero in the record (the device leaves F untouched when nothing is accepted — stale values

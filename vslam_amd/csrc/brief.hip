@@ -423,7 +423,9 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
     }
     const int tiles_x = vs_div_up(w, tw), ntiles = tiles_x * vs_div_up(h, th);
     const size_t tile_lds = (size_t)(th + 2 * kRMax) * (tw + 2 * kRMax + 16);
-    const bool tiled = w % 16 == 0 && (reinterpret_cast<uintptr_t>(blurred) & 15) == 0 && tile_lds <= 64 * 1024 && !patch_form;
+    // the tile lists pack a keypoint as x | y << 16 (unpacked with & 0xFFFF and an arithmetic >> 16): x < 65536, y < 32768
+    const bool tiled = w % 16 == 0 && (reinterpret_cast<uintptr_t>(blurred) & 15) == 0 && tile_lds <= 64 * 1024 && !patch_form &&
+                       w <= 65536 && h <= 32768;
     int32_t *tile_start = nullptr, *tile_kp = nullptr;
     if (tiled) {
         int rc;

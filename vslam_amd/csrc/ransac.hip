@@ -1184,6 +1184,11 @@ constexpr int kRankThreads = 512;
 constexpr int kPilotHyps = kRankThreads / 64;
 constexpr int kCandMax = 8;
 constexpr float kCntTinyDD = 0x1p-120f;
+// __builtin_amdgcn_fcmpf takes LLVM's FCmpInst::Predicate numbering: 2 = ogt, 4 = olt, 9 = ueq, 12 = ult.  The
+// tiny-denominator guards below need ult (true for dd < 2^-120 and for NaN).  Builds from c89bef8 (round 2,
+// "counts first") up to cce43df (round 3, where the fix rode along in the bench-parity commit) passed 9 there, so the guard fired only on NaN or dd == 2^-120 exactly, and zero / denormal
+// a0^2 were certified through v_rcp_f32 instead of taking the exact path (test_tiny_denominators_take_the_exact_path).
+constexpr int kFcmpOGT = 2, kFcmpOLT = 4, kFcmpULT = 12;
 // A hypothesis as the counting loop reads it from LDS: F, lo, hi (+ 1 pad): kCntRec floats per hypothesis.  (Storing every
 // element of F twice spares the loop nine v_movs per hypothesis — the (f, f) operands of the packed instructions — but
 // costs 4 KiB per workgroup, which is the difference between two and three workgroups per CU.)
@@ -1304,8 +1309,8 @@ __device__ __forceinline__ void cnt_eval_pair(const CntRec &R, const v2f X1, con
     v2f g = cnt_cheap(R, X1, Y1, X2, Y2, dd);
     ddmin = fminf(ddmin, fminf(dd.x, dd.y));
     // v_cmp straight into a lane mask (llvm::CmpInst predicates: 4 = ordered <, 2 = ordered >)
-    unsigned long long ia = __builtin_amdgcn_fcmpf(g.x, R.lo, 4), oa = __builtin_amdgcn_fcmpf(g.x, R.hi, 2);
-    unsigned long long ib = __builtin_amdgcn_fcmpf(g.y, R.lo, 4), ob = __builtin_amdgcn_fcmpf(g.y, R.hi, 2);
+    unsigned long long ia = __builtin_amdgcn_fcmpf(g.x, R.lo, kFcmpOLT), oa = __builtin_amdgcn_fcmpf(g.x, R.hi, kFcmpOGT);
+    unsigned long long ib = __builtin_amdgcn_fcmpf(g.y, R.lo, kFcmpOLT), ob = __builtin_amdgcn_fcmpf(g.y, R.hi, kFcmpOGT);
     if (PARTIAL) {
         const bool in_a = ix < m, in_b = ix + 1 < m;
         const unsigned long long va = __ballot(in_a), vb = __ballot(in_b);
@@ -1350,7 +1355,7 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const float4 X1, 
     y2a.x = Y2.x; y2a.y = Y2.y; y2b.x = Y2.z; y2b.y = Y2.w;
     cnt_eval_pair<PARTIAL>(R, x1a, y1a, x2a, y2a, ix, m, c, u0, u1, ddmin, acc);
     cnt_eval_pair<PARTIAL>(R, x1b, y1b, x2b, y2b, ix + 2, m, c, u2, u3, ddmin, acc);
-    if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, 12) != 0ull) {   // 12 = unordered or <: some dd is zero / denormal (or NaN)
+    if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, kFcmpULT) != 0ull) {   // unordered or <: some dd is zero / denormal (or NaN)
         // nothing of this sub-block is certified: all of it is queued, and the hypothesis' cheap sum means nothing
         if (lane == 0) s_unk[hh] = 1;
         c = 0;
@@ -1568,10 +1573,10 @@ __global__ __launch_bounds__(256) void ransac_screen_kernel(
         for (int u = 0; u < kU; u++) g[u] = cnt_cheap(R[u], X1, Y1, X2, Y2, dd[u]);
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            const unsigned long long oa = __builtin_amdgcn_fcmpf(g[u].x, R[u].hi, 2), ob = __builtin_amdgcn_fcmpf(g[u].y, R[u].hi, 2);
+            const unsigned long long oa = __builtin_amdgcn_fcmpf(g[u].x, R[u].hi, kFcmpOGT), ob = __builtin_amdgcn_fcmpf(g[u].y, R[u].hi, kFcmpOGT);
             int p = __popcll(va & ~oa) + __popcll(vb & ~ob);
             // a zero / denormal (or NaN) dd: v_rcp_f32 is not a 1-ulp reciprocal there, nothing is certified
-            if (__builtin_amdgcn_fcmpf(fminf(dd[u].x, dd[u].y), kCntTinyDD, 12) != 0ull) p = n0;   // 12 = unordered or <
+            if (__builtin_amdgcn_fcmpf(fminf(dd[u].x, dd[u].y), kCntTinyDD, kFcmpULT) != 0ull) p = n0;   // unordered or <
             mine = lane == j + u ? p : mine;
         }
     }

@@ -412,8 +412,15 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
             // and the compiler, which has to assume that they complete out of order relative to each other, would wait for
             // EVERYTHING in flight (vmcnt(0): the next row's prefetch and this store's acknowledgement) in front of every row.
             // Unseen by it, the store only makes its waits for the loads longer than they need to be, never too short.
-            const uint8_t *rowp = a.gout + (size_t)gy * a.w;
+            // The scheme leans on gfx950 behaviour (one vmcnt for loads and stores, loads returning in order among
+            // themselves) and on nothing in this kernel reading gout back: any other target gets the plain store, and
+            // VSLAM_NO_GRAY_FUSION=1 (bgr2gray in front of the gray form) stays the A/B reference in the tests.
+            uint8_t *rowp = a.gout + (size_t)gy * a.w;
+#if defined(__gfx950__)
             asm volatile("global_store_dword %0, %1, %2" : : "v"(a.x), "v"(d1), "s"(rowp) : "memory");
+#else
+            *reinterpret_cast<uint32_t *>(rowp + a.x) = d1;
+#endif
         }
         // the neighbours' bytes; beyond the strip: the two pixels left of it (bytes 2, 3 of the dword a lane 0 wants) and the
         // two right of it (bytes 0, 1), converted when the wave started

@@ -166,14 +166,19 @@ struct DevTree {
     uint64_t hash = 0, stamp = 0;
     // Single radius queries (src/vslam.cpp:149 asks one per map point) are answered from a table the device built when
     // the tree was constructed — the tree's points filed by pixel cell, vslam_kdtree_cell_table — copied to the host
-    // once.  Valid for the very point vector the tree was built from (identity + sampled contents; an in-place edit of
-    // the points calls for construct_kdtree or vslam::forget_kdtree, as a changed tree does in the reference).
+    // once.  Valid for the very point vector the tree was built from.  Checked per query: the vector's identity, a
+    // sample of its contents, and that every probed point still lies in the cell it was filed under; checked in full
+    // (every point and every node's pt_index against the hash taken at build time) on the first query and then every
+    // kFullCheckEvery-th one.  A mismatch drops the table and the query takes the device path, which re-validates
+    // everything on every call.  An in-place edit of a point that no probe touches can therefore go unnoticed for at
+    // most kFullCheckEvery - 1 single queries; vslam::forget_kdtree drops the table at once.
     std::vector<uint32_t> cells;      // [slots][2]
     std::vector<int32_t> pre;         // pre-order position -> point index
     uint32_t cell_mask = 0;
     const void *pts_ptr = nullptr;
     size_t pts_size = 0;
     uint64_t pts_sample = 0;
+    uint32_t since_full_check = 0;    // single queries answered since the last full validation
     ~DevTree() {   // the block goes back to the pool, not to hipFree
         if (block) device().tree_blocks.push_back(Block{block, block_bytes});
     }
@@ -182,6 +187,7 @@ std::map<const void *, std::shared_ptr<DevTree>> g_trees;
 void drop_cached_trees() { g_trees.clear(); }
 uint64_t g_stamp = 0;
 constexpr size_t kTreeCache = 64;
+constexpr uint32_t kFullCheckEvery = 256;
 
 inline uint64_t mix(uint64_t h, uint64_t v) {
     h ^= v;
@@ -318,6 +324,7 @@ bool cell_query(const DevTree &t, const std::vector<cv::Point2f> &points, const 
                     const uint32_t rank = T[2 * slot + 1];
                     const int32_t idx = t.pre[rank];
                     const cv::Point2f &pt = points[(size_t)idx];
+                    if ((int)std::floor(pt.x) != cx || (int)std::floor(pt.y) != cy) return false;   // moved since it was filed
                     const float dx = q.x - pt.x, dy = q.y - pt.y;
                     const float xx = dx * dx, yy = dy * dy;
                     if (xx + yy < r2) {   // strict, src/KDTree.cpp:161
@@ -567,6 +574,12 @@ std::vector<usize> radius_search(const frame_kdtree kdtree, const std::vector<cv
         Lock lk(g_mu);
         auto it = g_trees.find(kdtree.root);
         std::vector<usize> out;
+        if (it != g_trees.end() && !it->second->cells.empty()) {
+            DevTree &t = *it->second;
+            if (t.since_full_check == 0 && (points.size() < (size_t)t.count || t.hash != hash_tree(kdtree, t.count, points)))
+                t.cells.clear();   // edited since the build: the device path below sees the current points and nodes
+            if (++t.since_full_check >= kFullCheckEvery) t.since_full_check = 0;
+        }
         if (it != g_trees.end() && cell_query(*it->second, points, query_pt, radius, out)) return out;
     }
     return vslam::radius_search_batch(kdtree, points, std::vector<cv::Point2f>{query_pt}, radius)[0];

@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -154,7 +155,10 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
     vslam_ctx *ctx = detail::context();
     const int B = o.batch_frames, K = o.max_corners;
     const size_t frame_bytes = (size_t)o.width * o.height * 3;
-    uint64_t file_frames = (uint64_t)st.st_size / frame_bytes;   // a trailing partial frame is dropped
+    // A regular file is read at offsets by several threads; a FIFO, pipe or /dev/stdin reports st_size 0 and cannot be
+    // read at offsets: it is streamed with read() by the one reader thread until it ends.
+    const bool regular = S_ISREG(st.st_mode);
+    uint64_t file_frames = regular ? (uint64_t)st.st_size / frame_bytes : UINT64_MAX;   // a trailing partial frame is dropped
     if (o.max_frames && file_frames > o.max_frames) file_frames = o.max_frames;
     int readers = o.reader_threads;
     if (const char *e = std::getenv("VSLAM_READER_THREADS")) readers = std::atoi(e);   // tuning
@@ -204,7 +208,24 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
                 }
                 {   // frames read_total .. of the file -> slots have .. of the buffer, shared out over the reader threads
                     const uint64_t left = file_frames - read_total;
-                    const int want = (int)std::min<uint64_t>((uint64_t)(B - have), left);
+                    int want = (int)std::min<uint64_t>((uint64_t)(B - have), left);
+                    if (!regular) {   // sequential stream: whole frames until end of input
+                        int j = 0;
+                        for (; j < want; j++) {
+                            uint8_t *dst = hbuf[b] + frame_bytes * (size_t)(have + j);
+                            size_t got = 0;
+                            while (got < frame_bytes) {
+                                const ssize_t r = ::read(in, dst + got, frame_bytes - got);
+                                if (r < 0 && errno == EINTR) continue;
+                                if (r < 0) throw std::runtime_error("read failed");
+                                if (r == 0) break;
+                                got += (size_t)r;
+                            }
+                            if (got < frame_bytes) break;   // end of input (a trailing partial frame is dropped)
+                        }
+                        if (j < want) file_frames = read_total + (uint64_t)j;
+                        want = j;
+                    }
                     std::atomic<bool> failed{false};
                     auto share = [&](int t) {
                         for (int j = t; j < want; j += readers) {
@@ -221,10 +242,20 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
                             }
                         }
                     };
-                    std::vector<std::thread> pool;
-                    for (int t = 1; t < readers && t < want; t++) pool.emplace_back(share, t);
-                    share(0);
-                    for (auto &th : pool) th.join();
+                    if (regular) {
+                        // joined on every path out of this block: a thread that fails to start (std::system_error) must
+                        // reach the catch below, not std::terminate through ~thread of the ones already running
+                        struct Pool {
+                            std::vector<std::thread> threads;
+                            ~Pool() {
+                                for (auto &th : threads)
+                                    if (th.joinable()) th.join();
+                            }
+                        } pool;
+                        pool.threads.reserve((size_t)readers);
+                        for (int t = 1; t < readers && t < want; t++) pool.threads.emplace_back(share, t);
+                        share(0);
+                    }
                     if (failed) throw std::runtime_error("read failed (file truncated while in use?)");
                     have += want;
                     read_total += (uint64_t)want;
