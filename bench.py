@@ -79,90 +79,150 @@ FP32_PEAK_TFLOPS = 157.3                       # FMA counted as 2: 256 CUs x 4 S
 INT32_PEAK_TOPS = FP32_PEAK_TFLOPS / 2.0       # one 32-bit integer op per lane and clock
 INT8_MFMA_PEAK_TOPS = 5000.0                   # dense int8 MFMA (MI355X_MICROARCH.md: about 2x the 2.5 PFLOP/s bf16 rate)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
+PROFILE_TAG = "r04"
+SQ_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.csv")
+PMC_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_hbm_traffic.csv")
+STAMP_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_source_stamp.txt")
+SOLVE_WORK = os.path.join(ROOT, "profiles", PROFILE_TAG + "_solve_work.json")
+
+
+def solve_flops():
+    """Floating-point operations of one compute_fundamental (src/RansacFilter.cpp:69-103) on the bench's data, COUNTED:
+    tools/solve_flops.py has the oracle count Jacobi visits and rotations of both SVDs over 24 576 hypotheses and applies
+    the per-visit / per-rotation operation counts written out there (profiles/r04_solve_work.json; SURVEY 8(d) guessed 3000)."""
+    try:
+        with open(SOLVE_WORK) as fh:
+            return float(json.load(fh)["flop_per_hypothesis"])
+    except (OSError, KeyError, ValueError):
+        return 14850.0
+
+
 ALG_OPS = {
-    # kernel: (what one unit is, algorithmic ops per unit (SURVEY.md 8d), kind, peak in Tops/s)
+    # kernel: (what one unit is, algorithmic ops per unit, kind, peak in Tops/s)
     # ransac_count_kernel has no entry: it decides most (hypothesis, match) pairs without evaluating them (bail-out),
     # so SURVEY's H x M x 40 flop is not work it performs and a flop fraction of it would mean nothing
     "ransac_score_kernel": ("(hypothesis, match) residual evaluations", 40.0, "flop", FP32_PEAK_TFLOPS),
-    "ransac_solve_kernel": ("hypotheses (two SVDs, about 3000 flop each: SURVEY.md 8d)", 3000.0, "flop", FP32_PEAK_TFLOPS),
+    "ransac_solve_kernel": ("hypotheses (A, two Jacobi SVDs, F = U diag Vt: counted per visit and rotation, tools/solve_flops.py -> "
+                            "profiles/" + PROFILE_TAG + "_solve_work.json; about half of them f64)", solve_flops(), "flop", FP32_PEAK_TFLOPS),
     "min_eigen_kernel": ("pixels (stencil work, about 60 int/flop per pixel: SURVEY.md 8d)", 60.0, "flop", FP32_PEAK_TFLOPS),
     # the matcher forms each 256-bit Hamming distance as an int8 dot product on the matrix cores: 256 multiply-adds
     "match_knn2_kernel": ("(query, train) descriptor pairs", 512.0, "int8 op (256 multiply-adds on MFMA)", INT8_MFMA_PEAK_TOPS),
 }
-PROFILE_TAG = "r03"
-SQ_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.csv")
-PMC_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_hbm_traffic.csv")
-STAMP_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_source_stamp.txt")
+
+
+def kernel_sources():
+    """{timing slot: source file} for every __global__ kernel under vslam_amd/csrc."""
+    import re
+    from vslam_amd.profnames import slot_of
+    out = {}
+    d = os.path.join(ROOT, "vslam_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith(".hip"):
+            with open(os.path.join(d, name)) as fh:
+                for k in re.findall(r"__global__[^;{]*?\b([a-z][a-z0-9_]*_kernel)\s*\(", fh.read(), flags=re.S):
+                    out[slot_of(k)] = name
+    return out
 
 
 def source_stamp():
-    """Hash of the kernel sources: instruction counts per wave and HBM traffic per launch are properties of a BUILD, so
-    the committed counter summaries (tools/prof_all.sh writes this stamp beside them) only describe the running library
-    when the stamps agree."""
+    """One hash per kernel source (+ one over the shared headers): instruction counts per wave and HBM traffic per launch are
+    properties of a BUILD, so a kernel's committed counter rows (tools/prof_all.sh writes these stamps beside them) describe
+    the running library exactly when the stamp of the file that defines the kernel, and of the headers, still agree."""
     import hashlib
-    hsh = hashlib.sha256()
     d = os.path.join(ROOT, "vslam_amd", "csrc")
+    out, hdr = {}, hashlib.sha256()
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(d, name), "rb") as fh:
-                hsh.update(name.encode() + b"\0" + fh.read())
-    return hsh.hexdigest()[:16]
+        with open(os.path.join(d, name), "rb") as fh:
+            data = fh.read()
+        if name.endswith(".h"):
+            hdr.update(name.encode() + b"\0" + data)
+        elif name.endswith(".hip"):
+            out[name] = hashlib.sha256(data).hexdigest()[:16]
+    out["headers"] = hdr.hexdigest()[:16]
+    return out
 
 
-def counters_current():
-    try:
-        with open(STAMP_FILE) as fh:
-            return fh.read().split()[0] == source_stamp()
-    except (OSError, IndexError):
+_STAMP_CACHE = {}
+
+
+def counters_current(kernel=None):
+    """Do the committed counter rows of `kernel` (a timing slot; None: of every kernel) come from this build's sources?"""
+    if "now" not in _STAMP_CACHE:
+        try:
+            with open(STAMP_FILE) as fh:
+                _STAMP_CACHE["then"] = json.load(fh)
+        except (OSError, ValueError):
+            _STAMP_CACHE["then"] = {}
+        _STAMP_CACHE["now"] = source_stamp()
+        _STAMP_CACHE["src"] = kernel_sources()
+    then, now = _STAMP_CACHE["then"], _STAMP_CACHE["now"]
+    if not then or then.get("headers") != now["headers"]:
         return False
+    if kernel is None:
+        return then == now
+    f = _STAMP_CACHE["src"].get(kernel)
+    return f is not None and then.get(f) == now.get(f)
+
+
+def _profile_row(path, kernel):
+    import csv
+    from vslam_amd.profnames import slot_of
+    if not os.path.exists(path) or not counters_current(kernel):
+        return None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if slot_of(r["kernel"]) == kernel:
+                return r
+    return None
 
 
 def sq_counters(kernel):
-    """(waves per launch, VALU instructions per wave) from the committed rocprofv3 SQ counter summary."""
-    import csv
-    import re
-    if not os.path.exists(SQ_PROFILE) or not counters_current():
+    """(waves per launch, VALU instructions per wave, VALU-busy cycles per wave) from the committed rocprofv3 SQ summary."""
+    r = _profile_row(SQ_PROFILE, kernel)
+    if r is None:
         return None
-    with open(SQ_PROFILE) as f:
-        for r in csv.DictReader(f):
-            if re.sub(r"_(v4|stream|tiered|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
-                return float(r["waves_per_launch"]), float(r["valu_insts_per_wave"])
-    return None
+    return float(r["waves_per_launch"]), float(r["valu_insts_per_wave"]), float(r.get("valu_busy_cycles_per_wave") or 0.0)
+
+
+SIMDS, CLOCK_GHZ = 256 * 4, 2.4
 
 
 def arithmetic_view(kernel, units, ms_per_launch, full_batch):
     """flops / issue fractions of one launch of `kernel` that processed `units` units of work."""
-    if kernel not in ALG_OPS or ms_per_launch <= 0:
+    if ms_per_launch <= 0:
         return None
-    what, ops, kind, peak = ALG_OPS[kernel]
     t = ms_per_launch * 1e-3
-    tops = units * ops / t / 1e12
-    view = {"unit_of_work": what, "units_per_launch": units, "ops_per_unit": ops, "op_kind": kind,
-            "achieved": tops, "peak": peak, "unit": "Tops/s (vector ALU peak for this kind of op)",
-            "frac": tops / peak}
+    view = {}
+    if kernel in ALG_OPS:
+        what, ops, kind, peak = ALG_OPS[kernel]
+        tops = units * ops / t / 1e12
+        view = {"unit_of_work": what, "units_per_launch": units, "ops_per_unit": ops, "op_kind": kind,
+                "achieved": tops, "peak": peak, "unit": "Tops/s (vector ALU peak for this kind of op)",
+                "frac": tops / peak}
     sq = sq_counters(kernel) if full_batch else None
     if sq:
-        waves, insts = sq
+        waves, insts, busy = sq
         ginst = waves * insts / t / 1e9
         view["valu_issue"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU wave-instructions/s",
                               "frac": ginst / VALU_PEAK_GINST, "waves_per_launch": waves, "valu_insts_per_wave": insts,
                               "source": os.path.relpath(SQ_PROFILE, ROOT)}
-    return view
+        if busy > 0:
+            # rocprof's VALUBusy: cycles the launch's vector instructions occupy the SIMDs' vector pipes / pipe cycles available
+            frac = waves * busy / (SIMDS * t * CLOCK_GHZ * 1e9)
+            view["valu_busy"] = {"frac": frac, "valu_busy_cycles_per_wave": busy,
+                                 "what": "SQ_ACTIVE_INST_VALU x 4 summed over the launch's waves / (1024 SIMDs x launch time x 2.4 GHz): "
+                                         "the share of the chip's vector-pipe time this kernel's instruction mix occupies (f64 and packed "
+                                         "instructions hold the pipe longer than the 2 cycles the issue rate assumes)"}
+    return view or None
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/, C3 batch of 256 pairs);
     bench.py cannot collect PMC counters on itself."""
-    import csv
-    import re
-    path = PMC_PROFILE
-    if not os.path.exists(path) or not counters_current():
+    r = _profile_row(PMC_PROFILE, kernel)
+    if r is None:
         return None
-    with open(path) as f:
-        for r in csv.DictReader(f):
-            if re.sub(r"_(v4|stream|tiered|lds|mfma)_kernel$", "_kernel", r["kernel"]) == kernel:
-                return (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
-    return None
+    return (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
 
 
 def _cpu_worker(args):
@@ -538,11 +598,22 @@ def main():
                             "alg_GBps": alg / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
         kernels.sort(key=lambda k: -k["ms_per_launch"] * k["launches_per_step"])
         top = kernels[0]
-        traffic = pmc_traffic(top["kernel"]) if (args.workload == "C3" and P == WORKLOADS["C3"][4]) else None
-        result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                              "avg_launch_ms": top["ms_per_launch"]}
         full_batch = args.workload == "C3" and P == WORKLOADS["C3"][4]   # the shape the committed counter passes ran
+        if full_batch:   # every kernel of the step against the vector-pipe and HBM ceilings, where this build's counter rows exist
+            for k in kernels:
+                sq = sq_counters(k["kernel"])
+                t_ = k["ms_per_launch"] * 1e-3
+                if sq and t_ > 0:
+                    k["valu_issue_frac"] = sq[0] * sq[1] / t_ / 1e9 / VALU_PEAK_GINST
+                    if sq[2] > 0:
+                        k["valu_busy_frac"] = sq[0] * sq[2] / (SIMDS * t_ * CLOCK_GHZ * 1e9)
+                tr = pmc_traffic(k["kernel"])
+                if tr is not None:
+                    k["hbm_traffic_bytes_per_launch"] = tr
+                    k["hbm_traffic_frac_of_peak"] = tr / t_ / 1e9 / HBM_PEAK_GBS if t_ > 0 else None
+        traffic = pmc_traffic(top["kernel"]) if full_batch else None
+        hbm_view = {"achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS,
+                    "alg_bytes_per_launch": top["alg_bytes_per_launch"]}
 
         def units_of(kname):   # units of work one launch processes (M = inlier matches, a lower bound of the evaluated ones)
             if kname == "min_eigen_kernel":
@@ -553,14 +624,29 @@ def main():
 
         by_name = {k["kernel"]: k for k in kernels}
         av = arithmetic_view(top["kernel"], units_of(top["kernel"]), top["ms_per_launch"], full_batch)
-        if av:
-            result["roofline"]["arithmetic"] = av
-            why = ("a streaming stencil (cvtColor, integer Sobel and a certified f32 response for every pixel) held by its vector "
-                   "arithmetic, not by bandwidth"
-                   if top["kernel"] == "min_eigen_kernel" else
-                   "VALU-bound by construction (SURVEY.md 8d): its compulsory bytes are a rounding error next to its arithmetic")
-            result["roofline"]["note"] = (why + ", so the HBM fraction is small by design; `arithmetic` gives its algorithmic op rate "
-                                          "against the vector ALU peak and its issued VALU instructions against the chip's issue rate")
+        # The binding ceiling of the dominant kernel.  Both candidates for that place (ransac_solve, min_eigen) are held by
+        # the vector pipe, not by bandwidth: the headline fraction is the vector-instruction issue rate --
+        # waves x instructions per wave (committed SQ counters of this build) / this run's launch time, against the chip's
+        # 1228.8 G wave-instructions/s -- with the pipe-occupancy, flop and HBM views beside it.  Without counter rows
+        # of this build (other shapes, changed sources) only the HBM view can be formed and is what is reported.
+        if av and "valu_issue" in av:
+            vi = av["valu_issue"]
+            result["roofline"] = {"kernel": top["kernel"], "bound": "valu", "achieved": vi["achieved"], "peak": vi["peak"],
+                                  "unit": vi["unit"], "frac": vi["frac"], "traffic": traffic, "avg_launch_ms": top["ms_per_launch"],
+                                  "how": f"{vi['waves_per_launch']:.0f} waves x {vi['valu_insts_per_wave']:.0f} VALU instructions per wave "
+                                         f"({vi['source']}) / {top['ms_per_launch']:.4f} ms / 1e6 = achieved; peak = 1024 SIMDs x 2.4 GHz / 2 "
+                                         "cycles per wave instruction",
+                                  "valu_busy": av.get("valu_busy"), "hbm": hbm_view,
+                                  "flops": {k: av[k] for k in ("unit_of_work", "units_per_launch", "ops_per_unit", "op_kind", "achieved",
+                                                               "peak", "unit", "frac") if k in av} or None}
+        else:
+            result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                                  "avg_launch_ms": top["ms_per_launch"],
+                                  "note": "no counter rows of this build and shape under profiles/: only the bandwidth view can be formed; "
+                                          "the kernel is bound by its vector arithmetic (DESIGN.md 5)"}
+            if av:
+                result["roofline"]["arithmetic"] = av
         if "match_knn2_kernel" in by_name:   # north_star names the match kernel: always report it
             mk = by_name["match_knn2_kernel"]
             mv = arithmetic_view("match_knn2_kernel", units_of("match_knn2_kernel"), mk["ms_per_launch"], full_batch)
@@ -579,8 +665,9 @@ def main():
                                           "traffic": pmc_traffic(st["kernel"]) if (args.workload == "C3" and P == WORKLOADS["C3"][4]) else None,
                                           "avg_launch_ms": st["ms_per_launch"]}
         result["counter_profiles"] = {"tag": PROFILE_TAG, "match_this_build": counters_current(),
-                                      "note": "traffic / valu_issue come from the committed rocprofv3 PMC summaries and are omitted (null) "
-                                              "unless their source stamp equals this build's"}
+                                      "dominant_kernel_rows_match": counters_current(top["kernel"]),
+                                      "note": "traffic / valu_issue / valu_busy come from the committed rocprofv3 PMC summaries and are "
+                                              "omitted (null) for a kernel whose source file, or the shared headers, changed since"}
         result["kernels"] = kernels
         result["profile_pass_ms_per_step"] = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels)
 

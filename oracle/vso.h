@@ -72,6 +72,7 @@ int vso_ransac_sets(uint32_t seed, int n_matches, int min_items, int H, int32_t 
 /* cv::SVDecomp(A, w, u, vt, MODIFY_A|FULL_UV) for CV_32F, OpenCV 4.x built-in one-sided
  * Jacobi (modules/core/src/lapack.cpp JacobiSVDImpl_ / _SVDcompute). A is m x n
  * row-major; w has min(m,n); u is m x m; vt is n x n (FULL_UV).                      */
+int vso_compute_fundamental_work(const float *p1_set, const float *p2_set, int n_set, float *F, int32_t *work);
 int vso_svd32f_full(const float *A, int m, int n, float *w, float *u, float *vt);
 /* compute_fundamental: src/RansacFilter.cpp:69-103 (8 x 2 floats each set).         */
 int vso_compute_fundamental(const float *p1_set, const float *p2_set, int n_set, float *F);

@@ -27,7 +27,7 @@ namespace {
 struct P2 { float x, y; };
 
 // src/RansacFilter.cpp:69-103
-void compute_fundamental(const P2 *p1_set, const P2 *p2_set, int N, float *F_out) {
+void compute_fundamental(const P2 *p1_set, const P2 *p2_set, int N, float *F_out, int32_t *work = nullptr) {
     std::vector<float> A((size_t)N * 9);
     for (int i = 0; i < N; i++) {
         const float u1 = p1_set[i].x, v1 = p1_set[i].y;
@@ -39,11 +39,13 @@ void compute_fundamental(const P2 *p1_set, const P2 *p2_set, int N, float *F_out
     }
     std::vector<float> D(9), U((size_t)N * N), Vt(81);
     vso::svd32f_full(A.data(), N, 9, D.data(), U.data(), Vt.data());   // :94
+    if (work) { work[0] = vso::g_last_sweeps; work[1] = vso::g_last_visits; work[2] = vso::g_last_rotations; }
     float F0[9];
     std::memcpy(F0, &Vt[8 * 9], sizeof(F0));                            // V_t.row(8).reshape(0,3), :95
 
     float D3[3], U3[9], Vt3[9];
     vso::svd32f_full(F0, 3, 3, D3, U3, Vt3);                            // :98
+    if (work) { work[3] = vso::g_last_sweeps; work[4] = vso::g_last_visits; work[5] = vso::g_last_rotations; }
     D3[2] = 0;                                                          // :99
 
     // temp_F = U * diag(D) * V_t (:101): two 3x3 float products through the small-matrix path
@@ -119,6 +121,14 @@ int vso_compute_fundamental(const float *p1_set, const float *p2_set, int n_set,
     if (!p1_set || !p2_set || n_set <= 0 || n_set >= 9 || !F) return -1;
     compute_fundamental(reinterpret_cast<const P2 *>(p1_set), reinterpret_cast<const P2 *>(p2_set),
                         n_set, F);
+    return 0;
+}
+
+// compute_fundamental + what its two Jacobi SVDs did: work[6] = (sweeps, (i, j) visits, rotations) of the 8x9 system,
+// then of the 3x3 one.  For tools/solve_flops.py (operation counts of the solver; sweeps per hypothesis).
+int vso_compute_fundamental_work(const float *p1_set, const float *p2_set, int n_set, float *F, int32_t *work) {
+    if (!p1_set || !p2_set || n_set <= 0 || n_set >= 9 || !F || !work) return -1;
+    compute_fundamental(reinterpret_cast<const P2 *>(p1_set), reinterpret_cast<const P2 *>(p2_set), n_set, F, work);
     return 0;
 }
 

@@ -31,6 +31,9 @@
 
 namespace vso {
 
+// what the last jacobi_svd32f call on this thread did (tools/solve_flops.py counts the solver's work with it)
+thread_local int g_last_sweeps = 0, g_last_visits = 0, g_last_rotations = 0;
+
 double pinned_hypot(double a, double b) {
 #ifdef VSO_LIBM_HYPOT
     return std::hypot(a, b);
@@ -75,14 +78,18 @@ void jacobi_svd32f(float *At, size_t astep, float *_W, float *Vt, size_t vstep, 
         }
     }
 
+    g_last_sweeps = g_last_visits = g_last_rotations = 0;
     for (iter = 0; iter < max_iter; iter++) {
         bool changed = false;
+        g_last_sweeps++;
         for (i = 0; i < n - 1; i++)
             for (j = i + 1; j < n; j++) {
                 float *Ai = At + i * astep, *Aj = At + j * astep;
                 double a = W[i], p = 0, b = W[j];
                 for (k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+                g_last_visits++;
                 if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
+                g_last_rotations++;
 
                 p *= 2;
                 double beta = a - b, gamma = pinned_hypot((double)p, beta);

@@ -3,28 +3,26 @@
 
 usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv>
 Applies the calibration MI355X_MICROARCH.md prescribes: the factor that makes the known-size
-pmc_calib_copy{4,16}_kernel (1 GiB read, 1 GiB written) come out right is applied per access width
-(4-byte-per-lane kernels use the copy4 factor, 16-byte ones the copy16 factor)."""
+pmc_calib_copy{4,16}_kernel (1 GiB read, 1 GiB written) come out right (the same for 4 and 16 bytes per lane:
+FETCH_SIZE x 2, WRITE_SIZE x 1).  Every kernel of the library is listed (vslam_amd/profnames.py)."""
 import csv
-import re
+import os
 import sys
 from collections import defaultdict
 
-NAME = re.compile(r"((?:bgr2gray|min_eigen|corner_[a-z]+|gaussian7|keypoint_border|rbrief|kdtree_[a-z]+|match_[a-z0-9]+|"
-                  r"ransac_[a-z]+|pmc_calib_copy\d+)(?:_v4|_stream|_tiered|_lds|_rotate|_mfma)?_kernel)")
-WIDE = {}   # 16 B/lane side: write
-# (calibration shows the same factors for 4 B and 16 B per lane: FETCH_SIZE x2, WRITE_SIZE x1)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from vslam_amd.profnames import kernel_id  # noqa: E402
 
 
 def load(path):
     tot, cnt = defaultdict(float), defaultdict(int)
     with open(path) as f:
         for r in csv.DictReader(f):
-            m = NAME.search(r["Kernel_Name"])
-            if not m:
+            k = kernel_id(r["Kernel_Name"])
+            if not k:
                 continue
-            tot[m.group(1)] += float(r["Counter_Value"])
-            cnt[m.group(1)] += 1
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
     return {k: tot[k] / cnt[k] for k in tot}, cnt
 
 
@@ -40,10 +38,9 @@ def main(fetch_csv, write_csv, out):
         w.writerow(["kernel", "launches", "FETCH_SIZE_KiB_per_launch", "WRITE_SIZE_KiB_per_launch",
                     "read_factor", "write_factor", "hbm_read_MB_per_launch", "hbm_write_MB_per_launch"])
         for k in sorted(fe, key=lambda k: -(fe[k] + wr.get(k, 0))):
-            rf = cal["pmc_calib_copy16_kernel"][0] if WIDE.get(k) == "r" or "copy16" in k else cal["pmc_calib_copy4_kernel"][0]
-            wf = cal["pmc_calib_copy16_kernel"][1] if WIDE.get(k) == "w" or "copy16" in k else cal["pmc_calib_copy4_kernel"][1]
-            w.writerow([k, n[k], f"{fe[k]:.1f}", f"{wr.get(k, 0):.1f}", f"{rf:.3f}", f"{wf:.3f}",
-                        f"{fe[k] * 1024 * rf / 1e6:.2f}", f"{wr.get(k, 0) * 1024 * wf / 1e6:.2f}"])
+            c = cal["pmc_calib_copy16_kernel" if "copy16" in k else "pmc_calib_copy4_kernel"]
+            w.writerow([k, n[k], f"{fe[k]:.1f}", f"{wr.get(k, 0):.1f}", f"{c[0]:.3f}", f"{c[1]:.3f}",
+                        f"{fe[k] * 1024 * c[0] / 1e6:.2f}", f"{wr.get(k, 0) * 1024 * c[1] / 1e6:.2f}"])
     print(open(out).read())
 
 

@@ -1,7 +1,7 @@
 # rocprofv3 passes over the default bench command (C3): kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in their own
 # passes, with the calibration copies), SQ counters.  Usage (on the GPU box): bash tools/prof_all.sh <tag>
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -19,5 +19,5 @@ cd $R
 python3 tools/prof_summary.py $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_summary.csv > /dev/null
 python3 tools/pmc_summary.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_hbm_traffic.csv > /dev/null
 python3 tools/sq_summary.py $(find $O/sq -name "*counter_collection.csv" | head -1) $O/sq_counters.csv
-python3 -c "import sys; sys.path.insert(0, '.'); import bench; print(bench.source_stamp())" > $O/source_stamp.txt
+python3 -c "import sys, json; sys.path.insert(0, '.'); import bench; print(json.dumps(bench.source_stamp(), indent=1))" > $O/source_stamp.txt
 rm -rf $O/stats $O/fetch $O/write $O/sq   # the raw traces are large; the summaries are what is kept
