@@ -91,6 +91,13 @@ const int8_t *vslam_brief_pattern_31(void);
  *       min_items .. 7 stay 0 and find_fundamental uses all 8 (:49-53).  Values above 8 overrun the set in the
  *       reference and are rejected here.                                                                          */
 #define VSLAM_OPT_RANSAC_MIN_ITEMS 6
+/*   VSLAM_OPT_CORNER_LIST_CAP  0 (default): the corner detector's per-frame lists hold 16 x max_corners + 4096 entries
+ *       (image data lists about 10 x max_corners).  A frame that needs more (response plateaus, pure noise) is redone
+ *       from whole-image scratch taken from a pool of max(4, frames / 16) (at most 64) sets: the results never depend on
+ *       the bound.  Only if more frames of ONE call overflow than the pool has sets do those frames come back without
+ *       corners, and vslam_ctx_synchronize returns VSLAM_ERR_CAPACITY.  n > 0: n entries per frame (a test knob);
+ *       -1: every list sized for the whole image, as before round 4 (nothing can overflow; 16 bytes per pixel and frame). */
+#define VSLAM_OPT_CORNER_LIST_CAP 7
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

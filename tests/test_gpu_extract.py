@@ -95,6 +95,77 @@ def test_good_features_plateaus_and_flat(ctx, oracle):
     assert n[1] == 0
 
 
+def _noise_and_sparse(n_each, w, h, seed):
+    """n_each pure-noise frames (every ninth pixel or so is a 3x3 maximum: the longest lists there are) alternating with
+    n_each nearly flat frames that carry a dozen rectangles."""
+    rng = np.random.default_rng(seed)
+    kinds, imgs = [], []
+    for i in range(2 * n_each):
+        if i % 2 == 0:
+            kinds.append("n")
+            imgs.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+        else:
+            img = np.full((h, w), 90, np.uint8)
+            for _ in range(12):
+                x, y = rng.integers(8, w - 24), rng.integers(8, h - 24)
+                img[y:y + 9, x:x + 11] = rng.integers(150, 250)
+            kinds.append("s")
+            imgs.append(img)
+    return kinds, np.stack(imgs)
+
+
+@pytest.mark.parametrize("cap", [0, 700, 40, -1])
+def test_bounded_corner_lists_never_change_results(ctx, oracle, cap):
+    """The detector's per-frame lists are bounded (VSLAM_OPT_CORNER_LIST_CAP; default 16 x max_corners + 4096 entries);
+    a frame that overflows its list is redone by the plain exact pipeline on whole-image scratch from a pool.  Noise
+    frames overflow the default bound, cap = 700 makes the textured ones overflow as well, 40 nearly everything, -1 sizes
+    the lists for the whole image (nothing overflows): the same corners in the same order every time."""
+    ctx.set_option(ctx.OPT_CORNER_LIST_CAP, cap)
+    try:
+        w, h, maxc = 320, 240, 60
+        kinds, gray = _noise_and_sparse(2, w, h, 5)
+        assert kinds.count("n") == 2
+        bgr = frames_for(w, h, 12, n=1)                       # two textured frames
+        gray = np.concatenate([gray, np.stack([oracle.bgr2gray(b) for b in bgr])])[:4 if cap == 40 else 6]
+        for md in (3.0, 1.0):
+            xy, n = ctx.good_features(torch.from_numpy(gray).cuda(), maxc, min_distance=md)
+            ctx.synchronize()
+            xy, n = xy.cpu().numpy(), n.cpu().numpy()
+            for f in range(gray.shape[0]):
+                ref = oracle.good_features(gray[f], maxc, min_dist=md)
+                assert n[f] == len(ref) and np.array_equal(xy[f, :n[f]], ref), (cap, md, f, n[f], len(ref))
+    finally:
+        ctx.set_option(ctx.OPT_CORNER_LIST_CAP, 0)
+
+
+def test_corner_pool_exhaustion_is_reported(ctx, oracle):
+    """More overflowing frames in ONE call than the pool has sets (4 for up to 64 frames): the frames that found no set
+    come back without corners and the context reports VSLAM_ERR_CAPACITY -- never a silently wrong answer; the frames
+    that did find a set are exact, and the next call is clean."""
+    from vslam_amd import VslamError
+    w, h, maxc = 320, 240, 60
+    bgr = frames_for(w, h, 13, n=4)                           # 8 textured frames
+    gray = np.stack([oracle.bgr2gray(b) for b in bgr])
+    ctx.set_option(ctx.OPT_CORNER_LIST_CAP, 40)
+    try:
+        xy, n = ctx.good_features(torch.from_numpy(gray).cuda(), maxc)
+        with pytest.raises(VslamError, match="CAPACITY"):
+            ctx.synchronize()
+        xy, n = xy.cpu().numpy(), n.cpu().numpy()
+        refs = [oracle.good_features(g, maxc) for g in gray]
+        done = [f for f in range(8) if n[f] > 0]
+        assert len(done) == 4 and all(len(refs[f]) > 0 for f in range(8))
+        for f in done:
+            assert n[f] == len(refs[f]) and np.array_equal(xy[f, :n[f]], refs[f]), f
+    finally:
+        ctx.set_option(ctx.OPT_CORNER_LIST_CAP, 0)
+    xy, n = ctx.good_features(torch.from_numpy(gray).cuda(), maxc)
+    ctx.synchronize()
+    xy, n = xy.cpu().numpy(), n.cpu().numpy()
+    for f in range(8):
+        assert n[f] == len(refs[f]) and np.array_equal(xy[f, :n[f]], refs[f]), f
+
+
 def test_good_features_other_min_distance(ctx, oracle):
     bgr = frames_for(320, 240, 31)
     gray = ctx.bgr2gray(torch.from_numpy(bgr).cuda())

@@ -209,6 +209,9 @@ int vslam_ctx_synchronize(vslam_ctx *ctx) {
         if (flag) {
             VS_HIP(ctx, hipMemset(it->second.ptr, 0, sizeof(flag)));
             ctx->err = "a fixed-size device list overflowed (flag " + std::to_string(flag) + ")";
+            if (flag & 4)
+                ctx->err += ": more frames of one call needed the corner detector's whole-image fallback than its pool holds; "
+                            "those frames got no corners (VSLAM_OPT_CORNER_LIST_CAP = -1 sizes every list for the whole image)";
             return VSLAM_ERR_CAPACITY;
         }
     }
@@ -247,6 +250,11 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
     if (option == VSLAM_OPT_CORNER_WINDOW_PCT) {
         VS_REQUIRE(ctx, value >= 0 && value <= 100000, VSLAM_ERR_INVALID);
         ctx->corner_window_pct = value;
+        return VSLAM_OK;
+    }
+    if (option == VSLAM_OPT_CORNER_LIST_CAP) {
+        VS_REQUIRE(ctx, value >= -1, VSLAM_ERR_INVALID);
+        ctx->corner_list_cap = value;
         return VSLAM_OK;
     }
     if (option == VSLAM_OPT_MATCH_SHAPE) {

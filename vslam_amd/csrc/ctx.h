@@ -46,6 +46,7 @@ struct vslam_ctx {
     int ransac_solver = 0;                      // VSLAM_OPT_RANSAC_SOLVER: 0 exact Jacobi replay, 1 Gram / MFMA (not bit-exact)
     int match_shape = 0;                        // VSLAM_OPT_MATCH_SHAPE: 0 by size, 1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows
     int corner_window_pct = 135;                // VSLAM_OPT_CORNER_WINDOW_PCT
+    int corner_list_cap = 0;                    // VSLAM_OPT_CORNER_LIST_CAP: 0 = 16 x max_corners + 4096, -1 = whole image
     bool ransac_all_sums = false;   // VSLAM_OPT_RANSAC_ALL_SUMS: exact residual sum of every hypothesis (ransac_score_kernel)
     std::string err;
 
@@ -173,6 +174,26 @@ struct VsCornerCounters {
     uint32_t *cutkey;    // ordered response below which keys2 is incomplete (0: complete)
     uint32_t *hist;      // two-tier detector: the listed upper bounds by magnitude
 };
+// Whole-image scratch for the few frames the bounded two-tier path cannot finish (see vs_launch_good_features): `slots`
+// sets of (keys, response image, per-pixel state).  A frame claims a slot by a ticket on `count`; everything per slot.
+struct VsCornerPool {
+    int32_t *count = nullptr;      // tickets handed out (may exceed slots: the excess frames raise bit 2 of the error word)
+    int32_t *frame = nullptr;      // [slots] the frame filed under each slot
+    uint32_t *counts = nullptr;    // [slots] candidates found
+    uint32_t *fmax = nullptr;      // [slots] ordered exact maximum response
+    unsigned long long *keys = nullptr;   // [slots][key_cap]
+    float *eig = nullptr;          // [slots][w * h]
+    uint8_t *state = nullptr;      // [slots][w * h]
+    size_t key_cap = 0;
+    int slots = 0;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ int vs_pool_used(const VsCornerPool &p) {
+    const int used = *p.count;
+    return used < p.slots ? used : p.slots;
+}
+#endif
+int vs_launch_pool_candidates(vslam_ctx *ctx, const uint8_t *gray, int w, int h, double quality, const VsCornerPool &pool);
 size_t vs_response_hist_words(int frames);
 // `gray` still to be formed from a 3-byte image (cvtColor is then the detector's job: fused into its first kernel when
 // the layout allows, a launch of its own otherwise)

@@ -97,10 +97,12 @@ __global__ __launch_bounds__(kSetThreads) void ransac_mt_kernel(const uint32_t *
 constexpr int kMapThreads = 1024;
 // mi = RansacFilter::min_items: the reference draws min_items indices into sets that are 8 wide whatever min_items is
 // (src/RansacFilter.cpp:17,22): entries mi .. 7 stay 0, and a hypothesis consumes mi raw outputs (+ rejections).
-__global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *__restrict__ m_arr, int hyp, int nblk, int mi,
+template <bool EIGHT>   // min_items == 8, the usual case: d & 7, no per-entry test
+__global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *__restrict__ m_arr, int hyp, int nblk, int mi_arg,
                                                                  const uint32_t *__restrict__ raw, int32_t *__restrict__ sets,
                                                                  uint32_t *__restrict__ draws, int32_t *__restrict__ errflag) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int mi = EIGHT ? VSLAM_SET_SIZE : mi_arg;
     const int n = m_arr[b];
     int32_t *S = sets + (size_t)b * hyp * VSLAM_SET_SIZE;
     uint32_t *D = draws + (size_t)b * hyp * VSLAM_SET_SIZE;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *
         }
         for (int t = lo + tid; t < total + rej; t += kMapThreads) {
             const int d = t - rej;
-            const uint32_t range = (uint32_t)(n - (mi == VSLAM_SET_SIZE ? (d & 7) : d % mi));
+            const uint32_t range = (uint32_t)(n - (EIGHT ? (d & 7) : d % mi));
             const uint64_t prod = (uint64_t)R[t] * (uint64_t)range;
             const uint32_t low = (uint32_t)prod;
             if (low < range && low < (0u - range) % range) atomicMin(&s_first, t);   // rejected: consumed, yields no draw
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kMapThreads) void ransac_map_kernel(const int32_t *
         int cnt = 0, size = n;
 #pragma unroll
         for (int j = 0; j < VSLAM_SET_SIZE; j++) {
-            if (j >= mi) {
+            if (!EIGHT && j >= mi) {
                 S[(size_t)h * VSLAM_SET_SIZE + j] = 0;
                 continue;
             }
@@ -669,11 +671,11 @@ __device__ __forceinline__ void jacobi_null_row_8x9(float *pA, float (&R)[8][9],
 // One lane per hypothesis, one wave per workgroup.  grid = (ceil(hyp / 64), batch).
 __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_solve_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
-    const int32_t *__restrict__ m_arr, const int32_t *__restrict__ sets, int kp_stride, int hyp,
+    const int32_t *__restrict__ m_arr, int min_m, const int32_t *__restrict__ sets, int kp_stride, int hyp,
     float *__restrict__ hypF) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const int h = blockIdx.x * kSolveThreads + tid;
-    if (m_arr[b] < VSLAM_SET_SIZE) return;   // uniform per workgroup
+    if (m_arr[b] < min_m) return;   // uniform per workgroup (8 unless RansacFilter::min_items is smaller)
 
     __shared__ float sA[kSolveSplitFloats * kSolveThreads];
 
@@ -2206,8 +2208,11 @@ int vs_launch_ransac_map(vslam_ctx *ctx, const int32_t *m, int batch, int hyp, c
     int rc = vs_device_errflag(ctx, &flag);
     if (rc) return rc;
     VsProfScope ps(ctx, "ransac_sets_kernel");
-    ransac_map_kernel<<<batch, kMapThreads, 0, ctx->stream>>>(m, hyp, vs_mt_blocks(hyp), ctx->ransac_min_items, raw, sets, draws,
-                                                              flag);
+    if (ctx->ransac_min_items == VSLAM_SET_SIZE)
+        ransac_map_kernel<true><<<batch, kMapThreads, 0, ctx->stream>>>(m, hyp, vs_mt_blocks(hyp), VSLAM_SET_SIZE, raw, sets, draws, flag);
+    else
+        ransac_map_kernel<false><<<batch, kMapThreads, 0, ctx->stream>>>(m, hyp, vs_mt_blocks(hyp), ctx->ransac_min_items, raw, sets,
+                                                                         draws, flag);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }
@@ -2241,7 +2246,7 @@ int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, c
         return VSLAM_OK;
     }
     VsProfScope ps(ctx, "ransac_solve_kernel");
-    ransac_solve_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, sets, kp_stride, hyp, hypF);
+    ransac_solve_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }

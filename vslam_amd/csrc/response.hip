@@ -125,14 +125,21 @@ constexpr int kE4W = 256, kE4H = 32, kE4C = kE4W / 4 + 2;
 
 // Plain cornerMinEigenVal for vslam_min_eigen (the front-end path uses min_eigen_stream_kernel below, which
 // follows this kernel's arithmetic): a 256x32 tile per workgroup, every pixel of it owned.
+// With pool.count set, blockIdx.z is a slot of the corner pipeline's fallback pool (select.hip): input = the frame filed
+// under the slot, outputs (eig, frame_max) by slot; slots nobody claimed return at once.
 __global__ __launch_bounds__(256) void min_eigen_v4_kernel(const uint8_t *__restrict__ gray, int w, int h,
                                                            float *__restrict__ eig,
-                                                           uint32_t *__restrict__ frame_max) {
+                                                           uint32_t *__restrict__ frame_max, const VsCornerPool pool) {
     __shared__ uint32_t G[kE4H + 4][kE4C];   // bytes x0-4 .. x0+259 of raw rows y0-2 .. y0+33
     __shared__ uint32_t s_max;
-    const int f = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int f = blockIdx.z, fin = f;   // f: where the outputs go; fin: the frame read
+    if (pool.count) {
+        if (f >= vs_pool_used(pool)) return;
+        fin = pool.frame[f];
+    }
     const int x0 = blockIdx.x * kE4W, y0 = blockIdx.y * kE4H;
-    const uint8_t *src = gray + (size_t)f * w * h;
+    const uint8_t *src = gray + (size_t)fin * w * h;
     if (tid == 0) s_max = 0;
     for (int i = tid; i < (kE4H + 4) * kE4C; i += 256) {
         const int r = i / kE4C, c = i - r * kE4C;
@@ -941,14 +948,17 @@ constexpr int kCT = 256, kCTW = 64, kCTH = 16;
 __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
     const float *__restrict__ eig, int w, int h, const uint32_t *__restrict__ frame_max, double quality,
     unsigned long long *__restrict__ keys, uint32_t *__restrict__ counts,
-    size_t key_cap) {
+    size_t key_cap, const VsCornerPool pool) {
     __shared__ float E[kCTH + 2][kCTW + 2];
     __shared__ uint32_t s_cnt, s_base;
-    const int f = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * kCTW, y0 = blockIdx.y * kCTH;
+    const int f = blockIdx.z, tid = threadIdx.x;   // a frame, or a slot of the fallback pool (everything here is by slot then)
+    if (pool.count && f >= vs_pool_used(pool)) return;
+    const int x0 = blockIdx.x * kCTW;
     const float *src = eig + (size_t)f * w * h;
     const float mx = ord2f(frame_max[f]);
     const float thr = (float)((double)mx * quality);   // threshold(eig, maxVal*qualityLevel, THRESH_TOZERO)
+    for (int y0 = blockIdx.y * kCTH; y0 < h; y0 += gridDim.y * kCTH) {   // the grid may cover only some tile rows
+    __syncthreads();
     if (tid == 0) s_cnt = 0;
     for (int i = tid; i < (kCTH + 2) * (kCTW + 2); i += kCT) {
         const int r = i / (kCTW + 2), c = i - r * (kCTW + 2);
@@ -994,6 +1004,7 @@ __global__ __launch_bounds__(kCT) void corner_candidates_kernel(
         const size_t pos = (size_t)s_base + my_off + i;
         if (pos < key_cap) keys[(size_t)f * key_cap + pos] = mykeys[i];
     }
+    }
 }
 
 }  // namespace
@@ -1006,7 +1017,7 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VsProfScope ps(ctx, "min_eigen_kernel");
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && ((reinterpret_cast<uintptr_t>(eig) & 15) == 0)) {
         dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), frames);
-        min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
+        min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits, VsCornerPool{});
     } else {
         dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
         min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
@@ -1063,8 +1074,23 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
         if ((rc = vs_launch_min_eigen(ctx, gray, frames, w, h, eig, c.fmax))) return rc;
         VsProfScope ps(ctx, "corner_candidates_kernel");
         dim3 grid(vs_div_up(w, kCTW), vs_div_up(h, kCTH), frames);
-        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, c.fmax, quality, keys, c.counts, key_cap);
+        corner_candidates_kernel<<<grid, kCT, 0, ctx->stream>>>(eig, w, h, c.fmax, quality, keys, c.counts, key_cap, VsCornerPool{});
     }
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+// The fallback of the two-tier path (select.hip): the frames filed in the pool -- their bounded lists overflowed, or their
+// selection needs the per-pixel maps -- are redone with the plain pipeline on whole-image scratch: exact response of every
+// pixel and the frame maximum (by slot), then every candidate's exact key.  Always queued; returns at once when the pool
+// is empty (two launches of a few thousand idle workgroups).
+int vs_launch_pool_candidates(vslam_ctx *ctx, const uint8_t *gray, int w, int h, double quality, const VsCornerPool &pool) {
+    VsProfScope ps(ctx, "corner_rerun_kernels");
+    dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), pool.slots);
+    min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, pool.eig, pool.fmax, pool);
+    const int rows = vs_div_up(h, kCTH);
+    dim3 grid2(vs_div_up(w, kCTW), rows < 4 ? rows : 4, pool.slots);
+    corner_candidates_kernel<<<grid2, kCT, 0, ctx->stream>>>(pool.eig, w, h, pool.fmax, quality, pool.keys, pool.counts, pool.key_cap, pool);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }

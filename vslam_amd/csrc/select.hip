@@ -491,7 +491,8 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint8_t *__restrict__ state, unsigned long long *__restrict__ keys, const uint32_t *__restrict__ counts, size_t key_cap,
     int max_corners, float min_dist, float min_dist_sq, int sort_cap, float *__restrict__ out_xy,
     int32_t *__restrict__ out_n, int kp_stride, int32_t *__restrict__ overflow,
-    const uint32_t *__restrict__ frame_max, double quality, int use_lists, const DiscTable disc) {
+    const uint32_t *__restrict__ frame_max, double quality, int use_lists, const DiscTable disc,
+    const uint32_t *__restrict__ raw_counts, const VsCornerPool pool, int32_t *__restrict__ errflag) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long *sortbuf = reinterpret_cast<unsigned long long *>(smem_raw);
     __shared__ SelectShared sh;
@@ -500,15 +501,39 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int i = threadIdx.x; i < kDiscMax + 3; i += kST) sdisc.e[i] = disc.e[i];
     if (threadIdx.x == 0) sdisc.n = disc.n;   // (the first barrier below orders these)
 
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     // pass 1 = the rerun of the frames whose first selection ran out of keys above the cut (their list is complete now)
+    // pass 2 = the frames filed in the fallback pool: a workgroup per slot, inputs by slot (the plain pipeline's exact keys
+    //          of every candidate, whole-image E / S), outputs by frame
+    int f = blockIdx.x;
+    const int slot = blockIdx.x;
+    if (pass == 2) {
+        if (slot >= vs_pool_used(pool)) return;
+        f = pool.frame[slot];
+    }
     if (pass == 1 && need[f] == 0u) return;
-    float *E = eig + (size_t)f * w * h;   // slow path only: responses of the candidates, scattered from their keys
-    uint8_t *S = state + (size_t)f * w * h;
-    unsigned long long *K = keys + (size_t)f * key_cap;
+    float *E = eig + (size_t)slot * w * h;   // slow path only: responses of the candidates, scattered from their keys
+    uint8_t *S = state + (size_t)slot * w * h;
+    unsigned long long *K = keys + (size_t)slot * key_cap;
     float2 *O = reinterpret_cast<float2 *>(out_xy) + (size_t)f * kp_stride;
-    uint32_t n = counts[f];
+    uint32_t n = counts[slot];
+    // Bounded lists (passes 0 and 1 of the two-tier path; E and S do not exist there): a frame whose raw list did not fit,
+    // or whose selection needs the per-pixel maps, is filed in the pool and redone from scratch by pass 2; if the pool is
+    // full as well the frame gets no corners and bit 2 of the context's error word is raised (VSLAM_ERR_CAPACITY).
+    const bool bounded = pass != 2 && pool.count != nullptr;
+    auto to_pool = [&]() {   // every thread calls it, then returns
+        if (tid == 0) {
+            const int t = atomicAdd(pool.count, 1);
+            if (t < pool.slots) pool.frame[t] = f;
+            else atomicOr(errflag, 4);
+            out_n[f] = 0;
+        }
+    };
+    if (bounded && raw_counts[f] > key_cap) {
+        to_pool();
+        return;
+    }
     if (n > key_cap) {
         if (tid == 0) atomicAdd(overflow, 1);
         n = (uint32_t)key_cap;
@@ -518,14 +543,14 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
     // exact threshold: the fused detector prefilters with a running maximum, so only keys whose response is
     // > (float)(max * quality) count (every key of an exactly-thresholded list passes)
-    float thr = (float)((double)ord2f(frame_max[f]) * quality);
+    float thr = (float)((double)ord2f(frame_max[slot]) * quality);
     if (thr == 0.f) thr = 0.f;   // -0 -> +0 so the ordered-key compare equals the float compare
     // The two-tier detector's key list is complete only above cutkey[f] (a key below it may be outranked by a pixel that
     // was never evaluated): such keys are ignored, and if the selection then runs out of keys before it has max_corners
     // corners the frame is flagged and redone (pass 1) on the complete list.
     const uint32_t cut32 = (pass == 0 && cutkey) ? cutkey[f] : 0u;
     const bool cut_binds = cut32 > f2ord(thr);
-    const uint32_t t32 = cut_binds ? cut32 - 1u : f2ord(thr), m32 = frame_max[f];   // keys >= cut32 pass
+    const uint32_t t32 = cut_binds ? cut32 - 1u : f2ord(thr), m32 = frame_max[slot];   // keys >= cut32 pass
     auto finish = [&](uint32_t found) {   // tid 0: the count, or the request for the rerun
         if (cut_binds && found < want_max) {
             need[f] = 1u;
@@ -724,6 +749,10 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
     if (done) return;
+    if (bounded) {   // the slow path needs whole-image maps: the pool's pass has them
+        to_pool();
+        return;
+    }
 
     // ---------------------------------------------------------------- slow path (rare)
     // suppression over every candidate through a per-pixel state map in global memory
@@ -809,10 +838,27 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     uint8_t *state = nullptr;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int rc;
-    if ((rc = vs_arena_get(ctx, "gf.eig", sizeof(float) * px * frames, (void **)&eig))) return rc;
+    // The two-tier detector (width % 4 == 0, the usual case) keeps BOUNDED per-frame lists: the detector lists about
+    // 10 x max_corners pixels on image data, so 16 x max_corners + 4096 entries hold a frame's list with room to spare
+    // (VSLAM_OPT_CORNER_LIST_CAP: another bound; -1: the whole image, which nothing can overflow).  A frame that does
+    // overflow it (response plateaus, noise: every interior pixel can be listed), or whose selection needs per-pixel maps
+    // (its rank window outgrew LDS), is filed in a small pool of whole-image scratch and redone from scratch by the plain
+    // exact pipeline (pass 2 below): results never depend on the bound.  Should more frames of one call need the pool
+    // than it has slots, those frames get no corners and vslam_ctx_synchronize reports VSLAM_ERR_CAPACITY.
+    // Other widths run the plain pipeline on whole-image buffers for every frame, as before.
+    const bool two_tier = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
+    size_t key_cap = px;
+    if (two_tier && ctx->corner_list_cap >= 0) {
+        const size_t want = ctx->corner_list_cap > 0 ? (size_t)ctx->corner_list_cap : 16 * (size_t)max_corners + 4096;
+        if (want < key_cap) key_cap = want;
+    }
+    VsCornerPool pool;
+    pool.slots = two_tier ? (frames < 4 ? frames : (frames / 16 < 4 ? 4 : (frames / 16 > 64 ? 64 : frames / 16))) : 0;
+    pool.key_cap = px;
     // every per-frame counter of the pipeline in one block, so that one memset clears all of it:
-    // counts[F], overflow[1], fmax[F], low[F], count2[F], count3[F], need[F], cutkey[F], hist[F][bins]
-    const size_t F = (size_t)frames, words = 7 * F + 1 + vs_response_hist_words(frames);
+    // counts[F], overflow[1], fmax[F], low[F], count2[F], count3[F], need[F], cutkey[F], hist[F][bins],
+    // pool: count[1], frame[slots], counts[slots], fmax[slots]
+    const size_t F = (size_t)frames, words = 7 * F + 1 + vs_response_hist_words(frames) + 1 + 3 * (size_t)pool.slots;
     if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * words, (void **)&block))) return rc;
     VsCornerCounters c;
     c.counts = block;
@@ -824,12 +870,28 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     c.need = c.count3 + F;
     c.cutkey = c.need + F;
     c.hist = c.cutkey + F;
-    if ((rc = vs_arena_get(ctx, "gf.state", px * frames, (void **)&state))) return rc;
-    // every interior pixel can be a candidate (a plateau equals its own dilation), so the lists are sized for the whole
-    // image: exactness over memory.  keys = the detector's list, keys2 = the exact keys of the two-tier path.
-    const size_t key_cap = px;
+    {
+        uint32_t *pw = c.hist + vs_response_hist_words(frames);
+        pool.count = reinterpret_cast<int32_t *>(pw);
+        pool.frame = reinterpret_cast<int32_t *>(pw + 1);
+        pool.counts = pw + 1 + pool.slots;
+        pool.fmax = pw + 1 + 2 * (size_t)pool.slots;
+    }
+    int32_t *errflag = nullptr;
+    if ((rc = vs_device_errflag(ctx, &errflag))) return rc;
+    if (two_tier) {
+        if ((rc = vs_arena_get(ctx, "gf.pool.keys", sizeof(unsigned long long) * px * pool.slots, (void **)&pool.keys))) return rc;
+        if ((rc = vs_arena_get(ctx, "gf.pool.eig", sizeof(float) * px * pool.slots, (void **)&pool.eig))) return rc;
+        if ((rc = vs_arena_get(ctx, "gf.pool.state", px * pool.slots, (void **)&pool.state))) return rc;
+    } else {
+        if ((rc = vs_arena_get(ctx, "gf.eig", sizeof(float) * px * frames, (void **)&eig))) return rc;
+        if ((rc = vs_arena_get(ctx, "gf.state", px * frames, (void **)&state))) return rc;
+        pool = VsCornerPool{};
+    }
+    // keys = the detector's list, keys2 = the exact keys of the two-tier path
     if ((rc = vs_arena_get(ctx, "gf.keys", sizeof(unsigned long long) * key_cap * frames, (void **)&keys))) return rc;
-    if ((rc = vs_arena_get(ctx, "gf.keys2", sizeof(unsigned long long) * key_cap * frames, (void **)&keys2))) return rc;
+    if (two_tier)
+        if ((rc = vs_arena_get(ctx, "gf.keys2", sizeof(unsigned long long) * key_cap * frames, (void **)&keys2))) return rc;
 
     VS_HIP(ctx, hipMemsetAsync(block, 0, sizeof(uint32_t) * words, ctx->stream));
     // The selection ranks 1.25 x max_corners + 64 candidates (twice that if the suppression leaves it short, which it
@@ -873,10 +935,15 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                     \
             ctx->attr_done["corner_select" #EPT] = true;                                                                   \
         }                                                                                                                  \
-        corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(eig, raw_list ? c.cutkey : nullptr, c.need, PASS, w, h, \
-                                                                     state, KEYS, COUNTS, key_cap, max_corners, md, md2,   \
-                                                                     sort_cap, xy, n, kp_stride, overflow, c.fmax,         \
-                                                                     quality, use_lists, disc);                            \
+        if (PASS == 2)                                                                                                     \
+            corner_select_kernel<EPT><<<pool.slots, kST, lds, ctx->stream>>>(                                              \
+                pool.eig, nullptr, c.need, 2, w, h, pool.state, pool.keys, pool.counts, pool.key_cap, max_corners, md, md2, \
+                sort_cap, xy, n, kp_stride, overflow, pool.fmax, quality, use_lists, disc, nullptr, pool, errflag);         \
+        else                                                                                                               \
+            corner_select_kernel<EPT><<<frames, kST, lds, ctx->stream>>>(                                                  \
+                eig, raw_list ? c.cutkey : nullptr, c.need, PASS, w, h, state, KEYS, COUNTS, key_cap, max_corners, md, md2, \
+                sort_cap, xy, n, kp_stride, overflow, c.fmax, quality, use_lists, disc, raw_list ? c.counts : nullptr,     \
+                raw_list ? pool : VsCornerPool{}, errflag);                                                                \
     } while (0)
 #define VS_SELECT_DISPATCH(PASS, KEYS, COUNTS)                                                                             \
     switch (sort_cap / kST) {                                                                                              \
@@ -896,8 +963,14 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
             // the rerun, for the frames (if any) whose selection ran out of keys above the cut: every listed pixel is
             // evaluated, then selected from again.  Both launches return at once for the other frames.
             if ((rc = vs_launch_corner_exact(ctx, gray, frames, w, h, c, keys, keys2, key_cap, 0u, 1))) return rc;
+            {
+                VsProfScope ps(ctx, "corner_rerun_kernels");
+                VS_SELECT_DISPATCH(1, keys2, c.count3)
+            }
+            // the pool's frames (usually none: three launches that return at once), redone by the plain exact pipeline
+            if ((rc = vs_launch_pool_candidates(ctx, gray, w, h, quality, pool))) return rc;
             VsProfScope ps(ctx, "corner_rerun_kernels");
-            VS_SELECT_DISPATCH(1, keys2, c.count3)
+            VS_SELECT_DISPATCH(2, pool.keys, pool.counts)
         }
 #undef VS_SELECT_DISPATCH
 #undef VS_SELECT_LAUNCH
