@@ -33,6 +33,7 @@ extern "C" {
 #define VSLAM_ERR_NO_DEVICE (-3) /* no gfx950 device visible                                 */
 #define VSLAM_ERR_CAPACITY (-4)  /* a size exceeds what the kernels were built for           */
 #define VSLAM_ERR_DEGENERATE (-5)/* input the reference leaves undefined (<2 train rows, <8 matches) */
+#define VSLAM_ERR_COMM (-6)      /* RCCL is missing or one of its calls failed; see vslam_last_error()  */
 
 #define VSLAM_DESC_BYTES 32
 #define VSLAM_SET_SIZE 8         /* RansacFilter draws 8-subsets: src/RansacFilter.cpp:17    */
@@ -342,6 +343,44 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
                             const uint32_t *d_seeds, int hyp, float threshold, float *d_xy,
                             uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches,
                             int32_t *d_best, float *d_F);
+
+/* ------------------------------------------------------------ several devices
+ * Frame pairs are independent (src/RansacFilter.cpp:38: all state is per call), so a batch shards by contiguous slices,
+ * one slice per device, with per-pair seeds base ^ GLOBAL pair index -- a pair's result does not depend on the split --
+ * and the only exchange is the final gather of fixed-size result records (vslam_pack_records' layout).
+ * vslam_shard_range: the slice [lo, hi) of `items` that `rank` of `world` owns (the first items % world ranks get one more). */
+int vslam_shard_range(int items, int rank, int world, int *lo, int *hi);
+
+/* (i) One process that owns the devices: one context + one host thread per entry of `devices` (an entry may repeat: several
+ * contexts on one device).  vslam_multi_frontend_pairs = vslam_frontend_pairs + vslam_pack_records on every slice at once.
+ *   h_bgr_last / h_bgr_cur: HOST, [pairs][height][row_stride] each (page-locked memory from vslam_host_alloc uploads faster);
+ *   params->d_pattern must be NULL; h_pattern: HOST [256][4] int8 or NULL for ORB's learned table;
+ *   h_records: HOST [pairs][13 + kp_stride] int32, pair order; h_n_keypoints: HOST [2 * pairs] (last frames, then current)
+ *   or NULL.  Blocking: returns when every slice is done.  Options are per context: vslam_multi_ctx(m, i).            */
+typedef struct vslam_multi vslam_multi;
+int vslam_multi_create(const int *devices, int n_devices, vslam_multi **out);
+int vslam_multi_destroy(vslam_multi *m);
+int vslam_multi_size(const vslam_multi *m);
+vslam_ctx *vslam_multi_ctx(vslam_multi *m, int i);
+const char *vslam_multi_last_error(vslam_multi *m);
+int vslam_multi_frontend_pairs(vslam_multi *m, const uint8_t *h_bgr_last, const uint8_t *h_bgr_cur, int pairs, int width,
+                               int height, int row_stride, const vslam_extract_params *params, const int8_t *h_pattern,
+                               int kp_stride, uint32_t base_seed, int hyp, float threshold, int32_t *h_records,
+                               int32_t *h_n_keypoints);
+
+/* (ii) One process per device (any launcher): every rank runs its slice on its own context; the records are exchanged once,
+ * all-gather over RCCL (xGMI inside a node) on the context's stream.  RCCL is loaded when the first of these is called.
+ *   vslam_comm_unique_id: rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the launcher
+ *   has (a file, a socket, an environment variable, MPI); vslam_comm_create: collective over all ranks.
+ *   vslam_gather_records: every rank contributes words_per_rank int32 (equal on all ranks: pad the last slice);
+ *   d_all receives world x words_per_rank in rank order = pair order.  Asynchronous on the context's stream.          */
+#define VSLAM_COMM_ID_BYTES 128
+typedef struct vslam_comm vslam_comm;
+int vslam_comm_unique_id(void *id_out);
+int vslam_comm_create(vslam_ctx *ctx, const void *id, int world, int rank, vslam_comm **out);
+int vslam_comm_destroy(vslam_comm *comm);
+int vslam_gather_records(vslam_ctx *ctx, vslam_comm *comm, const int32_t *d_records, size_t words_per_rank,
+                         int32_t *d_all);
 
 #ifdef __cplusplus
 }

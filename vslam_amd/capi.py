@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libvslam_amd.so")
 
 OK = 0
 ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE",
-          -4: "VSLAM_ERR_CAPACITY", -5: "VSLAM_ERR_DEGENERATE"}
+          -4: "VSLAM_ERR_CAPACITY", -5: "VSLAM_ERR_DEGENERATE", -6: "VSLAM_ERR_COMM"}
 
 # every symbol include/vslam_amd.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
@@ -26,6 +26,8 @@ SYMBOLS = [
     "vslam_match_features",
     "vslam_frontend_pairs", "vslam_frontend_sequence", "vslam_pack_records",
     "vslam_host_alloc", "vslam_host_free", "vslam_upload_async", "vslam_upload_fence", "vslam_upload_wait",
+    "vslam_shard_range", "vslam_multi_create", "vslam_multi_destroy", "vslam_multi_size", "vslam_multi_ctx", "vslam_multi_last_error",
+    "vslam_multi_frontend_pairs", "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_gather_records",
 ]
 
 
@@ -449,3 +451,58 @@ class Context:
             _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out["nodes"]),
             _ptr(out["n"]), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"])))
         return out
+
+
+class MultiDevice:
+    """ctypes stub of vslam_multi_* (include/vslam_amd.h): one process, several device slots, host arrays in and out."""
+
+    def __init__(self, devices, lib=None):
+        self.lib = lib or load_library()
+        self.lib.vslam_multi_last_error.restype = C.c_char_p
+        self.lib.vslam_multi_ctx.restype = C.c_void_p
+        arr = (C.c_int * len(devices))(*devices)
+        self.handle = C.c_void_p()
+        rc = self.lib.vslam_multi_create(arr, C.c_int(len(devices)), C.byref(self.handle))
+        if rc != OK:
+            raise VslamError(f"{ERRORS.get(rc, rc)}: vslam_multi_create({list(devices)})")
+
+    def size(self):
+        return self.lib.vslam_multi_size(self.handle)
+
+    def set_option(self, option, value):
+        for i in range(self.size()):
+            ctx = C.c_void_p(self.lib.vslam_multi_ctx(self.handle, C.c_int(i)))
+            rc = self.lib.vslam_ctx_set_option(ctx, C.c_int(option), C.c_int(int(value)))
+            if rc != OK:
+                raise VslamError(f"{ERRORS.get(rc, rc)}: set_option")
+
+    def frontend_pairs(self, last, cur, max_corners, cos_a, sin_a, pattern, base_seed, hyp, threshold):
+        """last / cur: numpy uint8 (P, H, W, 3); pattern: numpy int8 (256, 4) or None.  Returns (records (P, 13 + K) int32,
+        keypoint counts (2 P,) int32)."""
+        import numpy as np
+        P, H, W, _ = last.shape
+        last = np.ascontiguousarray(last, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+        p = ExtractParams()
+        p.max_corners, p.quality, p.min_distance, p.cos_a, p.sin_a, p.d_pattern = max_corners, 0.01, 3.0, cos_a, sin_a, None
+        rec = np.zeros((P, 13 + max_corners), np.int32)
+        n = np.zeros(2 * P, np.int32)
+        pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8)
+        rc = self.lib.vslam_multi_frontend_pairs(
+            self.handle, last.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p), C.c_int(P), C.c_int(W), C.c_int(H),
+            C.c_int(3 * W), C.byref(p), pat.ctypes.data_as(C.c_void_p) if pat is not None else C.c_void_p(0), C.c_int(max_corners),
+            C.c_uint32(base_seed & 0xFFFFFFFF), C.c_int(hyp), C.c_float(threshold), rec.ctypes.data_as(C.c_void_p),
+            n.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise VslamError(f"{ERRORS.get(rc, rc)}: {self.lib.vslam_multi_last_error(self.handle).decode()}")
+        return rec, n
+
+    def close(self):
+        if self.handle:
+            self.lib.vslam_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
