@@ -570,6 +570,7 @@ def main():
             "config": {"workload": f"{args.workload}: {w}x{h}, {K} keypoints, {H} hypotheses, batch {P} pairs per GPU",
                        "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}" + (f", {backend_label} all_gather of result records" if multi else "")},
             "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
+            "workspace_bytes": ctx.workspace_bytes(),   # the context's grow-only workspaces for this batch shape (inputs / outputs not counted)
         }
         if rank_ms:
             result["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms}
@@ -747,6 +748,7 @@ def main():
             ms2, o2 = timed(c2, f2, P2, K2, H2, s2)
             b2 = o2["best"].cpu().numpy()
             others[wl] = {"workload": f"{w2}x{h2}, {K2} keypoints, {H2} hypotheses, batch {P2} pairs", "ms_per_step": ms2,
+                          "workspace_bytes": c2.workspace_bytes(),
                           "frame_pairs_per_s": P2 / ms2 * 1e3, "steps": 10, "mean_inlier_matches": float(b2[:, 3].mean()),
                           "degenerate": bool((b2[:, 0] < 0).any())}
             c2.close()

@@ -51,6 +51,9 @@ int vslam_ctx_synchronize(vslam_ctx *ctx);
 /* Waits for the context's stream and nothing else (vslam_ctx_synchronize also fetches the device-side error word). */
 int vslam_ctx_wait(vslam_ctx *ctx);
 const char *vslam_last_error(vslam_ctx *ctx);
+/* Device memory the context's grow-only workspaces hold at the moment (bytes; what a batch shape costs beside its own
+ * inputs and outputs).                                                                                    */
+int vslam_ctx_workspace_bytes(vslam_ctx *ctx, size_t *bytes_out);
 const char *vslam_version(void);
 /* ORB's learned rBRIEF test pairs (OpenCV `bit_pattern_31_`, the table behind cv::ORB::compute, src/Frame.cpp:57,68):
  * HOST pointer to 256 x (x0, y0, x1, y1) int8, static storage.  Every d_pattern argument below accepts NULL for a

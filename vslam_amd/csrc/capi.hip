@@ -226,6 +226,14 @@ int vslam_ctx_wait(vslam_ctx *ctx) {
 
 const char *vslam_last_error(vslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int vslam_ctx_workspace_bytes(vslam_ctx *ctx, size_t *bytes_out) {
+    if (!ctx || !bytes_out) return VSLAM_ERR_INVALID;
+    size_t total = 0;
+    for (const auto &kv : ctx->arena) total += kv.second.bytes;
+    *bytes_out = total;
+    return VSLAM_OK;
+}
+
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
     if (!ctx) return VSLAM_ERR_INVALID;
     if (option == VSLAM_OPT_RANSAC_ALL_SUMS) {
