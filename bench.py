@@ -548,7 +548,9 @@ def main():
     host_out = {k: out[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
     best = host_out["best"]
     n_kp = host_out["n"]
-    assert (best[:, 0] >= 0).all() and (best[:, 3] >= 8).all() and (n_kp > K // 2).all(), "bench output degenerate"
+    # (VSLAM_BENCH_ALLOW_DEGENERATE: tools/ab_kernels.py times kernel variants that produce wrong results on purpose)
+    assert os.environ.get("VSLAM_BENCH_ALLOW_DEGENERATE") or (
+        (best[:, 0] >= 0).all() and (best[:, 3] >= 8).all() and (n_kp > K // 2).all()), "bench output degenerate"
 
     result = None
     if rank == 0:

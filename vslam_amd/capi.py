@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvslam_amd.so")
+# VSLAM_AMD_LIB: another build of the same library (A/B timing of kernel variants: tools/ab_kernels.py)
+LIB_PATH = os.environ.get("VSLAM_AMD_LIB") or os.path.join(_HERE, "libvslam_amd.so")
 
 OK = 0
 ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE",
