@@ -78,6 +78,7 @@ def algorithmic_bytes(kernel, w, h, K, H, M, gray_fused=False):
 FP32_PEAK_TFLOPS = 157.3                       # FMA counted as 2: 256 CUs x 4 SIMDs x 32 lanes x 2 x 2.4 GHz
 INT32_PEAK_TOPS = FP32_PEAK_TFLOPS / 2.0       # one 32-bit integer op per lane and clock
 INT8_MFMA_PEAK_TOPS = 5000.0                   # dense int8 MFMA (MI355X_MICROARCH.md: about 2x the 2.5 PFLOP/s bf16 rate)
+FP4_MFMA_PEAK_TOPS = 10000.0                   # dense FP4 / FP6 MFMA (MI355X_MICROARCH.md: about 10 PF; v_mfma_scale_f32_32x32x64_f8f6f4)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
 PROFILE_TAG = "r04"
 SQ_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.csv")
@@ -105,8 +106,9 @@ ALG_OPS = {
     "ransac_solve_kernel": ("hypotheses (A, two Jacobi SVDs, F = U diag Vt: counted per visit and rotation, tools/solve_flops.py -> "
                             "profiles/" + PROFILE_TAG + "_solve_work.json; about half of them f64)", solve_flops(), "flop", FP32_PEAK_TFLOPS),
     "min_eigen_kernel": ("pixels (stencil work, about 60 int/flop per pixel: SURVEY.md 8d)", 60.0, "flop", FP32_PEAK_TFLOPS),
-    # the matcher forms each 256-bit Hamming distance as an int8 dot product on the matrix cores: 256 multiply-adds
-    "match_knn2_kernel": ("(query, train) descriptor pairs", 512.0, "int8 op (256 multiply-adds on MFMA)", INT8_MFMA_PEAK_TOPS),
+    # the matcher forms each 256-bit Hamming distance as an FP4 (+-1) dot product on the matrix cores: 256 multiply-adds
+    # (a stream of nothing but these multiplies issues at 7.25 Pop/s on this chip: tools/mfma_fp4_probe.hip)
+    "match_knn2_kernel": ("(query, train) descriptor pairs", 512.0, "FP4 op (256 multiply-adds on MFMA)", FP4_MFMA_PEAK_TOPS),
 }
 
 
@@ -654,7 +656,8 @@ def main():
             mk = by_name["match_knn2_kernel"]
             mv = arithmetic_view("match_knn2_kernel", units_of("match_knn2_kernel"), mk["ms_per_launch"], full_batch)
             result["roofline_match"] = {"kernel": "match_knn2_kernel", "bound": "mfma", "achieved": mv["achieved"], "peak": mv["peak"],
-                                        "unit": "TOP/s (int8, dense)", "frac": mv["frac"],
+                                        "unit": "TOP/s (FP4, dense)", "frac": mv["frac"],
+                                        "frac_of_int8_peak": mv["achieved"] / INT8_MFMA_PEAK_TOPS,   # the form rounds 1-3 used
                                         "traffic": pmc_traffic("match_knn2_kernel") if full_batch else None,
                                         "avg_launch_ms": mk["ms_per_launch"],
                                         "hbm": {"achieved": mk["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mk["alg_GBps"] / HBM_PEAK_GBS},

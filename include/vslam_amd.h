@@ -102,6 +102,10 @@ const int8_t *vslam_brief_pattern_31(void);
  *       corners, and vslam_ctx_synchronize returns VSLAM_ERR_CAPACITY.  n > 0: n entries per frame (a test knob);
  *       -1: every list sized for the whole image, as before round 4 (nothing can overflow; 16 bytes per pixel and frame). */
 #define VSLAM_OPT_CORNER_LIST_CAP 7
+/*   VSLAM_OPT_MATCH_FORM  0 (default) / 1: the matcher forms Hamming distances as FP4 (+-1) dot products on the matrix
+ *       cores (v_mfma_scale_f32_32x32x64_f8f6f4); 2: as int8 (0 / 1) dot products (v_mfma_i32_32x32x32_i8).  Exact either
+ *       way, same results bit for bit; a tuning / test knob.                                                       */
+#define VSLAM_OPT_MATCH_FORM 8
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

@@ -18,12 +18,15 @@ def _pack(items, K):
     return torch.from_numpy(d).cuda(), torch.from_numpy(n).cuda()
 
 
-@pytest.fixture(params=[1, 2], ids=["8x32", "4x64"])
+@pytest.fixture(params=[(1, 1), (2, 1), (1, 2), (2, 2)], ids=["fp4-8x32", "fp4-4x64", "i8-8x32", "i8-4x64"])
 def shape(ctx, request):
-    """Both workgroup shapes of the MFMA matcher (VSLAM_OPT_MATCH_SHAPE; the default picks one by kp_stride)."""
-    ctx.set_option(ctx.OPT_MATCH_SHAPE, request.param)
+    """Both workgroup shapes (VSLAM_OPT_MATCH_SHAPE; the default picks one by kp_stride) of both matrix-core forms of the
+    matcher (VSLAM_OPT_MATCH_FORM: FP4 +-1 products, the default, and int8 0 / 1 products)."""
+    ctx.set_option(ctx.OPT_MATCH_SHAPE, request.param[0])
+    ctx.set_option(ctx.OPT_MATCH_FORM, request.param[1])
     yield request.param
     ctx.set_option(ctx.OPT_MATCH_SHAPE, 0)
+    ctx.set_option(ctx.OPT_MATCH_FORM, 0)
 
 
 def test_knn2_and_ratio_bit_exact_ragged_batch(ctx, oracle, shape):
@@ -69,3 +72,33 @@ def test_full_size_property_self_match(ctx, shape):
     assert torch.equal(knn[:, :, 0], inv) and int(knn[:, :, 1].abs().sum()) == 0
     assert torch.all(m == K)
     assert torch.equal(pairs[:, :, 1], inv)
+
+
+def test_extreme_distances_and_index_range(ctx, oracle, shape):
+    """Distances 0, 1, 255 and 256 (the +-1 products of the FP4 form then sum to +-256, where the key arithmetic changes
+    sign), all-zero and all-one descriptors, and train indices up to the largest a key can carry at this stride."""
+    rng = np.random.default_rng(77)
+    K = 2100
+    q = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    q[0] = 0; q[1] = 255; q[2] = 0; q[3] = 255
+    t = rng.integers(0, 256, (K, 32), dtype=np.uint8)
+    t[5] = ~q[10]                         # distance 256 from query 10
+    t[K - 1] = q[11]                      # distance 0 at the last index
+    t[K - 2] = q[11]; t[K - 2, 0] ^= 1    # distance 1 right before it
+    t[100] = 255; t[101] = 0              # |b| = 256 and 0
+    far = np.stack([~q[12]] * 40)         # a query whose two best are both far: every train row at distance >= 250
+    far[:, 0] ^= np.arange(40, dtype=np.uint8) % 7
+    d1, n1 = _pack([q, q[12:13]], K)
+    d2, n2 = _pack([t, far], K)
+    pairs, m, knn = ctx.match_knn2_ratio(d1, n1, d2, n2, want_knn=True)
+    ctx.synchronize()
+    knn, m, pairs = knn.cpu().numpy(), m.cpu().numpy(), pairs.cpu().numpy()
+    for b, (a, tr) in enumerate(((q, t), (q[12:13], far))):
+        i0, e0, i1, e1 = oracle.match_knn2(a, tr)
+        g = knn[b, :len(a)]
+        assert np.array_equal(g[:, 0], i0) and np.array_equal(g[:, 1], e0), b
+        assert np.array_equal(g[:, 2], i1) and np.array_equal(g[:, 3], e1), b
+        ref, _ = oracle.match_knn2_ratio(a, tr)
+        assert m[b] == len(ref) and np.array_equal(pairs[b, :m[b]], ref), b
+    assert knn[0, 11, 0] == K - 1 and knn[0, 11, 1] == 0 and knn[0, 11, 2] == K - 2 and knn[0, 11, 3] == 1
+    assert knn[1, 0, 1] >= 250

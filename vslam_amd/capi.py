@@ -115,6 +115,7 @@ class Context:
     OPT_CORNER_WINDOW_PCT = 5
     OPT_RANSAC_MIN_ITEMS = 6
     OPT_CORNER_LIST_CAP = 7
+    OPT_MATCH_FORM = 8
 
     def set_option(self, option, value):
         self._check(self.lib.vslam_ctx_set_option(self.handle, C.c_int(option), C.c_int(int(value))))

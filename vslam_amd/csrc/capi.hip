@@ -260,6 +260,11 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
         ctx->corner_window_pct = value;
         return VSLAM_OK;
     }
+    if (option == VSLAM_OPT_MATCH_FORM) {
+        VS_REQUIRE(ctx, value >= 0 && value <= 2, VSLAM_ERR_INVALID);
+        ctx->match_form = value;
+        return VSLAM_OK;
+    }
     if (option == VSLAM_OPT_CORNER_LIST_CAP) {
         VS_REQUIRE(ctx, value >= -1, VSLAM_ERR_INVALID);
         ctx->corner_list_cap = value;

@@ -45,6 +45,7 @@ struct vslam_ctx {
     int ransac_min_items = VSLAM_SET_SIZE;     // VSLAM_OPT_RANSAC_MIN_ITEMS: indices drawn per 8-wide set
     int ransac_solver = 0;                      // VSLAM_OPT_RANSAC_SOLVER: 0 exact Jacobi replay, 1 Gram / MFMA (not bit-exact)
     int match_shape = 0;                        // VSLAM_OPT_MATCH_SHAPE: 0 by size, 1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows
+    int match_form = 0;                         // VSLAM_OPT_MATCH_FORM: 0 default (FP4), 1 FP4, 2 int8
     int corner_window_pct = 135;                // VSLAM_OPT_CORNER_WINDOW_PCT
     int corner_list_cap = 0;                    // VSLAM_OPT_CORNER_LIST_CAP: 0 = 16 x max_corners + 4096, -1 = whole image
     bool ransac_all_sums = false;   // VSLAM_OPT_RANSAC_ALL_SUMS: exact residual sum of every hypothesis (ransac_score_kernel)

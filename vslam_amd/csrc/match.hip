@@ -346,6 +346,225 @@ __global__ __launch_bounds__(64 * kMQ / (32 * RT)) void match_knn2_mfma_kernel(
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same knn-2 with FP4 operands (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1, unit block scales): a descriptor bit becomes
+// the nibble +1.0 (bit 0) or -1.0 (bit 1), so a.b over the 256 positions is 256 - 2 Hamming(a, b) -- no |a|, |b| terms --
+// in four K = 64 steps at twice the int8 form's rate, with half the operand registers and half the LDS traffic.  Every
+// product is +-1 and every partial sum an integer below 2^9: the f32 accumulation is exact, so distances, indices and
+// the tie order are those of the other two kernels.  The running two best per (lane, row) are float keys
+// dot * 16384 - train index (exact: below 2^23), largest first = smallest distance, then lowest index: one v_fma_f32,
+// one v_med3_f32 and one v_max_f32 per result.  Layout (tools/mfma_fp4_probe.hip checks it on the device): A lane l = row
+// l & 31, B lane l = column l & 31, each carrying 32 positions of the step chosen by l >> 5; D as for the int8 form.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int kFStride = 144;          // bytes per expanded train row in LDS: 128 + 16 (as kMStride: rows spread over the banks)
+constexpr float kFScale = 16384.f;     // VSLAM_MAX_KP: the index occupies the low 14 bits of a key
+constexpr float kFPad = 33554432.f;    // "index" of a train row beyond nt: below every key of a real row
+constexpr float kFNone = -67108864.f;  // no candidate yet
+constexpr int kFBias = 0x05000000;     // biased integer form of a key for the cross-lane merge: u = kFBias - (int)key > 0
+
+__device__ __forceinline__ uint32_t spread8_pm1(uint32_t b) {   // 8 bits -> 8 nibbles: 0x2 (+1.0) | bit << 3 (sign)
+    uint32_t x = (b | (b << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return (x << 3) | 0x22222222u;
+}
+__device__ __forceinline__ v4i spread32_pm1(uint32_t w) {       // 32 bits -> 32 nibbles (16 bytes)
+    v4i r;
+    r.x = (int)spread8_pm1(w & 0xFFu);
+    r.y = (int)spread8_pm1((w >> 8) & 0xFFu);
+    r.z = (int)spread8_pm1((w >> 16) & 0xFFu);
+    r.w = (int)spread8_pm1(w >> 24);
+    return r;
+}
+__device__ __forceinline__ float med3_f32(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// The train descriptors of a pair spread to +-1 nibbles once (128 bytes per row) instead of by every workgroup that
+// streams them: seven workgroups of a pair at 2000 keypoints would each redo the same spreading, a quarter of the
+// matcher's vector instructions.  Row stride 128 bytes, kp_pad rows per pair (a multiple of the tile height).
+__global__ __launch_bounds__(256) void match_spread_kernel(const uint8_t *__restrict__ desc2, const int32_t *__restrict__ n2,
+                                                           int kp_stride, int kp_pad, uint8_t *__restrict__ tx) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;   // dword i & 7 of row i >> 3
+    const int row = i >> 3;
+    if (row >= n2[b]) return;
+    const uint32_t w = reinterpret_cast<const uint32_t *>(desc2 + (size_t)b * kp_stride * VSLAM_DESC_BYTES)[i];
+    *reinterpret_cast<v4i *>(tx + ((size_t)b * kp_pad + row) * 128 + (size_t)(i & 7) * 16) = spread32_pm1(w);
+}
+
+// PRE: the train rows come spread already (tx, match_spread_kernel); otherwise the workgroup spreads them itself.
+// CT = train tiles per trip of the main loop (one barrier per trip; 2 only with PRE).
+template <int RT, bool PRE, int CT>
+__global__ __launch_bounds__(64 * kMQ / (32 * RT)) void match_knn2_fp4_kernel(
+    const uint8_t *__restrict__ desc1, const int32_t *__restrict__ n1, const uint8_t *__restrict__ desc2,
+    const int32_t *__restrict__ n2, int kp_stride, int32_t *__restrict__ sel, int32_t *__restrict__ knn,
+    const uint8_t *__restrict__ tx, int kp_pad) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = n1[b], nt = n2[b];
+    const int qbase = blockIdx.x * kMQ;
+    if (qbase >= nq) return;   // uniform for the whole workgroup
+
+    static_assert(CT == 1 || PRE, "two tiles per trip only with pre-spread train rows");
+    __shared__ __align__(16) uint8_t s_b[2][CT * kMT * kFStride];
+    const uint32_t *q32 = reinterpret_cast<const uint32_t *>(desc1 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
+    const uint32_t *t32 = reinterpret_cast<const uint32_t *>(desc2 + (size_t)b * kp_stride * VSLAM_DESC_BYTES);
+    int32_t *sel_b = sel + (size_t)b * kp_stride;
+    int4 *knn_b = knn ? reinterpret_cast<int4 *>(knn) + (size_t)b * kp_stride : nullptr;
+
+    const int r = lane & 31, half = lane >> 5;
+    // A operands: this lane's row of each of the wave's 32-row tiles; step s takes dword 2 s + half of the descriptor
+    v8i a[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int q = min(qbase + wave * (32 * RT) + rt * 32 + r, nq - 1);   // rows past the end repeat the last one (never written)
+        const uint2 *qrow = reinterpret_cast<const uint2 *>(q32 + (size_t)q * 8);   // (a run-time index into a register
+#pragma unroll                                                                      //  array would put the array in LDS)
+        for (int s = 0; s < 4; s++) {
+            const uint2 w2 = qrow[s];
+            const v4i x = spread32_pm1(half ? w2.y : w2.x);
+            a[rt][s] = v8i{x.x, x.y, x.z, x.w, 0, 0, 0, 0};
+        }
+    }
+    float k1[RT][16], k2[RT][16];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            k1[rt][g] = kFNone;
+            k2[rt][g] = kFNone;
+        }
+
+    // Staging as in the int8 form: thread t owns dword t & 7 of row t >> 3 of every tile; with 8 waves (RT = 1) the two
+    // halves of the workgroup share a dword and expand 16 bits of it each.
+    constexpr bool kSplit = RT == 1;
+    const int st = kSplit ? (tid & 255) : tid, shalf = kSplit ? (tid >> 8) : 0;
+    const int srow = st >> 3, sd = st & 7;
+    // what a thread carries from global memory to LDS per tile: its packed dword, or (PRE) its 16 (8) spread bytes; rows beyond
+    // nt are never initialised in tx -- any nibble pattern is a finite number, and those columns' keys carry kFPad
+    struct Stage {
+        uint4 v[CT];
+    };
+    const uint8_t *txb = PRE ? tx + (size_t)b * kp_pad * 128 + (size_t)srow * 128 + sd * 16 + (kSplit ? 8 * shalf : 0) : nullptr;
+    auto fetch = [&](int trip) -> Stage {
+        Stage st_;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (PRE) {
+                const uint8_t *src = txb + (size_t)(trip * CT + c) * (kMT * 128);
+                if (kSplit) {
+                    const uint2 h = *reinterpret_cast<const uint2 *>(src);
+                    v.x = h.x;
+                    v.y = h.y;
+                } else {
+                    v = *reinterpret_cast<const uint4 *>(src);
+                }
+            } else {
+                const int t = trip * kMT + srow;
+                v.x = t < nt ? t32[(size_t)t * 8 + sd] : 0u;
+            }
+            st_.v[c] = v;
+        }
+        return st_;
+    };
+    auto expand = [&](const Stage &st_, int buf) {
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const uint4 v = st_.v[c];
+            uint8_t *dst = &s_b[buf][(c * kMT + srow) * kFStride + sd * 16];
+            if (PRE) {
+                if (kSplit) *reinterpret_cast<uint2 *>(dst + 8 * shalf) = make_uint2(v.x, v.y);
+                else *reinterpret_cast<uint4 *>(dst) = v;
+            } else if (kSplit) {
+                const uint32_t hw = (v.x >> (16 * shalf)) & 0xFFFFu;
+                *reinterpret_cast<uint2 *>(dst + 8 * shalf) = make_uint2(spread8_pm1(hw & 0xFFu), spread8_pm1(hw >> 8));
+            } else {
+                *reinterpret_cast<v4i *>(dst) = spread32_pm1(v.x);
+            }
+        }
+    };
+
+    // (A software pipeline over the tiles -- three LDS buffers, the multiplies of tile i + 1 issued in front of the bookkeeping
+    // of tile i, two accumulator sets -- was measured and is slower: 0.222 against 0.198 ms at C3, 1.72 against 1.53 at C5; it
+    // costs a wave per SIMD, and the waves of the other workgroups already fill the matrix pipe while this one keeps books.)
+    const int ntrips = (nt + CT * kMT - 1) / (CT * kMT);
+    if (ntrips > 0) expand(fetch(0), 0);
+    Stage w_next;
+    if (ntrips > 1) w_next = fetch(1);
+    __syncthreads();
+    for (int trip = 0; trip < ntrips; trip++) {
+        const int buf = trip & 1;
+        if (trip + 1 < ntrips) expand(w_next, buf ^ 1);   // the other buffer was last read two barriers ago
+        if (trip + 2 < ntrips) w_next = fetch(trip + 2);
+        v16f acc[CT][RT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) acc[c][rt] = v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const uint8_t *src = &s_b[buf][(c * kMT + r) * kFStride + 16 * half];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const v4i bq = *reinterpret_cast<const v4i *>(src + 32 * s);
+                const v8i bv = v8i{bq.x, bq.y, bq.z, bq.w, 0, 0, 0, 0};
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    acc[c][rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[rt][s], bv, acc[c][rt], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const int t = (trip * CT + c) * kMT + r;
+            const float nidx = t < nt ? -(float)t : -kFPad;   // key = dot * 16384 - index
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const float key = __builtin_fmaf(acc[c][rt][g], kFScale, nidx);
+                    k2[rt][g] = med3_f32(k1[rt][g], k2[rt][g], key);
+                    k1[rt][g] = fmaxf(k1[rt][g], key);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // merge over the 32 lanes of a half (different columns of the same rows) on the biased integer form (smaller = better)
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            uint32_t x1 = (uint32_t)(kFBias - (int)k1[rt][g]), x2 = (uint32_t)(kFBias - (int)k2[rt][g]);
+            merge2<0xB1>(x1, x2);    // quad_perm [1,0,3,2]
+            merge2<0x4E>(x1, x2);    // quad_perm [2,3,0,1]
+            merge2<0x141>(x1, x2);   // row_half_mirror: the other quad of the 8
+            merge2<0x140>(x1, x2);   // row_mirror: the other 8 of the 16
+            {                        // the other 16 of the 32: across DPP rows, through the LDS crossbar
+                const uint32_t o1 = __shfl_xor(x1, 16, 64), o2 = __shfl_xor(x2, 16, 64);
+                const uint32_t lo = min(x1, o1), hi = max(x1, o1);
+                x2 = min(hi, min(x2, o2));
+                x1 = lo;
+            }
+            if (r != g) continue;
+            // lane (g, half) of each row tile writes row (g & 3) + 8 (g >> 2) + 4 half
+            const int q = qbase + wave * (32 * RT) + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * half;
+            if (q >= nq) continue;
+            const int e1 = kFBias - (int)x1, e2 = kFBias - (int)x2;             // dot * 16384 - index
+            const int dot1 = (e1 + 16383) >> 14, dot2 = (e2 + 16383) >> 14;     // ceil (arithmetic shift: floor)
+            const int i0 = dot1 * 16384 - e1, i1 = dot2 * 16384 - e2;
+            const int d0 = (256 - dot1) >> 1, d1 = (256 - dot2) >> 1;
+            const bool pass = (nt >= 2) && (10 * d0 < 7 * d1);
+            sel_b[q] = pass ? i0 : -1;
+            if (knn_b) {
+                int4 o;
+                o.x = nt >= 1 ? i0 : -1;
+                o.y = nt >= 1 ? d0 : 0x7FFFFFFF;
+                o.z = nt >= 2 ? i1 : -1;
+                o.w = nt >= 2 ? d1 : 0x7FFFFFFF;
+                knn_b[q] = o;
+            }
+        }
+}
+
 // Ordered compaction of the ratio-test survivors into (queryIdx, trainIdx) pairs, query order
 // (the reference's i_matches.push_back loop, src/Frame.cpp:89-94).  One workgroup per pair.
 __global__ __launch_bounds__(kThreads) void match_compact_kernel(const int32_t *__restrict__ sel,
@@ -415,7 +634,34 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
             const int pick = ctx->match_shape ? ctx->match_shape : (shape ? (shape[0] == '4' ? 2 : 1) : 0);
             const bool wide = pick ? pick == 2 : kp_stride <= 2048;
             dim3 grid(vs_div_up(kp_stride, kMQ), batch);
-            if (wide) match_knn2_mfma_kernel<2><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
+            static const char *form = getenv("VSLAM_MATCH_FORM");   // "i8": the int8 form (A/B timing); default FP4
+            const bool fp4 = ctx->match_form ? ctx->match_form == 1 : !(form && form[0] == 'i');
+            if (fp4) {
+                // The FP4 form as measured (tools/ab_match.sh, kernel alone, C3 / C5 in ms; int8 form: 0.279 / 1.97):
+                //   8 x 32, pre-spread, 2 tiles per trip   0.186 / 1.30   <- the default
+                //   8 x 32, pre-spread, 1 tile per trip    0.191 / 1.34
+                //   4 x 64, pre-spread, 1 (2) per trip     0.200 (0.205) / 1.35 (1.38)
+                //   8 x 32 / 4 x 64 spreading in place     0.198 / 1.51 and 0.208 / 1.44
+                // (8 x 32: 5 waves per SIMD; the pre-spread rows pay more the more workgroups share them)
+                const bool wide4 = pick == 2;
+                static const char *nopre = getenv("VSLAM_MATCH_NO_PRESPREAD");   // A/B timing: every workgroup spreads for itself
+                static const char *ct_env = getenv("VSLAM_MATCH_TILES_PER_TRIP");
+                const int ct = ct_env ? atoi(ct_env) : 2;
+                if (!nopre) {
+                    const int kp_pad = vs_div_up(kp_stride, 2 * kMT) * 2 * kMT;
+                    uint8_t *tx = nullptr;
+                    if ((rc = vs_arena_get(ctx, "match.spread", (size_t)batch * kp_pad * 128, (void **)&tx))) return rc;
+                    match_spread_kernel<<<dim3(vs_div_up(kp_stride * 8, 256), batch), 256, 0, ctx->stream>>>(d2, n2, kp_stride, kp_pad, tx);
+                    if (wide4 && ct == 2) match_knn2_fp4_kernel<2, true, 2><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
+                    else if (wide4) match_knn2_fp4_kernel<2, true, 1><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
+                    else if (ct == 2) match_knn2_fp4_kernel<1, true, 2><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
+                    else match_knn2_fp4_kernel<1, true, 1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
+                } else if (wide4) {
+                    match_knn2_fp4_kernel<2, false, 1><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, nullptr, 0);
+                } else {
+                    match_knn2_fp4_kernel<1, false, 1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, nullptr, 0);
+                }
+            } else if (wide) match_knn2_mfma_kernel<2><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
             else match_knn2_mfma_kernel<1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
         }
     }
