@@ -106,6 +106,11 @@ const int8_t *vslam_brief_pattern_31(void);
  *       cores (v_mfma_scale_f32_32x32x64_f8f6f4); 2: as int8 (0 / 1) dot products (v_mfma_i32_32x32x32_i8).  Exact either
  *       way, same results bit for bit; a tuning / test knob.                                                       */
 #define VSLAM_OPT_MATCH_FORM 8
+/*   VSLAM_OPT_TREE_FORK  where vslam_frontend_pairs / _sequence start the k-d build (an output of the path that no later
+ *       stage reads) on the auxiliary stream: -1 (default) by size (behind the matcher up to 2048 keypoint slots, in front
+ *       of it above), 0 in front of the matcher, 1 behind it, 2 behind the set mapping, 3 behind the 8-point solves,
+ *       4 behind the screen.  The call's last kernel waits for it.  Same results; a tuning knob.                       */
+#define VSLAM_OPT_TREE_FORK 9
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 
 /* device memory + copies for hosts that have no other allocator (the C++ adapters) */

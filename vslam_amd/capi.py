@@ -116,6 +116,7 @@ class Context:
     OPT_RANSAC_MIN_ITEMS = 6
     OPT_CORNER_LIST_CAP = 7
     OPT_MATCH_FORM = 8
+    OPT_TREE_FORK = 9
 
     def set_option(self, option, value):
         self._check(self.lib.vslam_ctx_set_option(self.handle, C.c_int(option), C.c_int(int(value))))

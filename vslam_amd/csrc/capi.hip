@@ -37,6 +37,40 @@ static int vs_default_pattern(vslam_ctx *ctx, const int8_t **out) {
     return VSLAM_OK;
 }
 
+int vs_aux_job_point(vslam_ctx *ctx, int point) {
+    if (ctx->aux_job_at != point || !ctx->aux_job) return VSLAM_OK;
+    ctx->aux_job_at = 0;
+    VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->aux_stream;
+    const int rc = ctx->aux_job();
+    ctx->stream = main_stream;
+    ctx->aux_job = nullptr;
+    if (rc) return rc;
+    VS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    return VSLAM_OK;
+}
+
+// Hand the k-d build of `frames` frames to the matching stages (see ctx.h: aux_job).  Where it is forked: beside the
+// matcher it takes the matcher's wave slots and registers; behind it, it runs beside the set mapping (one workgroup per
+// pair) and the first solves.  Measured (tools/ab_step.py, one process, alternating blocks): at C3 (2000 keypoints: the
+// build outlasts the FP4 matcher, 0.29 against 0.19 ms) 2.91 ms in front of the matcher, 2.85 behind it, 2.86 behind the set
+// mapping, 2.89 behind the solves, 2.95 behind the screen (2.78 with no trees at all); at C5 (4000 keypoints: the matcher
+// is the longer one, 1.30 against 1.08 ms) 15.26 in front, 15.31 behind.  So: behind the matcher up to 2048 keypoint slots.
+static int vs_defer_tree_build(vslam_ctx *ctx, const float *d_xy, const int32_t *d_n, int frames, int kp_stride, int32_t *d_nodes) {
+    ctx->aux_job = [=]() { return vs_launch_kdtree_build(ctx, d_xy, d_n, frames, kp_stride, d_nodes); };
+    ctx->aux_job_at = ctx->tree_fork >= 0 ? ctx->tree_fork : (kp_stride <= 2048 ? 1 : 0);
+    return vs_aux_job_point(ctx, 0);
+}
+struct VsAuxGuard {   // a job that was never forked (an error return in between) must not outlive the call that made it
+    vslam_ctx *c;
+    ~VsAuxGuard() {
+        c->aux_job = nullptr;
+        c->aux_job_at = 0;
+    }
+};
+
 int vs_device_errflag(vslam_ctx *ctx, int32_t **out) {
     const bool fresh = ctx->arena.find("ctx.errflag") == ctx->arena.end();
     int rc = vs_arena_get(ctx, "ctx.errflag", sizeof(int32_t), (void **)out);
@@ -258,6 +292,11 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
     if (option == VSLAM_OPT_CORNER_WINDOW_PCT) {
         VS_REQUIRE(ctx, value >= 0 && value <= 100000, VSLAM_ERR_INVALID);
         ctx->corner_window_pct = value;
+        return VSLAM_OK;
+    }
+    if (option == VSLAM_OPT_TREE_FORK) {
+        VS_REQUIRE(ctx, value >= -1 && value <= 4, VSLAM_ERR_INVALID);
+        ctx->tree_fork = value;
         return VSLAM_OK;
     }
     if (option == VSLAM_OPT_MATCH_FORM) {
@@ -619,6 +658,7 @@ int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_de
     if ((rc = vs_arena_get(ctx, "mf.mask", bk, (void **)&mask))) return rc;
 
     if ((rc = vs_launch_match(ctx, d_desc1, d_n1, d_desc2, d_n2, batch, kp_stride, pairs, m, nullptr))) return rc;
+    if ((rc = vs_aux_job_point(ctx, 1))) return rc;
     if (ctx->raw_seeds == d_seeds && ctx->raw_batch == batch && ctx->raw_hyp == hyp) {
         // the raw generator outputs were produced ahead of time (vs_sets_prefetch): only the mapping is left
         uint32_t *raw = nullptr;
@@ -629,6 +669,7 @@ int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_de
     } else if ((rc = vs_launch_ransac_sets(ctx, d_seeds, m, batch, hyp, sets, draws))) {
         return rc;
     }
+    if ((rc = vs_aux_job_point(ctx, 2))) return rc;
     return vs_launch_ransac(ctx, d_xy1, d_xy2, pairs, m, sets, batch, kp_stride, hyp, threshold, d_F, mask,
                             d_best, d_matches, hypF, hyp_count, hyp_sum);
 }
@@ -675,16 +716,9 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     rc = vslam_extract_features(ctx, d_bgr, 2 * pairs, width, height, row_stride, params, kp_stride,
                                     d_xy, d_desc, overlap ? nullptr : d_nodes, d_n, nullptr);
     if (rc) return rc;
-    if (overlap) {
-        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-        hipStream_t main_stream = ctx->stream;
-        ctx->stream = ctx->aux_stream;
-        rc = vs_launch_kdtree_build(ctx, d_xy, d_n, 2 * pairs, kp_stride, d_nodes);
-        ctx->stream = main_stream;
-        if (rc) return rc;
-        VS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
-    }
+    VsAuxGuard aux_guard{ctx};
+    if (overlap)
+        if ((rc = vs_defer_tree_build(ctx, d_xy, d_n, 2 * pairs, kp_stride, d_nodes))) return rc;
     const size_t half = (size_t)pairs * kp_stride;
     rc = vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * half, d_desc + VSLAM_DESC_BYTES * half,
                               d_n + pairs, pairs, kp_stride, d_seeds, hyp, threshold, d_matches, d_best,
@@ -738,16 +772,9 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
     rc = vslam_extract_features(ctx, d_bgr, frames, width, height, row_stride, params, kp_stride, d_xy, d_desc,
                                     overlap ? nullptr : d_nodes, d_n, nullptr);
     if (rc) return rc;
-    if (overlap) {
-        VS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-        hipStream_t main_stream = ctx->stream;
-        ctx->stream = ctx->aux_stream;
-        rc = vs_launch_kdtree_build(ctx, d_xy, d_n, frames, kp_stride, d_nodes);
-        ctx->stream = main_stream;
-        if (rc) return rc;
-        VS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
-    }
+    VsAuxGuard aux_guard{ctx};
+    if (overlap)
+        if ((rc = vs_defer_tree_build(ctx, d_xy, d_n, frames, kp_stride, d_nodes))) return rc;
     const size_t one = (size_t)kp_stride;
     rc = vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * one, d_desc + VSLAM_DESC_BYTES * one, d_n + 1,
                               frames - 1, kp_stride, d_seeds, hyp, threshold, d_matches, d_best, d_F, nullptr);

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -38,6 +39,13 @@ struct vslam_ctx {
     hipEvent_t ev_raw = nullptr;
     const uint32_t *raw_seeds = nullptr;
     int raw_batch = 0, raw_hyp = 0;
+    // An independent stage (the k-d build: an output of the path, nobody's input) that vslam_frontend_pairs / _sequence hand
+    // to the matching stages to be forked onto the auxiliary stream at the point where it disturbs them least:
+    // aux_job_at = 1 after the matcher, 2 after the set mapping, 3 after the solves, 4 after the screen (0: at once / none).  vs_aux_job_point(ctx, k)
+    // launches it when k is that point; the caller joins on ev_join.
+    std::function<int()> aux_job;
+    int aux_job_at = 0;
+    int tree_fork = -1;   // VSLAM_OPT_TREE_FORK: where the batched front-end forks the k-d build (-1: by size; 0 in front of the matcher)
     int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, otherwise on the auxiliary stream from min_eigen (where the gray image is complete) on
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     bool rbrief_table_ready = false; // transient: the rotated rBRIEF table of the coming describe call is already queued
@@ -86,6 +94,9 @@ struct vslam_ctx {
 // sticky device-side error word (bit 0: a fixed-size candidate list overflowed); vslam_ctx_synchronize
 // reads and clears it and reports VSLAM_ERR_CAPACITY
 int vs_device_errflag(vslam_ctx *ctx, int32_t **out);
+
+// fork the pending auxiliary job (if it was asked for at `point`) onto the auxiliary stream behind everything queued so far
+int vs_aux_job_point(vslam_ctx *ctx, int point);
 
 // grow-only named workspace
 int vs_arena_get(vslam_ctx *ctx, const char *name, size_t bytes, void **out);

@@ -2293,6 +2293,7 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
             VsProfScope ps(ctx, "ransac_cand_kernel");
             ransac_cand_kernel<<<batch, 64 * kCandMax, 0, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0, cbound);
         }
+        if (int arc = vs_aux_job_point(ctx, 4)) return arc;
         {
             VsProfScope ps(ctx, "ransac_count_kernel");
             const bool lds = kp_pad <= kCntLdsMatches;
@@ -2359,6 +2360,7 @@ int vs_launch_ransac(vslam_ctx *ctx, const float *xy1, const float *xy2, const i
                      float *hypF, int32_t *hyp_count, float *hyp_sum) {
     int rc = vs_launch_ransac_solve(ctx, xy1, xy2, pairs, m, sets, batch, kp_stride, hyp, hypF);
     if (rc) return rc;
+    if ((rc = vs_aux_job_point(ctx, 3))) return rc;
     return vs_launch_ransac_evaluate(ctx, xy1, xy2, pairs, m, hypF, batch, kp_stride, hyp, threshold, F, mask,
                                      best, matches, hyp_count, hyp_sum);
 }
