@@ -166,21 +166,24 @@ def counters_current(kernel=None):
     return f is not None and then.get(f) == now.get(f)
 
 
-def _profile_row(path, kernel):
+def _profile_row(path, kernel, weight):
+    """The committed counter row of the kernel that runs under timing slot `kernel`; where several variants share a slot
+    (the pool's idle min_eigen_v4 launches beside min_eigen_tiered) the one with the largest `weight` column."""
     import csv
     from vslam_amd.profnames import slot_of
     if not os.path.exists(path) or not counters_current(kernel):
         return None
+    best = None
     with open(path) as f:
         for r in csv.DictReader(f):
-            if slot_of(r["kernel"]) == kernel:
-                return r
-    return None
+            if slot_of(r["kernel"]) == kernel and (best is None or float(r[weight]) > float(best[weight])):
+                best = r
+    return best
 
 
 def sq_counters(kernel):
     """(waves per launch, VALU instructions per wave, VALU-busy cycles per wave) from the committed rocprofv3 SQ summary."""
-    r = _profile_row(SQ_PROFILE, kernel)
+    r = _profile_row(SQ_PROFILE, kernel, "valu_insts_per_wave")
     if r is None:
         return None
     return float(r["waves_per_launch"]), float(r["valu_insts_per_wave"]), float(r.get("valu_busy_cycles_per_wave") or 0.0)
@@ -221,10 +224,16 @@ def arithmetic_view(kernel, units, ms_per_launch, full_batch):
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/, C3 batch of 256 pairs);
     bench.py cannot collect PMC counters on itself."""
-    r = _profile_row(PMC_PROFILE, kernel)
-    if r is None:
+    import csv
+    from vslam_amd.profnames import slot_of
+    if _profile_row(PMC_PROFILE, kernel, "FETCH_SIZE_KiB_per_launch") is None:
         return None
-    return (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
+    total = 0.0   # every kernel accounted under the slot (the matcher's spreading pre-pass, the pool's idle launches)
+    with open(PMC_PROFILE) as f:
+        for r in csv.DictReader(f):
+            if slot_of(r["kernel"]) == kernel:
+                total += (float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])) * 1e6
+    return total
 
 
 def _cpu_worker(args):

@@ -8,8 +8,8 @@ import re
 
 _OURS = re.compile(r"^(?:void\s+)?(?:\(anonymous namespace\)::)?([a-z][a-z0-9_]*_kernel)\b")
 # variants of one stage share the stage's timing slot (VsProfScope name) in the library's own per-kernel timing
-_VARIANT = re.compile(r"_(v4|stream|tiered|lds|mfma|tile)_kernel$")
-_SLOT = {"ransac_map_kernel": "ransac_sets_kernel"}
+_VARIANT = re.compile(r"_(v4|stream|tiered|lds|mfma|fp4|tile)_kernel$")
+_SLOT = {"ransac_map_kernel": "ransac_sets_kernel", "match_spread_kernel": "match_knn2_kernel"}
 
 
 def kernel_id(printed_name):
