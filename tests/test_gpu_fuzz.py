@@ -1,4 +1,4 @@
-"""Fixed slices of the randomised parity runs (tests/fuzz_extract.py, tests/fuzz_ransac.py)."""
+"""Fixed slices of the randomised parity runs (tests/fuzz_extract.py, tests/fuzz_match.py, tests/fuzz_ransac.py)."""
 import pytest
 
 import fuzz_extract
@@ -8,6 +8,11 @@ pytestmark = pytest.mark.gpu
 
 def test_extraction_stages_on_random_shapes(ctx, oracle):
     assert fuzz_extract.run(ctx, oracle, seed=20261004, cases=150) == 150
+
+
+def test_matcher_on_random_ragged_batches(ctx, oracle):
+    import fuzz_match
+    assert fuzz_match.run(ctx, oracle, seed=20261006, cases=120) == 120
 
 
 def test_ransac_kernels_on_random_and_degenerate_inputs(ctx, oracle):

@@ -68,6 +68,23 @@ def test_multi_device_records_do_not_depend_on_the_split(batch, reference, slots
         md.close()
 
 
+def test_more_slots_than_pairs(batch, reference):
+    """Three pairs over five slots: two slices are empty and their contexts stay idle."""
+    last, cur = batch
+    ca, sa = synth.keypoint_rotation()
+    md = capi.MultiDevice([0] * 5)
+    try:
+        rec, n = md.frontend_pairs(last[:3], cur[:3], MAXC, ca, sa, None, SEED, HYP, THR)
+    finally:
+        md.close()
+    Fm, best, matches = shard.unpack_records(torch.from_numpy(rec), MAXC)
+    for i in range(3):
+        r = reference[i][2]
+        k = len(r["matches"])
+        assert int(best[i, 3]) == k and np.array_equal(matches[i, :k].numpy(), r["matches"]), i
+        assert np.array_equal(Fm[i].numpy().view(np.uint32), r["F"].view(np.uint32)), i
+
+
 def test_multi_device_rejects_bad_arguments(batch):
     last, cur = batch
     with pytest.raises(capi.VslamError):
