@@ -37,6 +37,8 @@ CONFIGS = {
     "fp4, no k-d trees": {ctx.OPT_MATCH_FORM: 0, ctx.OPT_MATCH_SHAPE: 0, "nodes": False},
     "int8 4x64, no k-d trees": {ctx.OPT_MATCH_FORM: 2, ctx.OPT_MATCH_SHAPE: 2, "nodes": False},
 }
+if os.environ.get("AB_ONLY_DEFAULT"):   # process-level knobs (environment variables) are compared across processes
+    CONFIGS = {k: v for k, v in CONFIGS.items() if k in ("fp4 (default)", "fp4, no k-d trees")}
 out = None
 times = {k: [] for k in CONFIGS}
 for rnd in range(rounds + 1):

@@ -186,8 +186,10 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <class S>
-__device__ int wave_partition(S &s, int a, int b, typename S::key_type pv, int *sl, int *sr) {
+// I = the stopper lists' element type: positions are below 16384 here, so 16-bit lists do (they are what decides how many
+// tree builds fit a CU's LDS at 4000 keypoints)
+template <class S, class I>
+__device__ int wave_partition(S &s, int a, int b, typename S::key_type pv, I *sl, I *sr) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nL = 0, nR = 0;
@@ -195,14 +197,14 @@ __device__ int wave_partition(S &s, int a, int b, typename S::key_type pv, int *
         const int p = p0 + lane;
         const bool st = p < b && !s.less(s.key(p), pv);
         const unsigned long long bal = __ballot(st);
-        if (st) sl[a + nL + (int)__popcll(bal & lt)] = p;
+        if (st) sl[a + nL + (int)__popcll(bal & lt)] = (I)p;
         nL += (int)__popcll(bal);
     }
     for (int p0 = b - 1; p0 >= a - 1; p0 -= 64) {   // right stoppers, descending, pivot slot a-1 included
         const int p = p0 - lane;
         const bool st = p >= a - 1 && !s.less(pv, s.key(p));
         const unsigned long long bal = __ballot(st);
-        if (st) sr[a + nR + (int)__popcll(bal & lt)] = p;
+        if (st) sr[a + nR + (int)__popcll(bal & lt)] = (I)p;
         nR += (int)__popcll(bal);
     }
     wave_sync_lds();
@@ -210,20 +212,20 @@ __device__ int wave_partition(S &s, int a, int b, typename S::key_type pv, int *
     int K = 0;
     for (int k0 = 0; k0 < m; k0 += 64) {   // pairs are monotone: count the leading L_k < R_k
         const int k = k0 + lane;
-        const bool sw = k < m && sl[a + k] < sr[a + k];
+        const bool sw = k < m && (int)sl[a + k] < (int)sr[a + k];
         const unsigned long long bal = __ballot(sw);
-        if (sw) s.swap(sl[a + k], sr[a + k]);
+        if (sw) s.swap((int)sl[a + k], (int)sr[a + k]);
         K += (int)__popcll(bal);
         if (bal != ~0ull) break;
     }
-    const int cl = K < nL ? sl[a + K] : 0x7FFFFFFF;
-    const int cr = K > 0 ? sr[a + K - 1] : 0x7FFFFFFF;
+    const int cl = K < nL ? (int)sl[a + K] : 0x7FFFFFFF;
+    const int cr = K > 0 ? (int)sr[a + K - 1] : 0x7FFFFFFF;
     wave_sync_lds();
     return cl < cr ? cl : cr;
 }
 
-template <class S>
-__device__ void wave_nth_element(S &s, int first, int nth, int last, int *sl, int *sr) {
+template <class S, class I>
+__device__ void wave_nth_element(S &s, int first, int nth, int last, I *sl, I *sr) {
     const int lane = threadIdx.x & 63;
     if (first == last || nth == last) return;
     int depth_limit = floor_lg(last - first) * 2;

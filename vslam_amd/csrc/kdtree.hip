@@ -30,19 +30,20 @@ struct Triple {
     int id;
 };
 
+template <class I>   // I: how point indices are kept in LDS (int, or uint16_t: they are below 16384)
 struct LdsStore {
     using value_type = Triple;
     using key_type = float;
     float *kx, *ky;
-    int *id;
+    I *id;
     const float *kaxis;   // kx or ky: the coordinate this level splits on
     bool use_y;
-    __device__ LdsStore(float *x, float *y, int *i, int axis) : kx(x), ky(y), id(i), kaxis(axis ? y : x), use_y(axis != 0) {}
-    __device__ Triple get(int i) const { return Triple{kx[i], ky[i], id[i]}; }
+    __device__ LdsStore(float *x, float *y, I *i, int axis) : kx(x), ky(y), id(i), kaxis(axis ? y : x), use_y(axis != 0) {}
+    __device__ Triple get(int i) const { return Triple{kx[i], ky[i], (int)id[i]}; }
     __device__ void set(int i, const Triple &t) {
         kx[i] = t.x;
         ky[i] = t.y;
-        id[i] = t.id;
+        id[i] = (I)t.id;
     }
     __device__ void swap(int i, int j) {
         const Triple a = get(i), b = get(j);
@@ -56,7 +57,7 @@ struct LdsStore {
 };
 
 // T = threads per workgroup; ranges shorter than MINLEN: one lane per subtree is cheaper than a wave each
-template <int T, int MINLEN>
+template <int T, int MINLEN, class I>
 __global__ __launch_bounds__(T) void kdtree_build_kernel(const float *__restrict__ xy,
                                                                      const int32_t *__restrict__ n_arr,
                                                                      int kp_stride,
@@ -67,16 +68,16 @@ __global__ __launch_bounds__(T) void kdtree_build_kernel(const float *__restrict
     if (n <= 0) return;   // root = NULL, src/KDTree.cpp:109-110
     float *kx = reinterpret_cast<float *>(smem);
     float *ky = kx + kp_stride;
-    int *id = reinterpret_cast<int *>(ky + kp_stride);
-    int *sl = id + kp_stride;            // stopper lists of the wave-cooperative partition
-    int *sr = sl + kp_stride + 1;
+    I *id = reinterpret_cast<I *>(ky + kp_stride);
+    I *sl = id + kp_stride;              // stopper lists of the wave-cooperative partition
+    I *sr = sl + kp_stride + 1;
     const float2 *P = reinterpret_cast<const float2 *>(xy) + (size_t)b * kp_stride;
     int32_t *out = nodes + (size_t)b * kp_stride;
     for (int i = tid; i < n; i += T) {
         const float2 p = P[i];
         kx[i] = p.x;
         ky[i] = p.y;
-        id[i] = i;   // point_indices = 0..N-1, :113-117
+        id[i] = (I)i;   // point_indices = 0..N-1, :113-117
     }
     __syncthreads();
 
@@ -100,14 +101,14 @@ __global__ __launch_bounds__(T) void kdtree_build_kernel(const float *__restrict
                 }
             }
             if (last > first) {
-                LdsStore s(kx, ky, id, depth & 1);
+                LdsStore<I> s(kx, ky, id, depth & 1);
                 const int mid = first + (last - first) / 2;
                 if (by_wave) {
                     vs_sel::wave_nth_element(s, first, mid, last, sl, sr);
-                    if (lane == 0) out[pos] = id[mid];
+                    if (lane == 0) out[pos] = (int32_t)id[mid];
                 } else {
                     vs_sel::nth_element(s, first, mid, last);
-                    out[pos] = id[mid];
+                    out[pos] = (int32_t)id[mid];
                 }
             }
         }
@@ -275,7 +276,13 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
                            int32_t *nodes) {
     VS_REQUIRE(ctx, xy && n && nodes, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, batch > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
-    const size_t lds = (size_t)kp_stride * 20 + 8;
+    // Point indices and the partition's stopper lists as 16-bit values (keypoint slots are below VSLAM_MAX_KP = 16384): 14
+    // instead of 20 bytes of LDS per point.  At 4000 keypoints that is 56 KB per tree, so two builds share a CU where
+    // 80 KB allowed one (VSLAM_KD_IDX16=0 / 1 forces either form; same trees).
+    static const char *idx_env = getenv("VSLAM_KD_IDX16");
+    const bool idx16 = idx_env ? idx_env[0] == '1' : true;
+    const size_t lds = idx16 ? (((size_t)kp_stride * 8 + (size_t)kp_stride * 2 * 3 + 4 + 15) & ~(size_t)15) : (size_t)kp_stride * 20 + 8;
+    VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
     VS_REQUIRE(ctx, lds <= 160 * 1024 - 512, VSLAM_ERR_CAPACITY);
     // Workgroup size by batch: with few trees in flight (the one-frame-at-a-time drop-in use) sixteen waves take the 8, 16
     // and 32 subtrees of depths 3-5 in one or two rounds instead of up to eight (one 2000-point tree: 0.24 -> 0.17 ms);
@@ -283,17 +290,19 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
     static const char *shape_env = getenv("VSLAM_KD_THREADS");   // 256 / 1024 force one (A/B timing)
     const int threads = shape_env ? atoi(shape_env) : (batch <= 32 ? 1024 : 256);
     VsProfScope ps(ctx, "kdtree_build_kernel");
-#define VS_KD_LAUNCH(T, M)                                                                                                  \
+#define VS_KD_LAUNCH(T, M, I)                                                                                               \
     do {                                                                                                                    \
-        if (!ctx->attr_done["kdtree_build" #T "_" #M]) {                                                                    \
-            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kdtree_build_kernel<T, M>),                      \
+        if (!ctx->attr_done["kdtree_build" #T "_" #M #I]) {                                                                 \
+            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kdtree_build_kernel<T, M, I>),                   \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));                 \
-            ctx->attr_done["kdtree_build" #T "_" #M] = true;                                                                \
+            ctx->attr_done["kdtree_build" #T "_" #M #I] = true;                                                             \
         }                                                                                                                   \
-        kdtree_build_kernel<T, M><<<batch, T, lds, ctx->stream>>>(xy, n, kp_stride, nodes);                                 \
+        kdtree_build_kernel<T, M, I><<<batch, T, lds, ctx->stream>>>(xy, n, kp_stride, nodes);                              \
     } while (0)
-    if (threads == 1024) VS_KD_LAUNCH(1024, 48);
-    else VS_KD_LAUNCH(256, 48);
+    if (threads == 1024 && idx16) VS_KD_LAUNCH(1024, 48, uint16_t);
+    else if (threads == 1024) VS_KD_LAUNCH(1024, 48, int);
+    else if (idx16) VS_KD_LAUNCH(256, 48, uint16_t);
+    else VS_KD_LAUNCH(256, 48, int);
 #undef VS_KD_LAUNCH
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
