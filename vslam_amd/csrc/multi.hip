@@ -108,6 +108,14 @@ int vslam_multi_frontend_pairs(vslam_multi *m, const uint8_t *h_bgr_last, const 
         return VSLAM_ERR_INVALID;
     }
     const int world = (int)m->members.size();
+    int callers_device = -1;   // slice 0 runs on the calling thread: its current device is put back afterwards
+    (void)hipGetDevice(&callers_device);
+    struct DeviceGuard {
+        int dev;
+        ~DeviceGuard() {
+            if (dev >= 0) (void)hipSetDevice(dev);
+        }
+    } device_guard{callers_device};
     const size_t frame_bytes = (size_t)height * row_stride;
     const size_t words = 13 + (size_t)kp_stride;
     auto work = [&](int r) {
