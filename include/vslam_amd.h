@@ -64,10 +64,12 @@ const int8_t *vslam_brief_pattern_31(void);
  *       (src/RansacFilter.cpp:59: a hypothesis matters only if its inlier count is the pair's maximum, and its
  *       residual sum only breaks ties among those).  Every hypothesis that reaches the maximum count is counted in
  *       full and exactly; a hypothesis is abandoned as soon as it can no longer reach a count already verified for
- *       the pair.  d_hyp_count holds the maximum for the hypotheses that reach it and -1 for all others; d_hyp_sum
- *       holds the exact sum where it can still decide the winner, -inf for maximum-count hypotheses a certified bound
- *       places below the winner's, NaN below the maximum count.  Winner, mask, F and matches are the reference's
- *       either way.
+ *       the pair -- or (round 4) can at best TIE such a count while a certified bound puts its residual sum below
+ *       that of a hypothesis verified to reach it: among equal counts the rule keeps the larger sum, so it can neither
+ *       win nor tie.  d_hyp_count holds the maximum for the hypotheses that reach it -- except for those abandoned on
+ *       the sum -- and -1 for all others; d_hyp_sum holds the exact sum where it can still decide the winner, -inf for
+ *       maximum-count hypotheses a certified bound places below the winner's, NaN where the count is -1.  Winner,
+ *       mask, F and matches are the reference's either way.
  *       1: the count and the residual sum of EVERY hypothesis are computed as the reference does (:105-140) — what
  *       the per-hypothesis parity tests ask for; about 3x the scoring time.
  *   VSLAM_OPT_RANSAC_MIN_MATCHES  8 (default) .. 1: vslam_ransac_evaluate skips items with fewer matches than this

@@ -65,8 +65,9 @@ def run(ctx, o, seed, cases=None, seconds=None):
             tag = (done, b, n, Hy, thr)
             assert np.array_equal(bits(out["hypF"][b]), bits(ref["hypF"])), ("hypF",) + tag
             from test_gpu_ransac import check_counts, check_sums
-            check_counts(out["hyp_count"][b], ref["hyp_count"], "all" if all_sums else "ties", ("count",) + tag)
-            check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], "all" if all_sums else "ties", ("sum",) + tag)
+            check_counts(out["hyp_count"][b], ref["hyp_count"], "all" if all_sums else "ties", ("count",) + tag, ref["hyp_sum"])
+            check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], "all" if all_sums else "ties", ("sum",) + tag,
+                       out["hyp_count"][b])
             assert out["best"][b, 0] == ref["winner"], ("winner",) + tag
             if ref["winner"] >= 0:
                 assert out["best"][b, 1] == ref["count"], ("best count",) + tag

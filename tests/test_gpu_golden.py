@@ -42,8 +42,8 @@ def test_ransac_golden(ctx):
         out = {k: v.cpu().numpy() for k, v in out.items()}
         assert np.array_equal(bits(out["hypF"][0]), bits(G["r_hypF"]))
         from test_gpu_ransac import check_counts, check_sums
-        check_counts(out["hyp_count"][0], G["r_hyp_count"], "all" if all_sums else "ties")
-        check_sums(out["hyp_sum"][0], G["r_hyp_count"], G["r_hyp_sum"], "all" if all_sums else "ties")
+        check_counts(out["hyp_count"][0], G["r_hyp_count"], "all" if all_sums else "ties", None, G["r_hyp_sum"])
+        check_sums(out["hyp_sum"][0], G["r_hyp_count"], G["r_hyp_sum"], "all" if all_sums else "ties", None, out["hyp_count"][0])
         assert np.array_equal(bits(out["F"][0]), bits(G["r_F"])) and np.array_equal(out["mask"][0, :100], G["r_mask"])
         assert out["best"][0, :3].tolist() == G["r_best"].tolist()
 

@@ -22,20 +22,38 @@ def sums_mode(ctx, request):
     ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
 
 
-def check_counts(got_count, ref_count, mode, tag=None):
-    """'all' mode: every count exact.  Default mode: the hypotheses that reach the pair's maximum count carry it (they
-    are always counted in full); every other hypothesis reads -1 — the counting kernel abandons a hypothesis as soon as
-    it can no longer reach a count already verified for the pair, so what it knows about the others is only that."""
+def _beaten(ref_count, ref_sum):
+    """Maximum-count hypotheses whose float residual sum is strictly below the largest one among them: the accept rule
+    (count, then the larger sum, src/RansacFilter.cpp:59) can neither pick them nor be tied by them."""
+    ref_count = np.asarray(ref_count); rs = np.asarray(ref_sum, dtype=np.float32)
+    top = ref_count == ref_count.max()
+    finite = rs[top & ~np.isnan(rs)]
+    if not finite.size:
+        return np.zeros(len(rs), bool)
+    return top & (rs < finite.max())
+
+
+def check_counts(got_count, ref_count, mode, tag=None, ref_sum=None):
+    """'all' mode: every count exact.  Default mode: every hypothesis below the pair's maximum count reads -1 -- the counting
+    kernel abandons a hypothesis as soon as it can no longer reach a count already verified for the pair -- and a hypothesis
+    that reaches the maximum carries it, unless (round 4, ref_sum given) it was abandoned because a certified bound put
+    its residual sum below that of a verified maximum-count hypothesis: then it reads -1 as well, which is allowed exactly
+    for hypotheses that are beaten on the sum."""
     got_count = np.asarray(got_count); ref_count = np.asarray(ref_count)
     if mode == "all":
         assert np.array_equal(got_count, ref_count), tag
         return
     top = ref_count == ref_count.max()
-    assert np.array_equal(got_count[top], ref_count[top]), tag
     assert (got_count[~top] == -1).all(), tag
+    carried = got_count == ref_count
+    if ref_sum is None:
+        assert carried[top].all(), tag
+    else:
+        assert (carried | ((got_count == -1) & _beaten(ref_count, ref_sum)))[top].all(), tag
+        assert carried[top & ~_beaten(ref_count, ref_sum)].all(), tag     # whoever can win or tie is counted in full
 
 
-def check_sums(got_sum, ref_count, ref_sum, mode, tag=None):
+def check_sums(got_sum, ref_count, ref_sum, mode, tag=None, got_count=None):
     """'all' mode: every sum bit-exact.  Default mode: sums exist only where the accept rule can consult them — for
     hypotheses whose count is the pair's maximum — and of those only the ones that can still be the largest: each such
     sum is bit-exact or -inf ("pruned: certainly smaller than the winner's"), never -inf for a hypothesis whose float
@@ -49,6 +67,10 @@ def check_sums(got_sum, ref_count, ref_sum, mode, tag=None):
     assert np.isnan(got_sum[~tied]).all(), tag
     exact = bits(got_sum) == bits(ref_sum)
     pruned = np.isneginf(got_sum) & ~exact
+    if got_count is not None:     # abandoned on the sum rule (count -1): no sum either, and only if beaten (check_counts)
+        gone = tied & (np.asarray(got_count) == -1)
+        assert np.isnan(got_sum[gone]).all(), tag
+        pruned = pruned | gone
     assert (exact | pruned)[tied].all(), tag
     finite_ref = ref_sum[tied & ~np.isnan(ref_sum)]
     if finite_ref.size:
@@ -174,8 +196,8 @@ def test_fundamental_bit_exact(ctx, oracle, sums_mode):
         ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], thr)
         bad = np.nonzero((bits(out["hypF"][b]) != bits(ref["hypF"])).any(axis=1))[0]
         assert bad.size == 0, f"item {b}: {bad.size} of {Hy} hypothesis F differ, first {bad[:5]}"
-        check_counts(out["hyp_count"][b], ref["hyp_count"], sums_mode, b)
-        check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], sums_mode, b)
+        check_counts(out["hyp_count"][b], ref["hyp_count"], sums_mode, b, ref["hyp_sum"])
+        check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], sums_mode, b, out["hyp_count"][b])
         assert out["best"][b, 0] == ref["winner"] and out["best"][b, 1] == ref["count"], b
         assert out["best"][b, 2] == int(bits(np.float32(ref["sum"])).reshape(-1)[0]), b
         assert np.array_equal(bits(out["F"][b]), bits(ref["F"])), b
@@ -206,8 +228,8 @@ def test_degenerate_geometry_still_bit_exact(ctx, oracle, sums_mode):
     for b in range(3):
         ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b], sets[b], thr)
         assert np.array_equal(bits(out["hypF"][b]), bits(ref["hypF"])), b
-        check_counts(out["hyp_count"][b], ref["hyp_count"], sums_mode, b)
-        check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], sums_mode, b)
+        check_counts(out["hyp_count"][b], ref["hyp_count"], sums_mode, b, ref["hyp_sum"])
+        check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], sums_mode, b, out["hyp_count"][b])
         assert out["best"][b, 0] == ref["winner"], b
         if ref["winner"] >= 0:
             assert np.array_equal(out["mask"][b], ref["mask"]), b
@@ -254,8 +276,8 @@ def _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr):
 
 
 def _compare(out, ref, b, n, mode):
-    check_counts(out["hyp_count"][b], ref["hyp_count"], mode, b)
-    check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], mode, b)
+    check_counts(out["hyp_count"][b], ref["hyp_count"], mode, b, ref["hyp_sum"])
+    check_sums(out["hyp_sum"][b], ref["hyp_count"], ref["hyp_sum"], mode, b, out["hyp_count"][b])
     assert out["best"][b, 0] == ref["winner"], b
     if ref["winner"] >= 0:
         assert out["best"][b, 1] == ref["count"], b
@@ -314,6 +336,35 @@ def test_many_tied_hypotheses(ctx, oracle, sums_mode):
     assert max(tied) >= 192, tied      # the top really is crowded
 
 
+def test_sum_rule_on_a_plateau_of_tied_hypotheses(ctx, oracle):
+    """One dominant motion plus a block that moves differently (the bench data's structure): every hypothesis drawn from
+    the dominant motion alone has the same inlier set, so hundreds tie at the maximum count and the accept rule picks
+    the largest residual sum among them.  The counting kernel abandons a tied hypothesis once a certified upper bound of its
+    sum lies below the sum of a candidate it counted exactly (ransac_cand_kernel's floor): winner, mask and F must be the
+    oracle's all the same, the abandoned ones must all be beaten on the sum (check_counts), and the rule must actually
+    have fired here."""
+    K, Hy, thr = 1500, 512, 10.0
+    B = 3
+    xy1 = np.zeros((B, K, 2), np.float32); xy2 = np.zeros((B, K, 2), np.float32)
+    for b in range(B):   # an exact two-view geometry (no noise, sub-pixel coordinates) for 85 %, uniform outliers for the rest
+        xy1[b], xy2[b], _ = synth.two_view_points(4100 + b, K, 1280, 720, inlier_frac=0.85, noise_px=0.0, integer=False)
+    pairs = np.tile(np.stack([np.arange(K), np.arange(K)], 1)[None], (B, 1, 1)).astype(np.int32)
+    m = np.array([K, K - 100, 1100], np.int32)
+    sets = np.stack([oracle.ransac_sets(900 + b, int(m[b]), Hy) for b in range(B)])
+    out = _find(ctx, oracle, xy1, xy2, pairs, m, sets, thr)
+    fired = 0
+    crowded = 0
+    for b in range(B):
+        n = int(m[b])
+        ref = oracle.find_fundamental(xy1[b], xy2[b], pairs[b, :n], sets[b], thr)
+        _compare(out, ref, b, n, "ties")
+        tied = ref["hyp_count"] == ref["hyp_count"].max()
+        crowded = max(crowded, int(tied.sum()))
+        fired += int((tied & (out["hyp_count"][b] == -1)).sum())
+    assert crowded >= 40, crowded     # the top really is a plateau
+    assert fired > 0                  # and some of it was abandoned on the sum
+
+
 def test_threshold_and_scale_outside_certified_range(ctx, oracle, sums_mode):
     """Thresholds / coordinates beyond the range the cheap evaluation's bounds are derived for (thr in [2^-20, 2^20],
     |coordinates| <= 2^20): every evaluation must take the exact sequence and still give the reference's counts."""
@@ -365,8 +416,8 @@ def test_tiny_denominators_take_the_exact_path(ctx, oracle, sums_mode):
                 counts[h], sums[h] = c, s_
                 if c > best or (c == best and s_ > best_sum):      # src/RansacFilter.cpp:59
                     best, best_sum, winner = c, s_, h
-        check_counts(out["hyp_count"][b], counts, sums_mode, b)
-        check_sums(out["hyp_sum"][b], counts, sums, sums_mode, b)
+        check_counts(out["hyp_count"][b], counts, sums_mode, b, sums)
+        check_sums(out["hyp_sum"][b], counts, sums, sums_mode, b, out["hyp_count"][b])
         assert out["best"][b, 0] == winner, (b, out["best"][b], winner, best)
         if winner >= 0:
             assert out["best"][b, 1] == best, b

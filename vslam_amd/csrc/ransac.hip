@@ -1233,12 +1233,13 @@ __device__ __forceinline__ void cnt_store_record(float *d, const float *f, const
     for (int k = 0; k < 9; k++) d[k] = f[k];
     d[9] = B.lo;
     d[10] = B.hi;
-    d[11] = 0.f;
+    d[11] = B.ok ? (float)(B.beta * (1.0 + 0x1p-20)) : -1.f;   // beta rounded up (the sum rule's error term); < 0: nothing is certified
 }
 
 struct CntRec {
     float f[9];   // the packed instructions take (f, f) operands: a splat of one register is an operand modifier (op_sel_hi)
     float lo, hi;
+    float beta;   // >= the band's beta; < 0 when the cheap values of this hypothesis are not certified
 };
 __device__ __forceinline__ void cnt_load_record(CntRec &R, const float *s_rec, int hh) {
     const float4 *r4 = reinterpret_cast<const float4 *>(s_rec + hh * kCntRec);
@@ -1248,6 +1249,7 @@ __device__ __forceinline__ void cnt_load_record(CntRec &R, const float *s_rec, i
     for (int k = 0; k < 9; k++) R.f[k] = f[k];
     R.lo = v2.y;
     R.hi = v2.z;
+    R.beta = v2.w;
 }
 
 // the cheap value g for two matches per lane; dd returned for the caller's denormal check
@@ -1346,7 +1348,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 template <bool PARTIAL>
 __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const float4 X1, const float4 Y1, const float4 X2, const float4 Y2,
                                               int ix, int hh, int lane, int m, int &cnt, cnt_queue_t *q, int &qn, v2f &acc,
-                                              int *s_unk, int &pot) {
+                                              int *s_unk, int &pot, bool &unk) {
     unsigned long long u0, u1, u2, u3;
     int c = 0;
     float ddmin = INFINITY;
@@ -1360,6 +1362,7 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const float4 X1, 
     if (__builtin_amdgcn_fcmpf(ddmin, kCntTinyDD, kFcmpULT) != 0ull) {   // unordered or <: some dd is zero / denormal (or NaN)
         // nothing of this sub-block is certified: all of it is queued, and the hypothesis' cheap sum means nothing
         if (lane == 0) s_unk[hh] = 1;
+        unk = true;   // wave-uniform
         c = 0;
         u0 = __builtin_amdgcn_sicmp(ix, m, 40);   // 40 = signed <
         u1 = __builtin_amdgcn_sicmp(ix + 1, m, 40);
@@ -1378,12 +1381,16 @@ __device__ __forceinline__ void cnt_sub_block(const CntRec &R, const float4 X1, 
 }
 
 // exact inlier count of one hypothesis over the ranked coordinate arrays (one wave, lanes over the matches)
-__device__ __forceinline__ int cnt_exact_ranked(const float *F9, const float *r, int kp_pad, int m, float threshold, int lane) {
+// (sum_out: the sum of every e as well, lanes' partial sums in double -- not the reference's sequential order: a value within
+// m 2^-53 of it, for a bound)
+__device__ __forceinline__ int cnt_exact_ranked(const float *F9, const float *r, int kp_pad, int m, float threshold, int lane,
+                                                double *sum_out = nullptr) {
     ResidualF R;
 #pragma unroll
     for (int j = 0; j < 9; j++) R.f[j] = F9[j];
     residual_prepare(R);
     int count = 0;
+    double esum = 0;
     for (int i0 = 0; i0 < m; i0 += 256) {   // the arrays are padded to a multiple of 256
         float4 c[4];
 #pragma unroll
@@ -1395,7 +1402,13 @@ __device__ __forceinline__ int cnt_exact_ranked(const float *F9, const float *r,
         for (int u = 0; u < 4; u++) {
             const float e = residual_e(R, c[u], (double)c[u].z, (double)c[u].w);
             count += __popcll(__ballot(i0 + u * 64 + lane < m && e <= threshold));
+            if (sum_out && i0 + u * 64 + lane < m) esum += (double)e;
         }
+    }
+    if (sum_out) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
+        *sum_out = esum;
     }
     return count;
 }
@@ -1409,11 +1422,13 @@ __device__ __forceinline__ int cnt_exact_ranked(const float *F9, const float *r,
 __global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int kp_pad, int hyp, float threshold,
-    const float *__restrict__ hypF, int32_t *__restrict__ cbound, float *__restrict__ rk, float *__restrict__ cmax) {
+    const float *__restrict__ hypF, int32_t *__restrict__ cbound, float *__restrict__ rk, float *__restrict__ cmax,
+    unsigned long long *__restrict__ sfloor) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = min(m_arr[b], kp_stride);
     if (m < min_m) return;
+    __shared__ double s_psum[kPilotHyps];   // the pilots' residual sums (lanes' partial sums: for the sum floor, a bound)
     __shared__ unsigned long long s_bits[kPilotHyps][VSLAM_MAX_KP / 64];
     __shared__ int s_hist[kPilotHyps][kPilotHyps + 1], s_off[kPilotHyps][kPilotHyps + 1], s_pcount[kPilotHyps];
     const float2 *P1 = reinterpret_cast<const float2 *>(xy1) + (size_t)b * kp_stride;
@@ -1430,6 +1445,7 @@ __global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
         for (int j = 0; j < 9; j++) R.f[j] = src[j];
         residual_prepare(R);
         int count = 0;
+        double esum = 0;
         float c1 = 0.f, c2 = 0.f;
         for (int g0 = 0; g0 < G; g0 += 4) {   // four matches per lane and round: their gathers are in flight together
             int2 pr[4];
@@ -1446,12 +1462,18 @@ __global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
                 const float e = residual_e(R, make_float4(a[u].x, a[u].y, c[u].x, c[u].y), (double)c[u].x, (double)c[u].y);
                 const unsigned long long in = __ballot((g0 + u) * 64 + lane < m && e <= threshold);
                 count += __popcll(in);
+                if ((g0 + u) * 64 + lane < m) esum += (double)e;
                 if (lane == 0 && g0 + u < G) s_bits[wave][g0 + u] = in;
                 c1 = fmaxf(c1, fmaxf(fabsf(a[u].x), fabsf(a[u].y)));
                 c2 = fmaxf(c2, fmaxf(fabsf(c[u].x), fabsf(c[u].y)));
             }
         }
-        if (lane == 0) s_pcount[wave] = count;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
+        if (lane == 0) {
+            s_pcount[wave] = count;
+            s_psum[wave] = esum;
+        }
         if (wave == 0) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1488,6 +1510,17 @@ __global__ __launch_bounds__(kRankThreads) void ransac_rank_kernel(
         int best = 0;   // the first word written to cbound[pair] in a call: a plain store, nothing to clear beforehand
         for (int w = 0; w < npil; w++) best = max(best, s_pcount[w]);
         cbound[b] = best;
+        if (sfloor) {   // the first sum floor of the pair (see ransac_cand_kernel): the best-counting pilots' largest sum
+            double fl = -INFINITY;
+            bool any_nan = false;
+            for (int w = 0; w < npil; w++)
+                if (s_pcount[w] == best) {
+                    any_nan = any_nan || !(s_psum[w] == s_psum[w]);
+                    if (s_psum[w] > fl) fl = s_psum[w];
+                }
+            const bool valid = best > 0 && !any_nan && fl > 0 && fl < 0x1p120;
+            sfloor[b] = valid ? ((unsigned long long)(uint32_t)best << 32) | (unsigned long long)__float_as_uint((float)(fl * (1.0 - 0x1p-20))) : 0ull;
+        }
         int run = 0;
         for (int v = kPilotHyps; v >= 0; v--)
             for (int w = 0; w < kPilotHyps; w++) {
@@ -1590,7 +1623,8 @@ __global__ __launch_bounds__(256) void ransac_screen_kernel(
 // full, exactly: cbound[pair] = max(cbound[pair], those counts).  One workgroup of 8 waves per pair.
 __global__ __launch_bounds__(64 * kCandMax) void ransac_cand_kernel(
     const float *__restrict__ rk, int kp_pad, const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp,
-    float threshold, const float *__restrict__ hypF, const int32_t *__restrict__ pot0, int32_t *__restrict__ cbound) {
+    float threshold, const float *__restrict__ hypF, const int32_t *__restrict__ pot0, int by_sum,
+    int32_t *__restrict__ cbound, unsigned long long *__restrict__ sfloor) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = min(m_arr[b], kp_stride);
@@ -1610,15 +1644,64 @@ __global__ __launch_bounds__(64 * kCandMax) void ransac_cand_kernel(
     const int per = (hyp + kCandMax - 1) / kCandMax;
     const int lo = min(hyp, wave * per), hi = min(hyp, lo + per);
     int n0 = 0, n1 = 0;
-    for (int i0 = lo; i0 < hi && (n0 < kCandMax || n1 < kCandMax); i0 += 64) {
+    // (by_sum: the wave also notes the first 32 best-scoring hypotheses of its share -- a random sample: a hypothesis' index
+    // says nothing about it -- and afterwards moves the one with the largest residual sum over the screen's matches to the
+    // front.  Those matches are mostly the pair's outliers, whose residuals dominate a residual sum, so that candidate's sum
+    // is likely to be near the largest among the hypotheses that tie the maximum count: what makes the sum floor below bite.)
+    __shared__ int s_samp[kCandMax][32];
+    int nsamp = 0;
+    for (int i0 = lo; i0 < hi && ((by_sum && nsamp < 32) || n0 < kCandMax || n1 < kCandMax); i0 += 64) {
         const int i = i0 + lane;
         const int v = i < hi ? P[i] : -2;
         unsigned long long b0 = __ballot(v == mx), b1 = __ballot(v == mx - 1);
+        if (by_sum) {
+            const int rs = nsamp + __popcll(b0 & ((1ull << lane) - 1ull));
+            if (v == mx && rs < 32) s_samp[wave][rs] = i;
+            nsamp = min(32, nsamp + (int)__popcll(b0));
+        }
         const int r0 = n0 + __popcll(b0 & ((1ull << lane) - 1ull)), r1 = n1 + __popcll(b1 & ((1ull << lane) - 1ull));
         if (v == mx && r0 < kCandMax) s_l0[wave][r0] = i;
         if (v == mx - 1 && r1 < kCandMax) s_l1[wave][r1] = i;
         n0 = min(kCandMax, n0 + __popcll(b0));
         n1 = min(kCandMax, n1 + __popcll(b1));
+    }
+    if (by_sum && nsamp > 1) {   // the sample's best by sum over the screen's matches to the front of the wave's list
+        // (a ranking aid only: nothing is certified with these values; NaN / inf simply rank oddly)
+        const int n128 = min(m, kScreenMatches);
+        const float *r = rk + (size_t)b * 4 * kp_pad;
+        const float2 x1 = *reinterpret_cast<const float2 *>(r + 2 * lane), y1 = *reinterpret_cast<const float2 *>(r + kp_pad + 2 * lane);
+        const float2 x2 = *reinterpret_cast<const float2 *>(r + 2 * kp_pad + 2 * lane), y2 = *reinterpret_cast<const float2 *>(r + 3 * kp_pad + 2 * lane);
+        v2f X1, Y1, X2, Y2;
+        X1.x = x1.x; X1.y = x1.y; Y1.x = y1.x; Y1.y = y1.y;
+        X2.x = x2.x; X2.y = x2.y; Y2.x = y2.x; Y2.y = y2.y;
+        float fl[9];   // lane l < nsamp: the F of sample l
+        {
+            const int hs = s_samp[wave][lane < nsamp ? lane : 0];
+            const float *src = hypF + ((size_t)b * hyp + hs) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) fl[k] = src[k];
+        }
+        float best_s = -INFINITY;
+        int best_i = -1;
+        for (int j = 0; j < nsamp; j++) {
+            CntRec R;
+#pragma unroll
+            for (int k = 0; k < 9; k++) R.f[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fl[k]), j));
+            v2f dd;
+            const v2f g = cnt_cheap(R, X1, Y1, X2, Y2, dd);
+            const float part = wave_sum_to_lane63((2 * lane < n128 ? g.x : 0.f) + (2 * lane + 1 < n128 ? g.y : 0.f));
+            const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), 63));
+            if (tot > best_s) {   // false for NaN
+                best_s = tot;
+                best_i = s_samp[wave][j];
+            }
+        }
+        if (lane == 0 && best_i >= 0 && n0 > 0) {
+            const int old = s_l0[wave][0];
+            for (int k = 1; k < n0; k++)
+                if (s_l0[wave][k] == best_i) s_l0[wave][k] = old;
+            s_l0[wave][0] = best_i;
+        }
     }
     if (lane == 0) {
         s_n0[wave] = n0;
@@ -1627,17 +1710,50 @@ __global__ __launch_bounds__(64 * kCandMax) void ransac_cand_kernel(
     __syncthreads();
     if (tid == 0) {
         int n = 0;
+        for (int w = 0; w < kCandMax && n < kCandMax; w++)   // every wave's first entry first (with ssum: its best by sum)
+            if (s_n0[w] > 0) s_cand[n++] = s_l0[w][0];
         for (int w = 0; w < kCandMax && n < kCandMax; w++)
-            for (int k = 0; k < s_n0[w] && n < kCandMax; k++) s_cand[n++] = s_l0[w][k];
+            for (int k = 1; k < s_n0[w] && n < kCandMax; k++) s_cand[n++] = s_l0[w][k];
         for (int w = 0; w < kCandMax && n < kCandMax; w++)
             for (int k = 0; k < s_n1[w] && n < kCandMax; k++) s_cand[n++] = s_l1[w][k];
         s_nc = n;
     }
     __syncthreads();
+    // The sum floor (the counting kernel's second way of dropping a hypothesis): among hypotheses of equal count the accept
+    // rule keeps the one with the LARGER residual sum (src/RansacFilter.cpp:59), so a candidate with exact count c and
+    // residual sum s rules out every hypothesis that can at best tie c with a sum certainly below s.
+    // sfloor[pair] = c << 32 | bits of a lower bound of s (a positive float: its bits order as the number does), so that
+    // a 64-bit maximum is "the higher count, then the larger sum": ransac_rank_kernel stores the best pilot's, this kernel
+    // keeps the larger of that and its own candidates'.  0 = no floor.
+    __shared__ int s_ccount[kCandMax];
+    __shared__ double s_csum[kCandMax];
     if (wave < s_nc) {
         const int h = s_cand[wave];
-        const int count = cnt_exact_ranked(hypF + ((size_t)b * hyp + h) * 9, rk + (size_t)b * 4 * kp_pad, kp_pad, m, threshold, lane);
-        if (lane == 0) atomicMax(&cbound[b], count);
+        double esum = 0;
+        const int count = cnt_exact_ranked(hypF + ((size_t)b * hyp + h) * 9, rk + (size_t)b * 4 * kp_pad, kp_pad, m, threshold, lane, &esum);
+        if (lane == 0) {
+            atomicMax(&cbound[b], count);
+            s_ccount[wave] = count;
+            s_csum[wave] = esum;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int cb = -1;
+        for (int k = 0; k < s_nc; k++) cb = max(cb, s_ccount[k]);
+        double fl = -INFINITY;
+        bool any_nan = false;
+        for (int k = 0; k < s_nc; k++)
+            if (s_ccount[k] == cb) {
+                any_nan = any_nan || !(s_csum[k] == s_csum[k]);
+                if (s_csum[k] > fl) fl = s_csum[k];
+            }
+        // a NaN sum among the best candidates takes part in the accept rule in ways a floor cannot express: no floor from them
+        const bool valid = cb > 0 && !any_nan && fl > 0 && fl < 0x1p120;
+        const float flf = (float)(fl * (1.0 - 0x1p-20));   // float rounding stays inside the 2^-20
+        const unsigned long long mine = valid ? ((unsigned long long)(uint32_t)cb << 32) | (unsigned long long)__float_as_uint(flf) : 0ull;
+        const unsigned long long pilots = sfloor[b];   // ransac_rank_kernel's: the higher count, then the larger sum
+        sfloor[b] = mine > pilots ? mine : pilots;
     }
 }
 
@@ -1647,7 +1763,8 @@ template <bool LDS>
 __global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(6, 6))) void ransac_count_kernel(
     const float *__restrict__ rk, int kp_pad, const int32_t *__restrict__ m_arr, int min_m, int kp_stride, int hyp, float threshold,
     const float *__restrict__ hypF, const int32_t *__restrict__ pot0, const float *__restrict__ cmax,
-    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx, int32_t *__restrict__ cbound) {
+    int32_t *__restrict__ hyp_count, float *__restrict__ hyp_sum, float *__restrict__ approx, int32_t *__restrict__ cbound,
+    const unsigned long long *__restrict__ sfloor) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler may know it
     const int hbase = blockIdx.x * kCntHyps;
@@ -1727,6 +1844,10 @@ __global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(
         cnt_queue_t *q = (cnt_queue_t *)(s_dyn + (LDS ? 4 * mpad : 0) + wave * kCntQueue);
         int qn = 0;
         int bound = bound0;
+        // the sum floor of ransac_cand_kernel: (the count it belongs to, a lower bound of that hypothesis' residual sum); -1: none
+        const unsigned long long fkey = sfloor ? sfloor[b] : 0ull;
+        const int floor_count = fkey != 0ull ? (int)(fkey >> 32) : -1;
+        const float floor_sum = __uint_as_float((uint32_t)fkey);
         const int nsub = mpad >> 8;
         const bool part = (m & 255) != 0;
         // the survivors are handed out one at a time: what a hypothesis costs (256 evaluations or all of them) is not known beforehand
@@ -1746,7 +1867,7 @@ __global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(
             CntRec R;
             cnt_load_record(R, s_rec, hh);
             int cnt = 0, pot = 0, seen = 0;
-            bool dropped = false;
+            bool dropped = false, unk = false;
             v2f acc;
             acc.x = 0.f;
             acc.y = 0.f;
@@ -1757,10 +1878,10 @@ __global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(
                 const float4 X1 = *reinterpret_cast<const float4 *>(cx1 + ix), Y1 = *reinterpret_cast<const float4 *>(cy1 + ix);
                 const float4 X2 = *reinterpret_cast<const float4 *>(cx2 + ix), Y2 = *reinterpret_cast<const float4 *>(cy2 + ix);
                 if (s == nsub - 1 && part) {
-                    cnt_sub_block<true>(R, X1, Y1, X2, Y2, ix, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
+                    cnt_sub_block<true>(R, X1, Y1, X2, Y2, ix, hh, lane, m, cnt, q, qn, acc, s_unk, pot, unk);
                     seen += m & 255;
                 } else {
-                    cnt_sub_block<false>(R, X1, Y1, X2, Y2, ix, hh, lane, m, cnt, q, qn, acc, s_unk, pot);
+                    cnt_sub_block<false>(R, X1, Y1, X2, Y2, ix, hh, lane, m, cnt, q, qn, acc, s_unk, pot, unk);
                     seen += 256;
                 }
                 while (qn >= 64) {   // a sub-block adds at most 256 words to the 63 left over: kCntQueue holds them
@@ -1774,6 +1895,24 @@ __global__ __launch_bounds__(64 * kCntWaves) __attribute__((amdgpu_waves_per_eu(
                 if (pot + (m - seen) < bound) {
                     dropped = true;
                     break;
+                }
+                // The sum rule.  The hypothesis can at best TIE the count the floor belongs to (every match not looked at
+                // yet would have to be an inlier, i.e. add at most `threshold` each to its residual sum), and among equal
+                // counts the accept rule keeps the larger sum: if an upper bound of its sum -- the cheap values so far,
+                // their certified error (the bound ransac_ties uses, over `seen` evaluations), threshold x the rest --
+                // lies below the floor by more than float rounding can close, it is neither the winner nor a tie.
+                // On data with one dominant motion a third to a half of the hypotheses share the maximum count and used to
+                // be counted in full for that; their sums are far from the best one's (outlier residuals dominate them).
+                if (seen < m && bound == floor_count && pot + (m - seen) == bound && !unk && R.beta >= 0.f) {
+                    // in float, every rounding covered by the 1e-4 factors (the terms are all positive)
+                    const float S = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(acc.x + acc.y)), 63));
+                    const float ns = (float)seen;
+                    const float err = (2.02f * R.beta * sqrtf(ns * S) + ns * R.beta * R.beta + 0x1p-18f * S) * 1.0001f;
+                    const float upper = ((S + err) + threshold * (float)(m - seen)) * 1.0001f;
+                    if (upper < floor_sum * 0.9999f) {   // false for NaN
+                        dropped = true;
+                        break;
+                    }
                 }
             }
             if (dropped) {
@@ -2276,13 +2415,17 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         float *rk = nullptr, *cmax = nullptr;
         const int kp_pad = cnt_pad(kp_stride);
         if ((rc = vs_arena_get(ctx, "ransac.cbound", sizeof(int32_t) * (size_t)batch, (void **)&cbound))) return rc;
+        unsigned long long *sfloor = nullptr;
+        if ((rc = vs_arena_get(ctx, "ransac.sfloor", sizeof(unsigned long long) * (size_t)batch, (void **)&sfloor))) return rc;
+        static const bool no_sum_rule = getenv("VSLAM_RANSAC_NO_SUM_RULE") != nullptr;   // A/B timing: bail out on counts only
+        const unsigned long long *use_floor = no_sum_rule ? nullptr : sfloor;
         if ((rc = vs_arena_get(ctx, "ransac.pot0", sizeof(int32_t) * (size_t)batch * hyp, (void **)&pot0))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.rk", sizeof(float) * 4 * (size_t)kp_pad * batch, (void **)&rk))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.cmax", sizeof(float) * 2 * (size_t)batch, (void **)&cmax))) return rc;
         {
             VsProfScope ps(ctx, "ransac_rank_kernel");
             ransac_rank_kernel<<<batch, kRankThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, min_m, kp_stride, kp_pad, hyp, threshold, hypF,
-                                                                        cbound, rk, cmax);
+                                                                        cbound, rk, cmax, sfloor);
         }
         {
             VsProfScope ps(ctx, "ransac_screen_kernel");
@@ -2291,7 +2434,8 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         }
         {
             VsProfScope ps(ctx, "ransac_cand_kernel");
-            ransac_cand_kernel<<<batch, 64 * kCandMax, 0, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0, cbound);
+            ransac_cand_kernel<<<batch, 64 * kCandMax, 0, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0,
+                                                                         no_sum_rule ? 0 : 1, cbound, sfloor);
         }
         if (int arc = vs_aux_job_point(ctx, 4)) return arc;
         {
@@ -2307,10 +2451,10 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
             dim3 grid(vs_div_up(hyp, kCntHyps), batch);
             if (lds)
                 ransac_count_kernel<true><<<grid, 64 * kCntWaves, dyn, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0,
-                                                                                      cmax, hyp_count, hyp_sum, approx, cbound);
+                                                                                      cmax, hyp_count, hyp_sum, approx, cbound, use_floor);
             else
                 ransac_count_kernel<false><<<grid, 64 * kCntWaves, dyn, ctx->stream>>>(rk, kp_pad, m, min_m, kp_stride, hyp, threshold, hypF, pot0,
-                                                                                       cmax, hyp_count, hyp_sum, approx, cbound);
+                                                                                       cmax, hyp_count, hyp_sum, approx, cbound, use_floor);
         }
         // the closing stages: one launch when the four waves' sum buffers fit LDS (kp_stride <= 4096), else three
         const size_t fin_lds = sizeof(float) * (size_t)kTieGrid * kp_stride;
