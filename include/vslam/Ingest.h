@@ -88,6 +88,16 @@ struct SequenceStats {
 // batch_frames.  Throws std::runtime_error on I/O or device errors.
 SequenceStats run_sequence(const std::string &video_path, const std::string &record_path, const SequenceOptions &options);
 
+// The same file over several devices of this process: entry r of `devices` (a device may repeat: several contexts on one
+// device) gets its own context, host thread and reader, and the pairs [lo, hi) of vslam_shard_range's split, i.e. frames
+// [lo, hi] -- the frame between two neighbouring slices is read and extracted by both, nothing else is shared and no device
+// talks to another.  Pair i keeps its global number and its seed (seed ^ i), so the record file is byte for byte the one
+// run_sequence writes.  Records wait in host memory until every slice is done (about 60 + 8 * inliers bytes per pair).
+// `video_path` must be a regular file (slices are read at offsets).  stats.seconds is the wall time of the whole call.
+// The slot contexts are kept for the next call (as the process-wide one of run_sequence is); calls are serialised.
+SequenceStats run_sequence_devices(const std::string &video_path, const std::string &record_path, const SequenceOptions &options,
+                                   const std::vector<int> &devices);
+
 }  // namespace vslam
 
 // C entry point for hosts without C++ (ctypes): returns 0 on success, -1 with a message in err on failure.
@@ -95,3 +105,8 @@ extern "C" int vslam_host_run_sequence(const char *video_path, const char *recor
                                        int batch_frames, int max_corners, int hypotheses, float threshold,
                                        uint32_t seed, uint64_t max_frames, uint64_t *frames_out, uint64_t *pairs_out,
                                        double *seconds_out, char *err, int err_cap);
+extern "C" int vslam_host_run_sequence_devices(const char *video_path, const char *record_path, int width, int height,
+                                               int batch_frames, int max_corners, int hypotheses, float threshold,
+                                               uint32_t seed, uint64_t max_frames, const int *devices, int n_devices,
+                                               uint64_t *frames_out, uint64_t *pairs_out, double *seconds_out, char *err,
+                                               int err_cap);

@@ -44,6 +44,10 @@ typedef struct vslam_ctx vslam_ctx;
 /* ------------------------------------------------------------------ context */
 int vslam_ctx_create(int device, vslam_ctx **out);
 int vslam_ctx_destroy(vslam_ctx *ctx);
+/* HIP's current device is per host thread: vslam_ctx_create leaves the context's device current on the creating thread, and
+ * every call on a context (allocation included) expects it to be.  A thread that did not create the context -- or that has
+ * since worked on another device -- calls this first.                                                                      */
+int vslam_ctx_make_current(vslam_ctx *ctx);
 /* Borrow a caller-owned hipStream_t (e.g. torch's current stream).  Taken literally: NULL is
  * HIP's default stream.  A fresh context runs on a private non-blocking stream.               */
 int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream);

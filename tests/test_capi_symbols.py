@@ -54,3 +54,14 @@ def test_product_does_not_reference_oracle():
                 if re.search(r'#include\s+"[^"]*(vso|oracle)', s) or "liboracle" in s or "oracle_lib" in s:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_library_exports_its_c_entry_points():
+    """libvslam_host.so (the C++ drop-in surfaces) exports the extern "C" entry points include/vslam/Ingest.h declares."""
+    from vslam_amd import build
+    host = ctypes.CDLL(build.build_host())
+    text = open(os.path.join(ROOT, "include", "vslam", "Ingest.h")).read()
+    names = sorted(set(re.findall(r'extern "C" int (vslam_host_[a-z_]+)\(', text)))
+    assert names == ["vslam_host_run_sequence", "vslam_host_run_sequence_devices"]
+    for n in names:
+        assert hasattr(host, n), n

@@ -79,6 +79,55 @@ def run_sequence(video_path, record_path, batch, seed, max_frames=0):
     return frames.value, pairs.value
 
 
+def run_sequence_devices(video_path, record_path, batch, seed, devices, max_frames=0, expect_error=None):
+    lib = ctypes.CDLL(build.build_host())
+    frames, pairs, secs = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+    err = ctypes.create_string_buffer(512)
+    dev = (ctypes.c_int * max(len(devices), 1))(*devices)
+    rc = lib.vslam_host_run_sequence_devices(str(video_path).encode(), str(record_path).encode(), W, H, batch, MAXC, HYP,
+                                             ctypes.c_float(THR), ctypes.c_uint32(seed), ctypes.c_uint64(max_frames),
+                                             dev, len(devices), ctypes.byref(frames), ctypes.byref(pairs),
+                                             ctypes.byref(secs), err, 512)
+    if expect_error is not None:
+        assert rc == -1 and expect_error in err.value.decode(), err.value.decode()
+        return None
+    assert rc == 0, err.value.decode()
+    return frames.value, pairs.value
+
+
+def test_capture_loop_over_device_slots(tmp_path):
+    """run_sequence_devices: the file's pairs split over several contexts (here all on device 0, the one a test box has),
+    each with its own reader and batches; the record file is byte for byte run_sequence's, whatever the number of slots --
+    more slots than pairs, slices shorter than a batch and a blank frame on a slice border included."""
+    clip = video(9, 94).copy()
+    clip[4] = 17                                            # pairs (3,4), (4,5): nothing to match, winner -1
+    vid = tmp_path / "clip.bgr"
+    vid.write_bytes(clip.tobytes() + b"\x02" * 31)
+    seed = 0x51CE
+    assert run_sequence(vid, tmp_path / "one.bin", 4, seed) == (9, 8)
+    want = (tmp_path / "one.bin").read_bytes()
+    for slots, batch in ((1, 4), (2, 3), (3, 2), (4, 64), (8, 3), (11, 2)):
+        out = tmp_path / f"multi_{slots}.bin"
+        assert run_sequence_devices(vid, out, batch, seed, [0] * slots) == (9, 8), slots
+        assert out.read_bytes() == want, slots
+    assert run_sequence_devices(vid, tmp_path / "short.bin", 3, seed, [0, 0, 0], max_frames=5) == (5, 4)
+    short = (tmp_path / "short.bin").read_bytes()
+    assert short == want[:len(short)] and len(short) > 40
+    (tmp_path / "single.bgr").write_bytes(clip[0].tobytes())
+    assert run_sequence_devices(tmp_path / "single.bgr", tmp_path / "none.bin", 3, seed, [0, 0]) == (1, 0)
+    assert len((tmp_path / "none.bin").read_bytes()) == 40
+    # what it refuses: no devices, a device that is not there, a stream
+    run_sequence_devices(vid, tmp_path / "x.bin", 3, seed, [], expect_error="no devices")
+    run_sequence_devices(vid, tmp_path / "x.bin", 3, seed, [0, 4096], expect_error="slot 1")
+    fifo = tmp_path / "clip.fifo"
+    os.mkfifo(fifo)
+    fd = os.open(fifo, os.O_RDWR)                            # keeps the open() inside the call from blocking
+    try:
+        run_sequence_devices(fifo, tmp_path / "x.bin", 3, seed, [0, 0], expect_error="regular file")
+    finally:
+        os.close(fd)
+
+
 def test_capture_loop_records(oracle, tmp_path, monkeypatch):
     n_frames, seed = 7, 0xABCD
     clip = video(n_frames, 91)

@@ -3,7 +3,10 @@
 front-end on consecutive frames -> record file.  Unlike bench.py's `value` this includes the file reads and the
 host-to-device copies.
 
-usage: ingest_bench.py [--frames 257] [--batch 64] [--width 1280 --height 720 --keypoints 2000 --hyp 4096]
+--slots N runs vslam::run_sequence_devices with N contexts on device 0 (one reader + one copy stream + one compute
+stream each), the one-GPU rehearsal of the several-device capture loop.
+
+usage: ingest_bench.py [--frames 257] [--batch 64] [--slots 0] [--width 1280 --height 720 --keypoints 2000 --hyp 4096]
 """
 import argparse
 import ctypes
@@ -25,6 +28,7 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--keypoints", type=int, default=2000)
     ap.add_argument("--hyp", type=int, default=4096)
+    ap.add_argument("--slots", type=int, default=0, help="0: run_sequence; N > 0: run_sequence_devices, N contexts on device 0")
     args = ap.parse_args()
     import numpy as np
     from vslam_amd import build, synth
@@ -44,15 +48,22 @@ def main():
     out = {}
     for label in ("warm-up", "timed"):
         t0 = time.perf_counter()
-        rc = lib.vslam_host_run_sequence(vid.encode(), rec.encode(), args.width, args.height, args.batch, args.keypoints,
-                                         args.hyp, ctypes.c_float(10.0), ctypes.c_uint32(1), ctypes.c_uint64(0),
-                                         ctypes.byref(frames), ctypes.byref(pairs), ctypes.byref(secs), err, 512)
+        if args.slots > 0:
+            dev = (ctypes.c_int * args.slots)(*([0] * args.slots))
+            rc = lib.vslam_host_run_sequence_devices(vid.encode(), rec.encode(), args.width, args.height, args.batch,
+                                                     args.keypoints, args.hyp, ctypes.c_float(10.0), ctypes.c_uint32(1),
+                                                     ctypes.c_uint64(0), dev, args.slots, ctypes.byref(frames),
+                                                     ctypes.byref(pairs), ctypes.byref(secs), err, 512)
+        else:
+            rc = lib.vslam_host_run_sequence(vid.encode(), rec.encode(), args.width, args.height, args.batch, args.keypoints,
+                                             args.hyp, ctypes.c_float(10.0), ctypes.c_uint32(1), ctypes.c_uint64(0),
+                                             ctypes.byref(frames), ctypes.byref(pairs), ctypes.byref(secs), err, 512)
         if rc != 0:
             sys.exit(err.value.decode())
         out = {"frames": frames.value, "pairs": pairs.value, "loop_seconds": secs.value,
                "wall_seconds": time.perf_counter() - t0, "pairs_per_s": pairs.value / secs.value,
                "input_GB_per_s": frames.value * args.width * args.height * 3 / secs.value / 1e9,
-               "batch_frames": args.batch, "record_bytes": os.path.getsize(rec)}
+               "batch_frames": args.batch, "slots": args.slots, "record_bytes": os.path.getsize(rec)}
     os.remove(vid)
     os.remove(rec)
     os.rmdir(tmp)

@@ -17,7 +17,7 @@ ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE
 
 # every symbol include/vslam_amd.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
-    "vslam_ctx_create", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_set_option", "vslam_ctx_synchronize", "vslam_ctx_wait",
+    "vslam_ctx_create", "vslam_ctx_make_current", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_set_option", "vslam_ctx_synchronize", "vslam_ctx_wait",
     "vslam_last_error", "vslam_ctx_workspace_bytes", "vslam_version", "vslam_brief_pattern_31", "vslam_dev_alloc", "vslam_dev_free", "vslam_copy_h2d",
     "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",

@@ -194,6 +194,12 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
     return VSLAM_OK;
 }
 
+int vslam_ctx_make_current(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    return VSLAM_OK;
+}
+
 int vslam_ctx_destroy(vslam_ctx *ctx) {
     if (!ctx) return VSLAM_ERR_INVALID;
     (void)hipSetDevice(ctx->device);

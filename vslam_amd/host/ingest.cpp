@@ -42,18 +42,26 @@ bool get(std::FILE *f, void *p, size_t n, bool eof_ok) {
 }
 const char kMagic[8] = {'V', 'S', 'L', 'A', 'M', 'R', 'E', 'C'};
 
+// a failed call on `ctx` -> std::runtime_error carrying that context's own message (detail::check reads the process-wide one)
+void check(vslam_ctx *ctx, int rc, const char *what) {
+    if (rc != VSLAM_OK)
+        throw std::runtime_error(std::string("vslam_amd: ") + what + " failed (rc=" + std::to_string(rc) + "): " + vslam_last_error(ctx));
+}
+
 struct Pinned {   // page-locked host buffer
+    vslam_ctx *ctx;
     uint8_t *p = nullptr;
-    explicit Pinned(size_t bytes) { detail::check(vslam_host_alloc(detail::context(), bytes, reinterpret_cast<void **>(&p)), "host_alloc"); }
-    ~Pinned() { (void)vslam_host_free(detail::context(), p); }
+    Pinned(vslam_ctx *c, size_t bytes) : ctx(c) { check(ctx, vslam_host_alloc(ctx, bytes, reinterpret_cast<void **>(&p)), "host_alloc"); }
+    ~Pinned() { (void)vslam_host_free(ctx, p); }
     Pinned(const Pinned &) = delete;
     Pinned &operator=(const Pinned &) = delete;
 };
 template <typename T>
 struct Dev {
+    vslam_ctx *ctx;
     T *p = nullptr;
-    explicit Dev(size_t count) { detail::check(vslam_dev_alloc(detail::context(), sizeof(T) * (count ? count : 1), reinterpret_cast<void **>(&p)), "dev_alloc"); }
-    ~Dev() { (void)vslam_dev_free(detail::context(), p); }
+    Dev(vslam_ctx *c, size_t count) : ctx(c) { check(ctx, vslam_dev_alloc(ctx, sizeof(T) * (count ? count : 1), reinterpret_cast<void **>(&p)), "dev_alloc"); }
+    ~Dev() { (void)vslam_dev_free(ctx, p); }
     Dev(const Dev &) = delete;
     Dev &operator=(const Dev &) = delete;
 };
@@ -140,50 +148,68 @@ bool RecordReader::next(PairRecord &r) {
 }
 
 // ------------------------------------------------------------------------------------------ the capture loop
-SequenceStats run_sequence(const std::string &video_path, const std::string &record_path, const SequenceOptions &o) {
-    if (o.width <= 0 || o.height <= 0 || o.batch_frames < 2 || o.max_corners <= 0 || o.hypotheses <= 0)
-        throw std::invalid_argument("run_sequence: bad options");
-    const int in = ::open(video_path.c_str(), O_RDONLY);
-    if (in < 0) throw std::runtime_error("run_sequence: cannot open " + video_path);
-    struct Closer {
-        int fd;
-        ~Closer() { ::close(fd); }
-    } closer{in};
-    struct stat st;
-    if (::fstat(in, &st) != 0) throw std::runtime_error("run_sequence: cannot stat " + video_path);
+namespace {
 
-    vslam_ctx *ctx = detail::context();
-    const int B = o.batch_frames, K = o.max_corners;
-    const size_t frame_bytes = (size_t)o.width * o.height * 3;
-    // A regular file is read at offsets by several threads; a FIFO, pipe or /dev/stdin reports st_size 0 and cannot be
-    // read at offsets: it is streamed with read() by the one reader thread until it ends.
-    const bool regular = S_ISREG(st.st_mode);
-    uint64_t file_frames = regular ? (uint64_t)st.st_size / frame_bytes : UINT64_MAX;   // a trailing partial frame is dropped
-    if (o.max_frames && file_frames > o.max_frames) file_frames = o.max_frames;
-    int readers = o.reader_threads;
-    if (const char *e = std::getenv("VSLAM_READER_THREADS")) readers = std::atoi(e);   // tuning
-    readers = readers < 1 ? 1 : (readers > 16 ? 16 : readers);
-    Pinned hbuf0(frame_bytes * B), hbuf1(frame_bytes * B);
-    uint8_t *hbuf[2] = {hbuf0.p, hbuf1.p};
-    Dev<uint8_t> dbuf0(frame_bytes * B), dbuf1(frame_bytes * B);
-    uint8_t *dbuf[2] = {dbuf0.p, dbuf1.p};
-    Dev<float> d_xy(2 * (size_t)B * K), d_F(9 * (size_t)B);
-    Dev<uint8_t> d_desc(32 * (size_t)B * K);
-    Dev<int32_t> d_nodes((size_t)B * K), d_n(B), d_matches(2 * (size_t)B * K), d_best(4 * (size_t)B);
-    Dev<uint32_t> d_seeds(B);
-    Dev<int8_t> d_pat(1024);
-    detail::check(vslam_copy_h2d(ctx, d_pat.p, detail::brief_pattern().data(), 1024), "pattern upload");
-    vslam_extract_params params;
-    detail::fill_extract_params(params, K, d_pat.p);
+struct Input {   // the opened video
+    int fd = -1;
+    bool regular = false;          // a regular file is read at offsets by several threads; anything else is streamed
+    uint64_t frames = UINT64_MAX;  // whole frames to process (UINT64_MAX: a stream, until it ends)
+    Input(const std::string &path, const SequenceOptions &o, const char *who) {
+        if (o.width <= 0 || o.height <= 0 || o.batch_frames < 2 || o.max_corners <= 0 || o.hypotheses <= 0)
+            throw std::invalid_argument(std::string(who) + ": bad options");
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error(std::string(who) + ": cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) {
+            ::close(fd);
+            throw std::runtime_error(std::string(who) + ": cannot stat " + path);
+        }
+        // A FIFO, pipe or /dev/stdin reports st_size 0 and cannot be read at offsets: it is streamed with read() by the
+        // one reader thread until it ends.
+        regular = S_ISREG(st.st_mode);
+        const size_t frame_bytes = (size_t)o.width * o.height * 3;
+        if (regular) frames = (uint64_t)st.st_size / frame_bytes;   // a trailing partial frame is dropped
+        if (o.max_frames && frames > o.max_frames) frames = o.max_frames;
+    }
+    ~Input() { ::close(fd); }
+    Input(const Input &) = delete;
+    Input &operator=(const Input &) = delete;
+};
 
+RecordHeader header_of(const SequenceOptions &o) {
     RecordHeader head;
     head.width = (uint32_t)o.width;
     head.height = (uint32_t)o.height;
-    head.max_corners = (uint32_t)K;
+    head.max_corners = (uint32_t)o.max_corners;
     head.hypotheses = (uint32_t)o.hypotheses;
     head.threshold = o.threshold;
     head.seed = o.seed;
-    RecordWriter writer(record_path, head);
+    return head;
+}
+
+// Frames [first_frame, first_frame + file_frames) of `in` on `ctx`: every consecutive pair inside the range goes to `sink`
+// in order.  Pair i keeps its global number (record.first_frame, and its seed o.seed ^ i), so a range computes exactly the
+// records the whole file would hold for those pairs.  A stream (not regular) starts at frame 0.
+template <typename Sink>
+SequenceStats run_range(vslam_ctx *ctx, int in, bool regular, uint64_t first_frame, uint64_t file_frames,
+                        const SequenceOptions &o, Sink &&sink) {
+    const int B = o.batch_frames, K = o.max_corners;
+    const size_t frame_bytes = (size_t)o.width * o.height * 3;
+    int readers = o.reader_threads;
+    if (const char *e = std::getenv("VSLAM_READER_THREADS")) readers = std::atoi(e);   // tuning
+    readers = readers < 1 ? 1 : (readers > 16 ? 16 : readers);
+    Pinned hbuf0(ctx, frame_bytes * B), hbuf1(ctx, frame_bytes * B);
+    uint8_t *hbuf[2] = {hbuf0.p, hbuf1.p};
+    Dev<uint8_t> dbuf0(ctx, frame_bytes * B), dbuf1(ctx, frame_bytes * B);
+    uint8_t *dbuf[2] = {dbuf0.p, dbuf1.p};
+    Dev<float> d_xy(ctx, 2 * (size_t)B * K), d_F(ctx, 9 * (size_t)B);
+    Dev<uint8_t> d_desc(ctx, 32 * (size_t)B * K);
+    Dev<int32_t> d_nodes(ctx, (size_t)B * K), d_n(ctx, B), d_matches(ctx, 2 * (size_t)B * K), d_best(ctx, 4 * (size_t)B);
+    Dev<uint32_t> d_seeds(ctx, B);
+    Dev<int8_t> d_pat(ctx, 1024);
+    check(ctx, vslam_copy_h2d(ctx, d_pat.p, detail::brief_pattern().data(), 1024), "pattern upload");
+    vslam_extract_params params;
+    detail::fill_extract_params(params, K, d_pat.p);
 
     // ---- reader thread: batch k -> hbuf[k & 1]; state[b]: 0 free, 1 filled (count[b] frames), 2 end of stream
     std::mutex mu;
@@ -231,7 +257,7 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
                         for (int j = t; j < want; j += readers) {
                             uint8_t *dst = hbuf[b] + frame_bytes * (size_t)(have + j);
                             size_t got = 0;
-                            const off_t at = (off_t)((read_total + (uint64_t)j) * frame_bytes);
+                            const off_t at = (off_t)((first_frame + read_total + (uint64_t)j) * frame_bytes);
                             while (got < frame_bytes) {
                                 const ssize_t r = ::pread(in, dst + got, frame_bytes - got, at + (off_t)got);
                                 if (r <= 0) {
@@ -319,16 +345,16 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
     bool final_batch = false, next_final = false;
     bool have = wait_filled(0, frames, final_batch);
     if (have) {
-        detail::check(vslam_upload_async(ctx, dbuf[0], hbuf[0], frame_bytes * (size_t)frames), "upload");
-        detail::check(vslam_upload_fence(ctx), "upload fence");
+        check(ctx, vslam_upload_async(ctx, dbuf[0], hbuf[0], frame_bytes * (size_t)frames), "upload");
+        check(ctx, vslam_upload_fence(ctx), "upload fence");
     }
     for (uint64_t k = 0; have; k++) {
         const int b = (int)(k & 1);
-        const uint64_t first = k * (uint64_t)(B - 1);   // global index of this batch's first frame = of its first pair
+        const uint64_t first = first_frame + k * (uint64_t)(B - 1);   // global index of this batch's first frame = of its first pair
         const int pairs = frames - 1;
         for (int i = 0; i < pairs; i++) h_seeds[i] = o.seed ^ (uint32_t)(first + (uint64_t)i);
-        detail::check(vslam_copy_h2d(ctx, d_seeds.p, h_seeds.data(), sizeof(uint32_t) * (size_t)pairs), "seed upload");
-        detail::check(vslam_frontend_sequence(ctx, dbuf[b], frames, o.width, o.height, 3 * o.width, &params, K, d_seeds.p,
+        check(ctx, vslam_copy_h2d(ctx, d_seeds.p, h_seeds.data(), sizeof(uint32_t) * (size_t)pairs), "seed upload");
+        check(ctx, vslam_frontend_sequence(ctx, dbuf[b], frames, o.width, o.height, 3 * o.width, &params, K, d_seeds.p,
                                               o.hypotheses, o.threshold, d_xy.p, d_desc.p, d_nodes.p, d_n.p, d_matches.p,
                                               d_best.p, d_F.p),
                       "frontend_sequence");
@@ -336,11 +362,11 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
         bool have_next = false;
         if (!final_batch) {
             have_next = wait_filled(b ^ 1, next_frames, next_final);
-            if (have_next) detail::check(vslam_upload_async(ctx, dbuf[b ^ 1], hbuf[b ^ 1], frame_bytes * (size_t)next_frames), "upload");
+            if (have_next) check(ctx, vslam_upload_async(ctx, dbuf[b ^ 1], hbuf[b ^ 1], frame_bytes * (size_t)next_frames), "upload");
         }
-        detail::check(vslam_copy_d2h(ctx, h_best.data(), d_best.p, sizeof(int32_t) * 4 * (size_t)pairs), "download");
-        detail::check(vslam_copy_d2h(ctx, h_F.data(), d_F.p, sizeof(float) * 9 * (size_t)pairs), "download");
-        detail::check(vslam_copy_d2h(ctx, h_matches.data(), d_matches.p, sizeof(int32_t) * 2 * (size_t)pairs * K), "download");
+        check(ctx, vslam_copy_d2h(ctx, h_best.data(), d_best.p, sizeof(int32_t) * 4 * (size_t)pairs), "download");
+        check(ctx, vslam_copy_d2h(ctx, h_F.data(), d_F.p, sizeof(float) * 9 * (size_t)pairs), "download");
+        check(ctx, vslam_copy_d2h(ctx, h_matches.data(), d_matches.p, sizeof(int32_t) * 2 * (size_t)pairs * K), "download");
         for (int i = 0; i < pairs; i++) {
             PairRecord r;
             r.first_frame = first + (uint64_t)i;
@@ -353,14 +379,14 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
             const int n = h_best[4 * i + 3];
             r.matches.resize((size_t)n);
             for (int j = 0; j < n; j++) r.matches[(size_t)j] = {h_matches[2 * ((size_t)i * K + j)], h_matches[2 * ((size_t)i * K + j) + 1]};
-            writer.append(r);
+            sink(std::move(r));
         }
         stats.pairs += (uint64_t)pairs;
-        stats.frames = first + (uint64_t)frames;
+        stats.frames = first - first_frame + (uint64_t)frames;
         stats.batches++;
         if (have_next) {
-            detail::check(vslam_upload_wait(ctx), "upload wait");   // hbuf[b ^ 1] is on the device
-            detail::check(vslam_upload_fence(ctx), "upload fence");
+            check(ctx, vslam_upload_wait(ctx), "upload wait");   // hbuf[b ^ 1] is on the device
+            check(ctx, vslam_upload_fence(ctx), "upload fence");
         }
         // hbuf[b] was uploaded before this batch ran and the next batch's shared frame comes from hbuf[b ^ 1]:
         // the reader may refill it
@@ -369,7 +395,103 @@ SequenceStats run_sequence(const std::string &video_path, const std::string &rec
         frames = next_frames;
         final_batch = next_final;
     }
+    stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return stats;
+}
+
+}  // namespace
+
+SequenceStats run_sequence(const std::string &video_path, const std::string &record_path, const SequenceOptions &o) {
+    Input input(video_path, o, "run_sequence");
+    RecordWriter writer(record_path, header_of(o));
+    SequenceStats stats = run_range(detail::context(), input.fd, input.regular, 0, input.frames, o,
+                                    [&](PairRecord &&r) { writer.append(r); });
     writer.close();
+    return stats;
+}
+
+namespace {
+// Contexts of run_sequence_devices, kept for the next call like the process-wide one (a context owns its streams and its
+// workspace arena: creating one and growing the arena again costs about 0.1 s per slot).  Entry (device, n) is the n-th
+// slot a call places on `device`; a slot thread has it to itself for the length of the call (g_slot_mu is held by the call).
+std::mutex g_slot_mu;
+std::vector<std::pair<std::pair<int, int>, vslam_ctx *>> g_slot_ctx;
+vslam_ctx *slot_context(int device, int nth) {   // on the thread that will use the context; the caller serialises
+    for (auto &e : g_slot_ctx)
+        if (e.first == std::make_pair(device, nth)) {
+            check(e.second, vslam_ctx_make_current(e.second), "ctx_make_current");
+            return e.second;
+        }
+    vslam_ctx *ctx = nullptr;
+    if (vslam_ctx_create(device, &ctx) != VSLAM_OK || !ctx)
+        throw std::runtime_error("cannot create a context on device " + std::to_string(device));
+    g_slot_ctx.push_back({{device, nth}, ctx});
+    return ctx;
+}
+}  // namespace
+
+SequenceStats run_sequence_devices(const std::string &video_path, const std::string &record_path, const SequenceOptions &o,
+                                   const std::vector<int> &devices) {
+    if (devices.empty()) throw std::invalid_argument("run_sequence_devices: no devices");
+    Input input(video_path, o, "run_sequence_devices");
+    if (!input.regular) throw std::invalid_argument("run_sequence_devices: the input must be a regular file (a stream cannot be read at offsets)");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int slots = (int)devices.size();
+    (void)detail::brief_pattern();   // resolved (settings / VSLAM_BRIEF_PATTERN / learned table) once, here: the slot threads only read it
+    const int64_t pairs = input.frames >= 2 ? (int64_t)input.frames - 1 : 0;
+    struct Slot {
+        std::vector<PairRecord> records;
+        SequenceStats stats;
+        std::string error;
+    };
+    std::vector<Slot> slot((size_t)slots);
+    std::lock_guard<std::mutex> one_call(g_slot_mu);   // the kept contexts belong to one call at a time
+    {
+        struct Pool {   // joined on every path out, as in the reader above
+            std::vector<std::thread> threads;
+            ~Pool() {
+                for (auto &th : threads)
+                    if (th.joinable()) th.join();
+            }
+        } pool;
+        pool.threads.reserve((size_t)slots);
+        std::mutex table_mu;   // g_slot_ctx itself, between this call's threads
+        for (int r = 0; r < slots; r++) {
+            // vslam_shard_range's rule in 64 bits: the first pairs % slots slots get one pair more
+            const int64_t base = pairs / slots, extra = pairs % slots;
+            const int64_t lo = base * r + std::min<int64_t>(r, extra), hi = lo + base + (r < extra ? 1 : 0);
+            if (hi <= lo) continue;   // more slots than pairs
+            int nth = 0;
+            for (int q = 0; q < r; q++) nth += devices[(size_t)q] == devices[(size_t)r];
+            pool.threads.emplace_back([&, r, lo, hi, nth] {
+                Slot &me = slot[(size_t)r];
+                try {
+                    vslam_ctx *ctx = nullptr;
+                    {   // makes devices[r] this thread's current device; everything below is allocated there
+                        std::lock_guard<std::mutex> lk(table_mu);
+                        ctx = slot_context(devices[(size_t)r], nth);
+                    }
+                    me.records.reserve((size_t)(hi - lo));
+                    // pairs [lo, hi) need frames [lo, hi]: neighbouring slots both read (and extract) the frame between them
+                    me.stats = run_range(ctx, input.fd, true, (uint64_t)lo, (uint64_t)(hi - lo) + 1, o,
+                                         [&](PairRecord &&rec) { me.records.push_back(std::move(rec)); });
+                } catch (const std::exception &e) {
+                    me.error = std::string("slot ") + std::to_string(r) + ": " + e.what();
+                }
+            });
+        }
+    }
+    for (const Slot &s : slot)
+        if (!s.error.empty()) throw std::runtime_error("run_sequence_devices: " + s.error);
+    RecordWriter writer(record_path, header_of(o));
+    SequenceStats stats;
+    for (const Slot &s : slot) {
+        for (const PairRecord &r : s.records) writer.append(r);
+        stats.pairs += s.stats.pairs;
+        stats.batches += s.stats.batches;
+    }
+    writer.close();
+    stats.frames = stats.pairs ? stats.pairs + 1 : std::min<uint64_t>(input.frames, 1);
     stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return stats;
 }
@@ -391,6 +513,37 @@ extern "C" int vslam_host_run_sequence(const char *video_path, const char *recor
         o.seed = seed;
         o.max_frames = max_frames;
         const vslam::SequenceStats s = vslam::run_sequence(video_path ? video_path : "", record_path ? record_path : "", o);
+        if (frames_out) *frames_out = s.frames;
+        if (pairs_out) *pairs_out = s.pairs;
+        if (seconds_out) *seconds_out = s.seconds;
+        return 0;
+    } catch (const std::exception &e) {
+        if (err && err_cap > 0) {
+            std::strncpy(err, e.what(), (size_t)err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return -1;
+    }
+}
+
+extern "C" int vslam_host_run_sequence_devices(const char *video_path, const char *record_path, int width, int height,
+                                               int batch_frames, int max_corners, int hypotheses, float threshold,
+                                               uint32_t seed, uint64_t max_frames, const int *devices, int n_devices,
+                                               uint64_t *frames_out, uint64_t *pairs_out, double *seconds_out, char *err,
+                                               int err_cap) {
+    try {
+        if (!devices || n_devices <= 0) throw std::invalid_argument("run_sequence_devices: no devices");
+        vslam::SequenceOptions o;
+        o.width = width;
+        o.height = height;
+        o.batch_frames = batch_frames;
+        o.max_corners = max_corners;
+        o.hypotheses = hypotheses;
+        o.threshold = threshold;
+        o.seed = seed;
+        o.max_frames = max_frames;
+        const vslam::SequenceStats s = vslam::run_sequence_devices(video_path ? video_path : "", record_path ? record_path : "", o,
+                                                                   std::vector<int>(devices, devices + n_devices));
         if (frames_out) *frames_out = s.frames;
         if (pairs_out) *pairs_out = s.pairs;
         if (seconds_out) *seconds_out = s.seconds;
