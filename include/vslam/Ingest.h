@@ -75,7 +75,7 @@ struct SequenceOptions {
     float threshold = 10.f;
     uint32_t seed = 0;           // pair i draws its sets from seed ^ i (the reference seeds from random_device)
     uint64_t max_frames = 0;     // stop after this many frames (0 = whole file)
-    int reader_threads = 8;      // threads that read a batch's frames from the file in parallel (pread)
+    int reader_threads = 12;     // threads that read a batch's frames from the file in parallel (pread)
 };
 
 struct SequenceStats {

@@ -1,9 +1,9 @@
 // Frame ingest + result records on top of the C ABI (include/vslam/Ingest.h).
 //
 // run_sequence keeps three things busy at once: a reader (a few threads, each pread()ing its share of the batch's
-// frames: one thread copies about 10 GB/s out of the page cache, a third of what the upload can take) fills one
-// page-locked buffer from the file while the copy stream uploads the other and the compute stream works on the batch
-// before it.
+// frames: one thread copies 5-9 GB/s out of the page cache, the upload takes 57 GB/s) fills one page-locked buffer
+// from the file while the copy stream uploads the other and the compute stream works on the batch before it.  A host
+// buffer goes back to the reader as soon as its upload is done, so reads and uploads run side by side all the time.
 // Batch k holds frames [k * (B - 1), k * (B - 1) + B): consecutive batches share one frame, so every
 // consecutive pair is computed exactly once and no feature has to survive a batch (re-extracting the shared
 // frame costs 1 / B of the extraction).
@@ -347,8 +347,16 @@ SequenceStats run_range(vslam_ctx *ctx, int in, bool regular, uint64_t first_fra
     if (have) {
         check(ctx, vslam_upload_async(ctx, dbuf[0], hbuf[0], frame_bytes * (size_t)frames), "upload");
         check(ctx, vslam_upload_fence(ctx), "upload fence");
+        check(ctx, vslam_upload_wait(ctx), "upload wait");
+        release(0);
     }
+    const bool trace = std::getenv("VSLAM_INGEST_TRACE") != nullptr;   // per-batch host timeline on stderr (milliseconds)
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     for (uint64_t k = 0; have; k++) {
+        const auto t_iter = std::chrono::steady_clock::now();
+        double t_enq = 0, t_filled = 0, t_down = 0, t_rec = 0;
         const int b = (int)(k & 1);
         const uint64_t first = first_frame + k * (uint64_t)(B - 1);   // global index of this batch's first frame = of its first pair
         const int pairs = frames - 1;
@@ -358,15 +366,18 @@ SequenceStats run_range(vslam_ctx *ctx, int in, bool regular, uint64_t first_fra
                                               o.hypotheses, o.threshold, d_xy.p, d_desc.p, d_nodes.p, d_n.p, d_matches.p,
                                               d_best.p, d_F.p),
                       "frontend_sequence");
+        t_enq = ms_since(t_iter);
         // the next batch goes up while this one is computed
         bool have_next = false;
         if (!final_batch) {
             have_next = wait_filled(b ^ 1, next_frames, next_final);
             if (have_next) check(ctx, vslam_upload_async(ctx, dbuf[b ^ 1], hbuf[b ^ 1], frame_bytes * (size_t)next_frames), "upload");
         }
+        t_filled = ms_since(t_iter);
         check(ctx, vslam_copy_d2h(ctx, h_best.data(), d_best.p, sizeof(int32_t) * 4 * (size_t)pairs), "download");
         check(ctx, vslam_copy_d2h(ctx, h_F.data(), d_F.p, sizeof(float) * 9 * (size_t)pairs), "download");
         check(ctx, vslam_copy_d2h(ctx, h_matches.data(), d_matches.p, sizeof(int32_t) * 2 * (size_t)pairs * K), "download");
+        t_down = ms_since(t_iter);
         for (int i = 0; i < pairs; i++) {
             PairRecord r;
             r.first_frame = first + (uint64_t)i;
@@ -384,13 +395,19 @@ SequenceStats run_range(vslam_ctx *ctx, int in, bool regular, uint64_t first_fra
         stats.pairs += (uint64_t)pairs;
         stats.frames = first - first_frame + (uint64_t)frames;
         stats.batches++;
+        t_rec = ms_since(t_iter);
         if (have_next) {
             check(ctx, vslam_upload_wait(ctx), "upload wait");   // hbuf[b ^ 1] is on the device
             check(ctx, vslam_upload_fence(ctx), "upload fence");
+            // A host buffer is free again the moment its upload is done, not when its batch has been computed: the reader
+            // fills hbuf[b] with batch k + 2 while hbuf[b ^ 1] goes up, so file reads and uploads overlap each other as well
+            // as the kernels.  (Only the reader writes the buffers: the frame batch k + 2 shares with k + 1 is still in
+            // hbuf[b ^ 1] when it copies it, whatever the state of that buffer.)
+            release(b ^ 1);
         }
-        // hbuf[b] was uploaded before this batch ran and the next batch's shared frame comes from hbuf[b ^ 1]:
-        // the reader may refill it
-        release(b);
+        if (trace)
+            std::fprintf(stderr, "batch %llu: enqueued %.2f, next batch filled + upload issued %.2f, results down %.2f, records %.2f, upload done %.2f\n",
+                         (unsigned long long)k, t_enq, t_filled, t_down, t_rec, ms_since(t_iter));
         have = have_next;
         frames = next_frames;
         final_batch = next_final;
