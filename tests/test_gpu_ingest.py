@@ -5,14 +5,13 @@
 * vslam::run_sequence (through its C entry point): raw BGR24 file -> record file; the records equal the oracle's
   pair results and do not depend on the batch size (which moves the frame that consecutive batches share).
 """
-import ctypes
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from vslam_amd import build, records, synth
+from vslam_amd import records, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -69,30 +68,15 @@ def test_sequence_equals_oracle_and_pairs(ctx, oracle):
 
 
 def run_sequence(video_path, record_path, batch, seed, max_frames=0):
-    lib = ctypes.CDLL(build.build_host())
-    frames, pairs, secs = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
-    err = ctypes.create_string_buffer(512)
-    rc = lib.vslam_host_run_sequence(str(video_path).encode(), str(record_path).encode(), W, H, batch, MAXC, HYP,
-                                     ctypes.c_float(THR), ctypes.c_uint32(seed), ctypes.c_uint64(max_frames),
-                                     ctypes.byref(frames), ctypes.byref(pairs), ctypes.byref(secs), err, 512)
-    assert rc == 0, err.value.decode()
-    return frames.value, pairs.value
+    return records.run_sequence(video_path, record_path, W, H, batch, MAXC, HYP, THR, seed, max_frames)[:2]
 
 
 def run_sequence_devices(video_path, record_path, batch, seed, devices, max_frames=0, expect_error=None):
-    lib = ctypes.CDLL(build.build_host())
-    frames, pairs, secs = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
-    err = ctypes.create_string_buffer(512)
-    dev = (ctypes.c_int * max(len(devices), 1))(*devices)
-    rc = lib.vslam_host_run_sequence_devices(str(video_path).encode(), str(record_path).encode(), W, H, batch, MAXC, HYP,
-                                             ctypes.c_float(THR), ctypes.c_uint32(seed), ctypes.c_uint64(max_frames),
-                                             dev, len(devices), ctypes.byref(frames), ctypes.byref(pairs),
-                                             ctypes.byref(secs), err, 512)
     if expect_error is not None:
-        assert rc == -1 and expect_error in err.value.decode(), err.value.decode()
+        with pytest.raises(RuntimeError, match=expect_error):
+            records.run_sequence(video_path, record_path, W, H, batch, MAXC, HYP, THR, seed, max_frames, devices=devices)
         return None
-    assert rc == 0, err.value.decode()
-    return frames.value, pairs.value
+    return records.run_sequence(video_path, record_path, W, H, batch, MAXC, HYP, THR, seed, max_frames, devices=devices)[:2]
 
 
 def test_capture_loop_over_device_slots(tmp_path):

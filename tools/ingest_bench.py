@@ -9,7 +9,6 @@ stream each), the one-GPU rehearsal of the several-device capture loop.
 usage: ingest_bench.py [--frames 257] [--batch 64] [--slots 0] [--width 1280 --height 720 --keypoints 2000 --hyp 4096]
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -31,9 +30,8 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="0: run_sequence; N > 0: run_sequence_devices, N contexts on device 0")
     args = ap.parse_args()
     import numpy as np
-    from vslam_amd import build, synth
+    from vslam_amd import records, synth
 
-    lib = ctypes.CDLL(build.build_host())
     tmp = tempfile.mkdtemp(prefix="vslam_ingest_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     vid, rec = os.path.join(tmp, "clip.bgr"), os.path.join(tmp, "clip.rec")
     # a clip whose neighbouring frames match: 'last' / 'current' halves of synthetic pairs interleaved, repeated
@@ -43,26 +41,17 @@ def main():
     with open(vid, "wb") as f:
         for i in range(args.frames):
             f.write(clip[i % 16].tobytes())
-    frames, pairs, secs = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
-    err = ctypes.create_string_buffer(512)
     out = {}
     for label in ("warm-up", "timed"):
         t0 = time.perf_counter()
-        if args.slots > 0:
-            dev = (ctypes.c_int * args.slots)(*([0] * args.slots))
-            rc = lib.vslam_host_run_sequence_devices(vid.encode(), rec.encode(), args.width, args.height, args.batch,
-                                                     args.keypoints, args.hyp, ctypes.c_float(10.0), ctypes.c_uint32(1),
-                                                     ctypes.c_uint64(0), dev, args.slots, ctypes.byref(frames),
-                                                     ctypes.byref(pairs), ctypes.byref(secs), err, 512)
-        else:
-            rc = lib.vslam_host_run_sequence(vid.encode(), rec.encode(), args.width, args.height, args.batch, args.keypoints,
-                                             args.hyp, ctypes.c_float(10.0), ctypes.c_uint32(1), ctypes.c_uint64(0),
-                                             ctypes.byref(frames), ctypes.byref(pairs), ctypes.byref(secs), err, 512)
-        if rc != 0:
-            sys.exit(err.value.decode())
-        out = {"frames": frames.value, "pairs": pairs.value, "loop_seconds": secs.value,
-               "wall_seconds": time.perf_counter() - t0, "pairs_per_s": pairs.value / secs.value,
-               "input_GB_per_s": frames.value * args.width * args.height * 3 / secs.value / 1e9,
+        try:
+            frames, pairs, secs = records.run_sequence(vid, rec, args.width, args.height, args.batch, args.keypoints, args.hyp,
+                                                       10.0, 1, devices=[0] * args.slots if args.slots > 0 else None)
+        except RuntimeError as e:
+            sys.exit(str(e))
+        out = {"frames": frames, "pairs": pairs, "loop_seconds": secs,
+               "wall_seconds": time.perf_counter() - t0, "pairs_per_s": pairs / secs,
+               "input_GB_per_s": frames * args.width * args.height * 3 / secs / 1e9,
                "batch_frames": args.batch, "slots": args.slots, "record_bytes": os.path.getsize(rec)}
     os.remove(vid)
     os.remove(rec)

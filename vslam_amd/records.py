@@ -50,3 +50,27 @@ def read_records(path):
         off += 8 * n
         recs.append(dict(first_frame=first, winner=winner, inliers=inliers, score=np.float32(score), F=F, matches=m))
     return header, recs
+
+
+def run_sequence(video_path, record_path, width, height, batch_frames, max_corners, hypotheses, threshold, seed,
+                 max_frames=0, devices=None):
+    """vslam::run_sequence (devices None) / vslam::run_sequence_devices (a list of device indices, one context each) through
+    their C entry points in libvslam_host.so: raw BGR24 file in, record file out.  -> (frames, pairs, seconds).
+    Raises RuntimeError with the library's message."""
+    import ctypes
+    from . import build
+    lib = ctypes.CDLL(build.build_host())
+    frames, pairs, secs = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+    err = ctypes.create_string_buffer(512)
+    head = (str(video_path).encode(), str(record_path).encode(), int(width), int(height), int(batch_frames), int(max_corners),
+            int(hypotheses), ctypes.c_float(threshold), ctypes.c_uint32(seed & 0xFFFFFFFF), ctypes.c_uint64(max_frames))
+    tail = (ctypes.byref(frames), ctypes.byref(pairs), ctypes.byref(secs), err, 512)
+    if devices is None:
+        rc = lib.vslam_host_run_sequence(*head, *tail)
+    else:
+        devices = list(devices)
+        dev = (ctypes.c_int * max(len(devices), 1))(*devices)
+        rc = lib.vslam_host_run_sequence_devices(*head, dev, len(devices), *tail)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return frames.value, pairs.value, secs.value
