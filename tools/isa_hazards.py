@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Scan gfx950 assembly (hipcc -S / -save-temps) for the one hazard the compiler cannot see for us: an inline-asm vector
+instruction reading a VGPR that a v_dot* / v_mfma* instruction wrote fewer than `need` wait states earlier in the same basic
+block.  The hazard recogniser knows what the compiler's own instructions are and pads them; for an asm statement it only
+knows the registers.  (Found the hard way: an asm v_mad_u32_u24 one wait state behind a v_dot4_u32_u8 read the old value
+on a third of the pixels; three wait states, the distance LLVM keeps for its own non-DOT readers, is what the other asm
+sites have.)
+
+usage: python tools/isa_hazards.py file.s [...]   -> exit status 1 if any site is closer than 3 wait states
+       scan(text, need=3) -> list of (function, distance, reader line, writer opcode)"""
+import re
+import sys
+
+_REG = re.compile(r"^v(\d+)$")
+_RANGE = re.compile(r"^v\[(\d+):(\d+)\]$")
+
+
+def _regs(tok):
+    tok = tok.strip().rstrip(",")
+    m = _REG.match(tok)
+    if m:
+        return [int(m.group(1))]
+    m = _RANGE.match(tok)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return []
+
+
+def scan(text, need=3):
+    found = []
+    fn, last, pos, in_asm = None, {}, 0, False
+    for ln in text.splitlines():
+        s = ln.strip()
+        if not s:
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if s.startswith(";"):
+            continue
+        if s.endswith(":") or (":" in s and s.split(":")[0].startswith((".LBB", "_Z"))):
+            name = s.split(":")[0]
+            if name.startswith(".LBB") or name.startswith(".L"):
+                last = {}            # a label: predecessors unknown; the compiler pads across blocks for its own instructions,
+                continue             # and an asm statement at a block's head is at least a branch away from any writer
+            if not name.startswith("."):
+                fn, last, pos = name, {}, 0
+            continue
+        if s.startswith("."):
+            continue
+        parts = s.split(None, 1)
+        op = parts[0]
+        args = parts[1].split(",") if len(parts) > 1 else []
+        if op == "s_nop":
+            pos += int(args[0].split(";")[0]) + 1
+            continue
+        pos += 1
+        if not op.startswith("v_") or not args:
+            continue
+        if in_asm:
+            for a in args[1:]:
+                for r in _regs(a.split(";")[0]):
+                    w = last.get(r)
+                    if w and w[1].startswith(("v_dot", "v_mfma", "v_smfmac")):
+                        d = pos - w[0] - 1
+                        if d < need:
+                            found.append((fn, d, s, w[1]))
+        for r in _regs(args[0]):
+            last[r] = (pos, op)
+    return found
+
+
+if __name__ == "__main__":
+    bad = 0
+    for path in sys.argv[1:]:
+        for fn, d, reader, writer in scan(open(path).read()):
+            print(f"{path}: {fn}: `{reader}` reads a {writer} result {d} wait state(s) later")
+            bad += 1
+    sys.exit(1 if bad else 0)

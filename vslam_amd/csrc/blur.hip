@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kBT) void gaussian7_kernel(const uint8_t *__restric
 // Step t of a segment owning rows [ys, ye): filter gray row ys - 3 + t horizontally; from t = 6 on, output
 // row ys - 6 + t.  Same Q8 taps, Q16 accumulate and rounding as gaussian7_kernel.
 struct BlurState {
-    uint32_t rp[7][4];    // horizontally filtered rows (Q8, < 2^16)
+    uint32_t pk[7][4];    // horizontally filtered rows (Q8, < 2^16) in pairs: slot k holds row k - 1 | row k << 16
+    uint32_t last[4];     // the newest filtered row by itself
     uint32_t raw[7][3];   // prefetched gray dwords x-4, x, x+4 of the next seven rows
 };
 struct BlurArgs {
@@ -62,10 +63,13 @@ struct BlurArgs {
     bool edge, left_fix, right_fix, own_lane;
 };
 
-__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+// v_mad_u32_u24 through the builtin, not inline asm: the result feeds v_dot2_u32_u16 as its addend, and the wait states the
+// hardware wants between the two are inserted by the compiler only if it can see what wrote the register (seen: with the
+// asm form the third and fourth pixel of a lane, whose multiply-adds come last, read a stale addend).
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+typedef unsigned short blur_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t rows, uint32_t taps, uint32_t acc) {   // v_dot2_u32_u16
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_u16x2, rows), __builtin_bit_cast(blur_u16x2, taps), acc, false);
 }
 
 template <int K>   // K = t % 7: ring slot of both the filtered row and the prefetched gray row
@@ -92,24 +96,31 @@ __device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int 
         if (a.left_fix) d0 = __builtin_amdgcn_perm(d1, d1, 0x01020300u);
         if (a.right_fix) d2 = __builtin_amdgcn_perm(d1, d1, 0x00000102u);
     }
-    st.rp[K][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), W0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), W1, 0u, false), false);
-    st.rp[K][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), W0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), W1, 0u, false), false);
-    st.rp[K][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), W0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), W1, 0u, false), false);
-    st.rp[K][3] = __builtin_amdgcn_udot4(d1, W0, __builtin_amdgcn_udot4(d2, W1, 0u, false), false);
+    uint32_t row[4];
+    row[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), W0,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), W1, 0u, false), false);
+    row[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), W0,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), W1, 0u, false), false);
+    row[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), W0,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), W1, 0u, false), false);
+    row[3] = __builtin_amdgcn_udot4(d1, W0, __builtin_amdgcn_udot4(d2, W1, 0u, false), false);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {   // filed with the row before it: the column pass takes two rows per instruction
+        st.pk[K][i] = st.last[i] | (row[i] << 16);
+        st.last[i] = row[i];
+    }
     if (t < 6) return;
     const int y = a.ys - 6 + t;
-    // column pass: v_mad_u32_u24 chains (every operand is below 2^24), the rounding constant rides in as the first
-    // addend, and the result byte (bits 16..23 of the sum, which is below 2^24) is picked with v_perm_b32
+    // column pass over the window's rows r0 .. r6 = slots K + 1 .. K + 6, K: three v_dot2_u32_u16 on the pairs (r0, r1),
+    // (r2, r3), (r4, r5) and one v_mad_u32_u24 for r6 (every sum is below 2^24), the rounding constant rides in as the
+    // first addend, and the result byte (bits 16..23 of the sum) is picked with v_perm_b32
     uint32_t sum[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        uint32_t acc = mad_u24(st.rp[(K + 1) % 7][i] + st.rp[K][i], 18u, 1u << 15);
-        acc = mad_u24(st.rp[(K + 2) % 7][i] + st.rp[(K + 6) % 7][i], 34u, acc);
-        acc = mad_u24(st.rp[(K + 3) % 7][i] + st.rp[(K + 5) % 7][i], 48u, acc);
-        sum[i] = mad_u24(st.rp[(K + 4) % 7][i], 56u, acc);
+        uint32_t acc = mad_u24(row[i], 18u, 1u << 15);
+        acc = dot2_u16(st.pk[(K + 2) % 7][i], 18u | (34u << 16), acc);
+        acc = dot2_u16(st.pk[(K + 4) % 7][i], 48u | (56u << 16), acc);
+        sum[i] = dot2_u16(st.pk[(K + 6) % 7][i], 48u | (34u << 16), acc);
     }
     const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);   // bytes: sum0[2], sum1[2], 0, 0
     const uint32_t hi = __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);   // bytes: 0, 0, sum2[2], sum3[2]
@@ -151,6 +162,8 @@ __global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__
     a.voff_l = (uint32_t)(xc - 4 < 0 ? 0 : xc - 4);
     a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
     BlurState st;
+#pragma unroll
+    for (int i = 0; i < 4; i++) st.last[i] = 0u;
 #pragma unroll
     for (int k = 0; k < 7; k++) {   // steps >= 7 always (a segment has at least one row)
         const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;

@@ -54,6 +54,12 @@ __device__ __forceinline__ void sqrt_rn4(const float t[4], float out[4]) {
 }
 
 
+// Inline asm hides from the compiler's hazard recogniser what kind of instruction reads `d`: after a v_dot4 (response.hip
+// feeds these the doubled gray values) a non-DOT vector instruction must not read the result for three wait states, and
+// the compiler only guarantees one in front of an asm statement (seen in blur.hip, where an asm v_mad_u32_u24 right behind
+// a v_dot4 read stale registers).  The plain C form `(float)((d >> 8 B) & 255)` selects the same instruction and is safe by
+// construction, but costs min_eigen 4-6 % through the schedule it leads to; the asm form stays, and
+// tests/test_isa_hazards.py (tools/isa_hazards.py) checks the distance in the generated code on every build.
 template <int B>
 __device__ __forceinline__ float cvt_ubyte(uint32_t d) {   // (float) of byte B of d
     float r;
