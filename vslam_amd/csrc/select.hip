@@ -858,7 +858,8 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     // every per-frame counter of the pipeline in one block, so that one memset clears all of it:
     // counts[F], overflow[1], fmax[F], low[F], count2[F], count3[F], need[F], cutkey[F], hist[F][bins],
     // pool: count[1], frame[slots], counts[slots], fmax[slots]
-    const size_t F = (size_t)frames, words = 7 * F + 1 + vs_response_hist_words(frames) + 1 + 3 * (size_t)pool.slots;
+    // (rounded up to 256 bytes: hipMemsetAsync clears a size that is not a multiple of its wide stores with a second kernel)
+    const size_t F = (size_t)frames, words = (7 * F + 1 + vs_response_hist_words(frames) + 1 + 3 * (size_t)pool.slots + 63) & ~(size_t)63;
     if ((rc = vs_arena_get(ctx, "gf.counts", sizeof(uint32_t) * words, (void **)&block))) return rc;
     VsCornerCounters c;
     c.counts = block;
