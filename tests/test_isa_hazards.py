@@ -27,6 +27,15 @@ _Zkernel:
     assert len(found) == 1 and found[0][1] == 1 and found[0][3] == "v_dot4_u32_u8"
     ok = bad.replace("s_nop 0", "s_nop 2")
     assert isa_hazards.scan(ok) == []
+    trans = """
+_Zk:
+	v_sqrt_f32_e32 v3, v2
+	;;#ASMSTART
+	v_max3_f32 v4, v3, v1, v0
+	;;#ASMEND
+"""
+    assert len(isa_hazards.scan(trans)) == 1                       # a transcendental's result, read at once
+    assert isa_hazards.scan(trans.replace(";;#ASMSTART", "v_mov_b32 v9, v8\n\t;;#ASMSTART")) == []
     # a compiler-selected reader is the compiler's business
     assert isa_hazards.scan(bad.replace(";;#ASMSTART", "").replace(";;#ASMEND", "")) == []
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scan gfx950 assembly (hipcc -S / -save-temps) for the one hazard the compiler cannot see for us: an inline-asm vector
 instruction reading a VGPR that a v_dot* / v_mfma* instruction wrote fewer than `need` wait states earlier in the same basic
-block.  The hazard recogniser knows what the compiler's own instructions are and pads them; for an asm statement it only
+block (and, with one wait state, a transcendental instruction's result).  The hazard recogniser knows what the compiler's own instructions are and pads them; for an asm statement it only
 knows the registers.  (Found the hard way: an asm v_mad_u32_u24 one wait state behind a v_dot4_u32_u8 read the old value
 on a third of the pixels; three wait states, the distance LLVM keeps for its own non-DOT readers, is what the other asm
 sites have.)
@@ -11,6 +11,7 @@ usage: python tools/isa_hazards.py file.s [...]   -> exit status 1 if any site i
 import re
 import sys
 
+_TRANS = ("v_sqrt_", "v_rsq_", "v_rcp_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
 _REG = re.compile(r"^v(\d+)$")
 _RANGE = re.compile(r"^v\[(\d+):(\d+)\]$")
 
@@ -64,10 +65,14 @@ def scan(text, need=3):
             for a in args[1:]:
                 for r in _regs(a.split(";")[0]):
                     w = last.get(r)
-                    if w and w[1].startswith(("v_dot", "v_mfma", "v_smfmac")):
-                        d = pos - w[0] - 1
-                        if d < need:
-                            found.append((fn, d, s, w[1]))
+                    if not w:
+                        continue
+                    d = pos - w[0] - 1
+                    if w[1].startswith(("v_dot", "v_mfma", "v_smfmac")) and d < need:
+                        found.append((fn, d, s, w[1]))
+                    # gfx940+: a non-transcendental reader right behind a transcendental writer wants one wait state
+                    if w[1].startswith(_TRANS) and d < 1:
+                        found.append((fn, d, s, w[1]))
         for r in _regs(args[0]):
             last[r] = (pos, op)
     return found
