@@ -30,10 +30,10 @@ void extract_features(Frame &frame, int nrows, int ncols);
 // reference: include/Frame.h:34, src/Frame.cpp:82-105
 void match_features(const Frame &frame1, const Frame &frame2, RansacFilter &rf,
                     std::vector<std::pair<int, int>> &matches, cv::Mat &F);
-#ifdef VSLAM_HAVE_OPENCV
-// reference: include/Frame.h:30, src/Frame.cpp:8-13 (needs cv::circle)
+// reference: include/Frame.h:30, src/Frame.cpp:8-13; called by the capture loop (src/vslam.cpp:91).  Host code: the image is
+// copied and every keypoint gets cv::circle(annotated, p, 2, Scalar(0, 255, 0)) -- cv::circle itself where OpenCV is
+// installed, its radius-2 outline (the eight pixels of OpenCV's midpoint circle, clipped to the image) otherwise.
 void draw(const Frame &frame, cv::Mat &annotated);
-#endif
 
 namespace vslam {
 struct Settings {

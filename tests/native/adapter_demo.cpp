@@ -44,6 +44,23 @@ int main(int argc, char **argv) {
         initialize_frame(fr, image, i);              // :60
         extract_features(fr);                        // :64
     }
+    {   // draw (src/Frame.cpp:8-13, src/vslam.cpp:91): a copy of the image with a green radius-2 ring on every keypoint
+        cv::Mat annotated;
+        draw(frames[0], annotated);
+        if (annotated.rows != h || annotated.cols != w || annotated.data == frames[0].image.data) return 21;
+        size_t changed = 0, green = 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const unsigned char *a = annotated.ptr<unsigned char>(y) + 3 * x, *b = frames[0].image.ptr<unsigned char>(y) + 3 * x;
+                if (a[0] == 0 && a[1] == 255 && a[2] == 0) green++;
+                if (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) changed++;
+            }
+        if (frames[0].points.empty() || green < 4 || green > 8 * frames[0].points.size() || changed > green) return 22;
+        const cv::Point c(frames[0].points[0]);   // corners lie at least a few pixels inside the image
+        const unsigned char *r = annotated.ptr<unsigned char>(c.y) + 3 * (c.x + 2), *m = annotated.ptr<unsigned char>(c.y) + 3 * c.x;
+        const unsigned char *m0 = frames[0].image.ptr<unsigned char>(c.y) + 3 * c.x;
+        if (!(r[0] == 0 && r[1] == 255 && r[2] == 0) || m[0] != m0[0] || m[1] != m0[1] || m[2] != m0[2]) return 23;
+    }
     RansacFilter rf(8, hyp, 10);                     // :19
     rf.set_seed(seed);
     std::vector<std::pair<int, int>> matches;

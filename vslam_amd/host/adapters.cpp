@@ -26,6 +26,9 @@
 #include <vector>
 
 #include "../../include/vslam/Frame.h"
+#ifdef VSLAM_HAVE_OPENCV
+#include <opencv2/imgproc.hpp>
+#endif
 #include "../../include/vslam_amd.h"
 #include "host_internal.h"
 
@@ -796,6 +799,30 @@ std::pair<int, float> RansacFilter::compute_fundamental_residual(const std::vect
 void initialize_frame(Frame &frame, const cv::Mat &image, long frame_id) {
     frame.image = image;   // shallow, aliases the capture buffer (src/Frame.cpp:4)
     frame.id = (u64)frame_id;
+}
+
+void draw(const Frame &frame, cv::Mat &annotated) {   // src/Frame.cpp:8-13; display only, nothing here touches the device
+    frame.image.copyTo(annotated);
+#ifdef VSLAM_HAVE_OPENCV
+    for (const auto &p : frame.points) cv::circle(annotated, p, 2, cv::Scalar(0, 255, 0));
+#else
+    if (annotated.empty()) return;
+    // cv::circle, radius 2, thickness 1: the midpoint walk plots (+-2, 0), (0, +-2) and then (+-1, +-1)
+    static const int ring[8][2] = {{2, 0}, {-2, 0}, {0, 2}, {0, -2}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
+    const int cn = annotated.channels();
+    for (const auto &p : frame.points) {
+        const cv::Point c(p);   // cvRound, as cv::circle's Point parameter converts
+        for (const auto &d : ring) {
+            const int x = c.x + d[0], y = c.y + d[1];
+            if (x < 0 || y < 0 || x >= annotated.cols || y >= annotated.rows) continue;
+            unsigned char *px = annotated.ptr<unsigned char>(y) + (size_t)x * cn;
+            if (annotated.depth() != CV_8U) continue;
+            px[0] = 0;                       // Scalar(0, 255, 0): B, G, R
+            if (cn > 1) px[1] = 255;
+            if (cn > 2) px[2] = 0;
+        }
+    }
+#endif
 }
 
 void extract_features(Frame &frame, int nrows, int ncols) {
