@@ -133,3 +133,33 @@ def test_large_frames_from_bgr_rows(ctx, oracle, w, h, pad, maxc):
         assert out["n_detected"][f] == r["n_detected"] and out["n"][f] == k, (w, h, f)
         assert np.array_equal(out["xy"][f, :k], r["xy"]) and np.array_equal(out["desc"][f, :k], r["desc"]), (w, h, f)
         assert np.array_equal(out["nodes"][f, :k], r["nodes"]), (w, h, f)
+
+
+def test_repeated_steps_are_deterministic():
+    """The same batch through the whole front-end 400 times on two contexts whose runs overlap on the device: every output of
+    every run equals the first run's (tools/determinism_soak.py is the long form).  A race, a stale workspace or a
+    timing-dependent pipeline hazard shows up here as a difference in some run; a comparison with the oracle of one run
+    would not see it."""
+    from vslam_amd import Context
+    w, h, K, H, P = 640, 480, 1000, 1024, 32
+    dev = torch.device("cuda:0")
+    bgr = synth.frames_torch(0x50AC0004, P, w, h, dev)
+    ca, sa = synth.keypoint_rotation()
+    seeds = torch.from_numpy(shard.pair_seeds(0x50AC0004, 0, P).view(np.int32)).to(dev)
+    ctxs = [Context(0, use_torch_stream=False) for _ in range(2)]
+    ref = ctxs[0].frontend_pairs(bgr, P, K, ca, sa, None, seeds, H, 10.0)
+    ctxs[0].synchronize()
+    ref = {k: v.clone() for k, v in ref.items()}
+    assert int(ref["best"][:, 1].min()) >= 8          # real models, not an empty batch
+    outs = [None, None]
+    for i in range(400):
+        c = i & 1
+        if outs[c] is not None:
+            ctxs[c].synchronize()
+            for k, v in ref.items():
+                assert torch.equal(outs[c][k], v), (i - 2, k)
+        outs[c] = ctxs[c].frontend_pairs(bgr, P, K, ca, sa, None, seeds, H, 10.0, out=outs[c])
+    for c in range(2):
+        ctxs[c].synchronize()
+        for k, v in ref.items():
+            assert torch.equal(outs[c][k], v), k
