@@ -136,6 +136,10 @@ int vslam_host_free(vslam_ctx *ctx, void *h_ptr);
 int vslam_upload_async(vslam_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int vslam_upload_fence(vslam_ctx *ctx);
 int vslam_upload_wait(vslam_ctx *ctx);
+/* The way back: device -> host on the context's COMPUTE stream, behind everything queued on it so far (the result copy that
+ * closes a batch).  Returns at once; the bytes are there when the stream has been waited for (vslam_ctx_wait /
+ * vslam_ctx_synchronize / vslam_pipeline_wait).  Page-locked h_dst keeps the copy asynchronous.                          */
+int vslam_download_async(vslam_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 
 /* per-kernel timing with HIP events on the context's stream (bench.py's roofline leg) */
 int vslam_prof_enable(vslam_ctx *ctx, int on);
@@ -361,6 +365,48 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
                             const uint32_t *d_seeds, int hyp, float threshold, float *d_xy,
                             uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches,
                             int32_t *d_best, float *d_F);
+
+/* ------------------------------------------------------------ batches in flight on one device
+ * The reference's capture loop (src/vslam.cpp:53-77) finishes one frame pair before it looks at the next.  On the device
+ * a batch runs through stages that fill the chip and stages of one workgroup per frame or pair that leave most of it
+ * idle; the entry points are stream-ordered and a context owns its streams and workspaces, so a caller with a queue of
+ * batches keeps k of them in flight on k contexts and the idle parts of one are filled by another (2.87 -> 2.60 ms per
+ * batch at the headline shape with k = 3).  A TICKET is one batch:
+ *   vslam_pipeline_acquire   next context, round-robin; waits for the batch that used it k tickets ago (at most k batches
+ *                            are ever queued) and files that batch's status.  Enqueue the batch on the context returned --
+ *                            any entry points of this header, uploads and vslam_gather_records included;
+ *   vslam_pipeline_commit    closes the batch (its status = the context's device-side error word at this point of the
+ *                            stream: copied and cleared in stream order, so one batch's overflow is reported for that
+ *                            ticket only and does not reach the next batch of the same context);
+ *   vslam_pipeline_submit_pairs / _sequence   acquire + vslam_frontend_pairs / _sequence (+ vslam_pack_records when
+ *                            d_records is not NULL) + commit.  Output buffers are the caller's, one set per batch in flight.
+ *                            An error of the wrapped call is returned at once, *ticket_out = -1, the slot stays usable;
+ *   vslam_pipeline_wait      blocks until that batch is complete; returns its status (VSLAM_OK, VSLAM_ERR_CAPACITY, ...).
+ *                            Statuses of failed batches nobody asked about are kept (the last 256);
+ *   vslam_pipeline_poll      1 = complete, 0 = not yet (never blocks);
+ *   vslam_pipeline_drain     waits for everything; the first failure not yet collected by vslam_pipeline_wait, else VSLAM_OK.
+ * Inputs of a batch must be ordered before it: resident, or uploaded through the acquired context (vslam_upload_async +
+ * vslam_upload_fence).  One submitting thread at a time (calls are serialised by a mutex).  n_ctx: 1 .. 16.           */
+typedef struct vslam_pipeline vslam_pipeline;
+int vslam_pipeline_create(int device, int n_ctx, vslam_pipeline **out);
+int vslam_pipeline_destroy(vslam_pipeline *p);
+int vslam_pipeline_size(const vslam_pipeline *p);
+vslam_ctx *vslam_pipeline_ctx(vslam_pipeline *p, int slot);   /* ticket t runs on slot t % size */
+const char *vslam_pipeline_last_error(vslam_pipeline *p);
+int vslam_pipeline_set_option(vslam_pipeline *p, int option, int value);   /* vslam_ctx_set_option on every context */
+int vslam_pipeline_acquire(vslam_pipeline *p, vslam_ctx **ctx_out, int64_t *ticket_out);
+int vslam_pipeline_commit(vslam_pipeline *p, int64_t ticket);
+int vslam_pipeline_submit_pairs(vslam_pipeline *p, const uint8_t *d_bgr, int pairs, int width, int height, int row_stride,
+                                const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                                float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                                int32_t *d_matches, int32_t *d_best, float *d_F, int32_t *d_records, int64_t *ticket_out);
+int vslam_pipeline_submit_sequence(vslam_pipeline *p, const uint8_t *d_bgr, int frames, int width, int height, int row_stride,
+                                   const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                                   float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                                   int32_t *d_matches, int32_t *d_best, float *d_F, int32_t *d_records, int64_t *ticket_out);
+int vslam_pipeline_poll(vslam_pipeline *p, int64_t ticket);
+int vslam_pipeline_wait(vslam_pipeline *p, int64_t ticket);
+int vslam_pipeline_drain(vslam_pipeline *p);
 
 /* ------------------------------------------------------------ several devices
  * Frame pairs are independent (src/RansacFilter.cpp:38: all state is per call), so a batch shards by contiguous slices,

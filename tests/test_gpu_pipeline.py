@@ -1,0 +1,227 @@
+"""Batches in flight behind the C ABI (vslam_pipeline_*, include/vslam_amd.h; C++: include/vslam/Pipeline.h).
+
+* the pipeline's output for every batch == the same batch on a single context == the oracle, bit for bit, for queues whose
+  length is not a multiple of the number of contexts and batches of different sizes (workspaces regrow between tickets);
+* a batch that overflows (VSLAM_ERR_CAPACITY) reports it on ITS ticket; the tickets before and behind it -- the next batch
+  of the same context included -- are clean and exact; a bad argument is refused at once and costs nothing;
+* the consecutive-frames form, poll(), drain();
+* the C++ surface through tests/native/pipeline_demo.cpp."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from vslam_amd import build, capi, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, MAXC, HYP, THR, SEED = 320, 240, 300, 64, 10.0, 0xFACE
+SIZES = [2, 1, 3, 1, 4, 2, 1]          # seven batches, 14 pairs
+
+
+@pytest.fixture(scope="module")
+def batches():
+    out, first = [], 0
+    for i, n in enumerate(SIZES):
+        bgr = synth.frames_numpy(500 + i, n, W, H)
+        seeds = (np.uint32(SEED) ^ np.arange(first, first + n, dtype=np.uint32))
+        out.append((bgr, seeds))
+        first += n
+    return out
+
+
+@pytest.fixture(scope="module")
+def reference(batches, oracle):
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    ref = []
+    for bgr, seeds in batches:
+        n = bgr.shape[0] // 2
+        rows = []
+        for i in range(n):
+            a = oracle.extract_features(bgr[i], MAXC, ca, sa, pat)
+            b = oracle.extract_features(bgr[n + i], MAXC, ca, sa, pat)
+            rows.append((a, b, oracle.match_features(a["xy"], a["desc"], b["xy"], b["desc"], int(seeds[i]), HYP, THR)))
+        ref.append(rows)
+    return ref
+
+
+def check_batch(out, rows):
+    n = len(rows)
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    for i, (a, b, r) in enumerate(rows):
+        k = len(r["matches"])
+        assert (o["n"][i], o["n"][n + i]) == (a["n"], b["n"]), i
+        assert np.array_equal(o["xy"][i, :a["n"]], a["xy"]) and np.array_equal(o["desc"][n + i, :b["n"]], b["desc"]), i
+        assert np.array_equal(o["nodes"][i, :a["n"]], a["nodes"]) and np.array_equal(o["nodes"][n + i, :b["n"]], b["nodes"]), i
+        assert o["best"][i, 3] == k and np.array_equal(o["matches"][i, :k], r["matches"]), i
+        if r["rc"] == 0:
+            assert np.array_equal(o["F"][i].view(np.uint32), r["F"].view(np.uint32)), i
+
+
+@pytest.mark.parametrize("n_ctx", [1, 2, 3, 5])
+def test_pipeline_equals_single_context_and_oracle(ctx, batches, reference, n_ctx):
+    pat = torch.from_numpy(synth.brief_pattern()).cuda()
+    ca, sa = synth.keypoint_rotation()
+    dev = [(torch.from_numpy(b).cuda(), torch.from_numpy(s.view(np.int32)).cuda()) for b, s in batches]
+    pipe = capi.Pipeline(0, n_ctx)
+    try:
+        assert pipe.size() == n_ctx
+        outs, recs, tickets = [], [], []
+        for bgr, seeds in dev:
+            n = bgr.shape[0] // 2
+            o = capi.Pipeline.alloc_outputs(torch, 2 * n, n, MAXC, bgr.device)
+            r = torch.zeros((n, 13 + MAXC), dtype=torch.int32, device=bgr.device)
+            tickets.append(pipe.submit_pairs(bgr, n, MAXC, ca, sa, pat if len(outs) % 2 else None, seeds, HYP, THR, o, records=r))
+            outs.append(o)
+            recs.append(r)
+        assert tickets == list(range(len(SIZES)))
+        pipe.wait(tickets[3])               # out of order on purpose
+        assert pipe.poll(tickets[3]) and pipe.poll(tickets[0])
+        pipe.drain()
+        assert all(pipe.poll(t) for t in tickets)
+        for (bgr, seeds), o, r, rows in zip(dev, outs, recs, reference):
+            n = bgr.shape[0] // 2
+            check_batch(o, rows)
+            single = ctx.frontend_pairs(bgr, n, MAXC, ca, sa, pat, seeds, HYP, THR)
+            ctx.synchronize()
+            for k in ("n", "best", "F", "xy", "desc", "nodes"):
+                assert torch.equal(single[k], o[k]), k
+            assert torch.equal(ctx.pack_records(o["F"], o["best"], o["matches"]), r)
+        assert pipe.workspace_bytes() > 0
+    finally:
+        pipe.close()
+
+
+def test_an_error_in_one_batch_does_not_poison_the_next(oracle):
+    """Ticket 1 overflows the corner lists on more frames than the fallback pool has sets (a bound of 40 entries, 8 frames,
+    4 sets): its wait() says VSLAM_ERR_CAPACITY.  Tickets 0, 2 and 3 -- 3 runs on the same context right behind it -- are
+    clean and exact, and so is ticket 1's own repeat with the default bound."""
+    w, h, maxc = 320, 240, 60
+    ca, sa = synth.keypoint_rotation()
+    bgr_np = synth.frames_numpy(77, 4, w, h)                  # 4 pairs = 8 textured frames
+    bgr = torch.from_numpy(bgr_np).cuda()
+    seeds_np = np.arange(4, dtype=np.uint32) + 9
+    seeds = torch.from_numpy(seeds_np.view(np.int32)).cuda()
+    pat = synth.brief_pattern()
+    rows = []
+    for i in range(4):
+        a = oracle.extract_features(bgr_np[i], maxc, ca, sa, pat)
+        b = oracle.extract_features(bgr_np[4 + i], maxc, ca, sa, pat)
+        rows.append((a, b, oracle.match_features(a["xy"], a["desc"], b["xy"], b["desc"], int(seeds_np[i]), HYP, THR)))
+
+    def check(o):
+        o = {k: v.cpu().numpy() for k, v in o.items()}
+        for i, (a, b, r) in enumerate(rows):
+            k = len(r["matches"])
+            assert (o["n"][i], o["n"][4 + i]) == (a["n"], b["n"]), i
+            assert o["best"][i, 3] == k and np.array_equal(o["matches"][i, :k], r["matches"]), i
+
+    pipe = capi.Pipeline(0, 2)
+    try:
+        outs = [capi.Pipeline.alloc_outputs(torch, 8, 4, maxc, bgr.device) for _ in range(5)]
+        t0 = pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[0])
+        t1, c1 = pipe.acquire()                                # slot 1, by hand: the bound applies to this batch only
+        c1.set_option(c1.OPT_CORNER_LIST_CAP, 40)
+        c1.frontend_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, out=outs[1])
+        c1.set_option(c1.OPT_CORNER_LIST_CAP, 0)
+        pipe.commit(t1)
+        t2 = pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[2])
+        t3 = pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[3])   # same context as t1 (retires t1 first)
+        assert (t0, t1, t2, t3) == (0, 1, 2, 3)
+        # a bad argument is refused at once, takes no ticket's worth of state with it
+        with pytest.raises(capi.VslamError, match="INVALID"):
+            pipe.submit_pairs(bgr[:0], 0, maxc, ca, sa, None, seeds, HYP, THR, outs[4])
+        t5 = pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[4])
+        assert pipe.wait_status(t3)[0] == 0 and pipe.wait_status(t0)[0] == 0 and pipe.wait_status(t2)[0] == 0
+        rc, msg = pipe.wait_status(t1)
+        assert rc == -4 and "ticket 1" in msg and "overflowed" in msg, (rc, msg)
+        assert pipe.wait_status(t1)[0] == 0                   # collected: reported once
+        assert pipe.wait_status(t5)[0] == 0
+        pipe.drain()                                           # nothing left to report
+        for i in (0, 2, 3, 4):
+            check(outs[i])
+        n1 = outs[1]["n"].cpu().numpy()
+        assert (n1 == 0).sum() == 4                            # the four frames that found no whole-image set
+    finally:
+        pipe.close()
+
+
+def test_drain_reports_the_first_uncollected_failure():
+    w, h, maxc = 320, 240, 60
+    ca, sa = synth.keypoint_rotation()
+    bgr = torch.from_numpy(synth.frames_numpy(78, 4, w, h)).cuda()
+    seeds = torch.arange(4, dtype=torch.int32).cuda()
+    pipe = capi.Pipeline(0, 3)
+    try:
+        pipe.set_option(capi.Context.OPT_CORNER_LIST_CAP, 40)
+        outs = [capi.Pipeline.alloc_outputs(torch, 8, 4, maxc, bgr.device) for _ in range(2)]
+        pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[0])
+        pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[1])
+        with pytest.raises(capi.VslamError, match=r"CAPACITY: ticket 0: .*\+1 more"):
+            pipe.drain()
+        pipe.drain()
+        t, c = pipe.acquire()
+        with pytest.raises(capi.VslamError, match="open"):
+            pipe.drain()
+        pipe.commit(t)
+        with pytest.raises(capi.VslamError, match="INVALID"):
+            pipe.commit(t)
+        pipe.drain()
+    finally:
+        pipe.close()
+
+
+def test_pipeline_sequence_form(ctx):
+    pat = torch.from_numpy(synth.brief_pattern()).cuda()
+    ca, sa = synth.keypoint_rotation()
+    clips = [torch.from_numpy(np.ascontiguousarray(synth.frames_numpy(600 + i, n, W, H)[:n + 1])).cuda() for i, n in enumerate((3, 5, 2, 4))]
+    pipe = capi.Pipeline(0, 3)
+    try:
+        outs = []
+        for i, clip in enumerate(clips):
+            f = clip.shape[0]
+            seeds = torch.arange(10 * i, 10 * i + f - 1, dtype=torch.int32).cuda()
+            o = capi.Pipeline.alloc_outputs(torch, f, f - 1, MAXC, clip.device)
+            pipe.submit_sequence(clip, MAXC, ca, sa, pat, seeds, HYP, THR, o)
+            outs.append((clip, seeds, o))
+        pipe.drain()
+        for clip, seeds, o in outs:
+            single = ctx.frontend_sequence(clip, MAXC, ca, sa, pat, seeds, HYP, THR)
+            ctx.synchronize()
+            for k in ("n", "best", "F", "xy", "desc", "nodes"):
+                assert torch.equal(single[k], o[k]), k
+    finally:
+        pipe.close()
+
+
+def test_pipeline_cpp_surface(batches, reference, tmp_path):
+    build.build_host()
+    exe = str(tmp_path / "pipeline_demo")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "native", "pipeline_demo.cpp"),
+                    "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vslam_amd"), "-lvslam_amd",
+                    "-Wl,-rpath," + os.path.join(ROOT, "vslam_amd")], check=True)
+    # one contiguous run of pairs; the demo cuts it into batches of 1, 2, 3, 1, 2, 3 ... with seeds SEED ^ global pair index
+    last = np.concatenate([b[:b.shape[0] // 2] for b, _ in batches])
+    cur = np.concatenate([b[b.shape[0] // 2:] for b, _ in batches])
+    rows = [r for rr in reference for r in rr]
+    P = last.shape[0]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("7i", W, H, MAXC, HYP, SEED, P, 3))
+        f.write(last.tobytes())
+        f.write(cur.tobytes())
+    subprocess.run([exe, fin, fout], check=True, timeout=120)
+    buf = open(fout, "rb").read()
+    off = 0
+    for i, (_, _, r) in enumerate(rows):
+        winner, inl, k = struct.unpack_from("3i", buf, off); off += 12
+        Fm = np.frombuffer(buf, np.float32, 9, off); off += 36
+        m = np.frombuffer(buf, np.int32, 2 * k, off).reshape(k, 2); off += 8 * k
+        assert k == len(r["matches"]) and np.array_equal(m, r["matches"]), i
+        if r["rc"] == 0:
+            assert np.array_equal(Fm.view(np.uint32), r["F"].view(np.uint32)) and inl == k, i
+    assert off == len(buf)

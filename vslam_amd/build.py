@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvslam_amd.so")
 SOURCES = ["capi.hip", "match.hip", "ransac.hip", "kdtree.hip", "gray.hip", "response.hip", "select.hip", "blur.hip",
-           "brief.hip", "orb_grid.hip", "pose.hip", "assoc.hip", "multi.hip"]
+           "brief.hip", "orb_grid.hip", "pose.hip", "assoc.hip", "multi.hip", "pipeline.hip"]
 HEADERS = ["ctx.h", "introselect.h", "image_common.h", os.path.join("..", "..", "include", "vslam_amd.h"),
            os.path.join("..", "..", "include", "vslam_brief_pattern_31.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]

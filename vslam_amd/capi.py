@@ -26,9 +26,12 @@ SYMBOLS = [
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points", "vslam_reprojection_filter",
     "vslam_match_features",
     "vslam_frontend_pairs", "vslam_frontend_sequence", "vslam_pack_records",
-    "vslam_host_alloc", "vslam_host_free", "vslam_upload_async", "vslam_upload_fence", "vslam_upload_wait",
+    "vslam_host_alloc", "vslam_host_free", "vslam_upload_async", "vslam_upload_fence", "vslam_upload_wait", "vslam_download_async",
     "vslam_shard_range", "vslam_multi_create", "vslam_multi_destroy", "vslam_multi_size", "vslam_multi_ctx", "vslam_multi_last_error",
     "vslam_multi_frontend_pairs", "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_gather_records",
+    "vslam_pipeline_create", "vslam_pipeline_destroy", "vslam_pipeline_size", "vslam_pipeline_ctx", "vslam_pipeline_last_error",
+    "vslam_pipeline_set_option", "vslam_pipeline_acquire", "vslam_pipeline_commit", "vslam_pipeline_submit_pairs",
+    "vslam_pipeline_submit_sequence", "vslam_pipeline_poll", "vslam_pipeline_wait", "vslam_pipeline_drain",
 ]
 
 
@@ -507,6 +510,123 @@ class MultiDevice:
     def close(self):
         if self.handle:
             self.lib.vslam_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pipeline:
+    """ctypes stub of vslam_pipeline_* (include/vslam_amd.h): k contexts on one device, batches handed to them round-robin.
+
+    `acquire()` returns (ticket, Context view of the slot's vslam_ctx); enqueue the batch on it, then `commit(ticket)`.
+    `submit_pairs` is the one-call form.  Output tensors are the caller's: keep one set per batch in flight."""
+
+    class _Borrowed(Context):
+        """A Context object over a vslam_ctx the pipeline owns (never destroyed from here)."""
+
+        def __init__(self, lib, handle, device):   # noqa: no super().__init__: nothing is created
+            import torch
+            self.torch = torch
+            self.lib = lib
+            self.handle = C.c_void_p(handle)
+            self.device = torch.device("cuda", device)
+
+        def close(self):
+            self.handle = C.c_void_p()
+
+    def __init__(self, device=0, n_ctx=3, lib=None):
+        self.lib = lib or load_library()
+        self.lib.vslam_pipeline_last_error.restype = C.c_char_p
+        self.lib.vslam_pipeline_ctx.restype = C.c_void_p
+        self.handle = C.c_void_p()
+        rc = self.lib.vslam_pipeline_create(C.c_int(device), C.c_int(n_ctx), C.byref(self.handle))
+        if rc != OK:
+            raise VslamError(f"vslam_pipeline_create({device}, {n_ctx}) failed: {ERRORS.get(rc, rc)}")
+        self.device = device
+        self.contexts = [self._Borrowed(self.lib, self.lib.vslam_pipeline_ctx(self.handle, C.c_int(i)), device)
+                         for i in range(self.size())]
+
+    def size(self):
+        return self.lib.vslam_pipeline_size(self.handle)
+
+    def _check(self, rc):
+        if rc != OK:
+            raise VslamError(f"{ERRORS.get(rc, rc)}: {self.lib.vslam_pipeline_last_error(self.handle).decode()}")
+
+    def set_option(self, option, value):
+        self._check(self.lib.vslam_pipeline_set_option(self.handle, C.c_int(option), C.c_int(int(value))))
+
+    def acquire(self):
+        ctx = C.c_void_p()
+        t = C.c_int64()
+        self._check(self.lib.vslam_pipeline_acquire(self.handle, C.byref(ctx), C.byref(t)))
+        return t.value, self.contexts[t.value % len(self.contexts)]
+
+    def commit(self, ticket):
+        self._check(self.lib.vslam_pipeline_commit(self.handle, C.c_int64(ticket)))
+
+    def submit_pairs(self, bgr, pairs, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, out, records=None, kp_stride=None):
+        F, H, W, _ = bgr.shape
+        assert F == 2 * pairs
+        K = kp_stride or max_corners
+        p = self.contexts[0]._params(max_corners, cos_a, sin_a, pattern)
+        t = C.c_int64()
+        self._check(self.lib.vslam_pipeline_submit_pairs(
+            self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K), _ptr(seeds),
+            C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out.get("nodes")), _ptr(out["n"]),
+            _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"]), _ptr(records), C.byref(t)))
+        return t.value
+
+    def submit_sequence(self, bgr, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, out, records=None, kp_stride=None):
+        F, H, W, _ = bgr.shape
+        K = kp_stride or max_corners
+        p = self.contexts[0]._params(max_corners, cos_a, sin_a, pattern)
+        t = C.c_int64()
+        self._check(self.lib.vslam_pipeline_submit_sequence(
+            self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K), _ptr(seeds),
+            C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out.get("nodes")), _ptr(out["n"]),
+            _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"]), _ptr(records), C.byref(t)))
+        return t.value
+
+    @staticmethod
+    def alloc_outputs(torch, frames, pairs, K, device):
+        return dict(xy=torch.zeros((frames, K, 2), dtype=torch.float32, device=device),
+                    desc=torch.zeros((frames, K, 32), dtype=torch.uint8, device=device),
+                    nodes=torch.full((frames, K), -1, dtype=torch.int32, device=device),
+                    n=torch.zeros((frames,), dtype=torch.int32, device=device),
+                    matches=torch.zeros((pairs, K, 2), dtype=torch.int32, device=device),
+                    best=torch.zeros((pairs, 4), dtype=torch.int32, device=device),
+                    F=torch.zeros((pairs, 9), dtype=torch.float32, device=device))
+
+    def poll(self, ticket):
+        rc = self.lib.vslam_pipeline_poll(self.handle, C.c_int64(ticket))
+        if rc < 0:
+            self._check(rc)
+        return bool(rc)
+
+    def wait(self, ticket):
+        self._check(self.lib.vslam_pipeline_wait(self.handle, C.c_int64(ticket)))
+
+    def wait_status(self, ticket):
+        """(rc, message) instead of raising."""
+        rc = self.lib.vslam_pipeline_wait(self.handle, C.c_int64(ticket))
+        return rc, (self.lib.vslam_pipeline_last_error(self.handle).decode() if rc else "")
+
+    def drain(self):
+        self._check(self.lib.vslam_pipeline_drain(self.handle))
+
+    def workspace_bytes(self):
+        return sum(c.workspace_bytes() for c in self.contexts)
+
+    def close(self):
+        if self.handle:
+            for c in self.contexts:
+                c.close()
+            self.lib.vslam_pipeline_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -71,6 +71,15 @@ struct VsAuxGuard {   // a job that was never forked (an error return in between
     }
 };
 
+// what a non-zero device-side error word says (vslam_ctx_synchronize, vslam_pipeline_wait)
+std::string vs_errflag_message(int32_t flag) {
+    std::string m = "a fixed-size device list overflowed (flag " + std::to_string(flag) + ")";
+    if (flag & 4)
+        m += ": more frames of one call needed the corner detector's whole-image fallback than its pool holds; "
+             "those frames got no corners (VSLAM_OPT_CORNER_LIST_CAP = -1 sizes every list for the whole image)";
+    return m;
+}
+
 int vs_device_errflag(vslam_ctx *ctx, int32_t **out) {
     const bool fresh = ctx->arena.find("ctx.errflag") == ctx->arena.end();
     int rc = vs_arena_get(ctx, "ctx.errflag", sizeof(int32_t), (void **)out);
@@ -248,10 +257,7 @@ int vslam_ctx_synchronize(vslam_ctx *ctx) {
         VS_HIP(ctx, hipMemcpy(&flag, it->second.ptr, sizeof(flag), hipMemcpyDeviceToHost));
         if (flag) {
             VS_HIP(ctx, hipMemset(it->second.ptr, 0, sizeof(flag)));
-            ctx->err = "a fixed-size device list overflowed (flag " + std::to_string(flag) + ")";
-            if (flag & 4)
-                ctx->err += ": more frames of one call needed the corner detector's whole-image fallback than its pool holds; "
-                            "those frames got no corners (VSLAM_OPT_CORNER_LIST_CAP = -1 sizes every list for the whole image)";
+            ctx->err = vs_errflag_message(flag);
             return VSLAM_ERR_CAPACITY;
         }
     }
@@ -371,6 +377,12 @@ int vslam_upload_fence(vslam_ctx *ctx) {
     if (!ctx) return VSLAM_ERR_INVALID;
     VS_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->copy_stream));
     VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
+    return VSLAM_OK;
+}
+int vslam_download_async(vslam_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, bytes == 0 || (h_dst && d_src), VSLAM_ERR_INVALID);
+    if (bytes) VS_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return VSLAM_OK;
 }
 int vslam_upload_wait(vslam_ctx *ctx) {

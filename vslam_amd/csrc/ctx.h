@@ -94,6 +94,7 @@ struct vslam_ctx {
 // sticky device-side error word (bit 0: a fixed-size candidate list overflowed); vslam_ctx_synchronize
 // reads and clears it and reports VSLAM_ERR_CAPACITY
 int vs_device_errflag(vslam_ctx *ctx, int32_t **out);
+std::string vs_errflag_message(int32_t flag);
 
 // fork the pending auxiliary job (if it was asked for at `point`) onto the auxiliary stream behind everything queued so far
 int vs_aux_job_point(vslam_ctx *ctx, int point);

@@ -1,0 +1,294 @@
+// Batches in flight on ONE device behind the C ABI (include/vslam_amd.h: vslam_pipeline_*).
+//
+// The reference's capture loop (src/vslam.cpp:53-77) handles one frame pair from first to last call before it looks at the
+// next.  On the device a batch goes through stages of very different shape: kernels that fill the chip (the detector, the
+// 8-point solves) and kernels of one workgroup per frame or pair that leave most of it idle (selection, the closing RANSAC
+// stages).  Every entry point is stream-ordered and a context owns its streams and workspaces, so the idle parts of one
+// batch can be filled by the arithmetic of another: k contexts, batches handed to them round-robin, each batch's outputs
+// in buffers the caller owns.  Measured at the headline shape: 2.87 ms per batch on one context, 2.60 with three.
+//
+// A ticket is one batch.  acquire() hands out the next context (waiting for the batch that used it k tickets ago, which
+// bounds the queue at k batches), the caller enqueues whatever belongs to the batch on it, commit() closes the batch: the
+// context's device-side error word is copied to a page-locked word of the slot and cleared IN STREAM ORDER, then an event
+// is recorded.  So a batch's status is its own: an overflow in batch t is reported by wait(t) and nowhere else, and the
+// batches before and behind it on the same context are untouched.  Host code only; no kernel lives here.
+#include "ctx.h"
+
+#include <algorithm>
+#include <deque>
+#include <mutex>
+
+namespace {
+struct Slot {
+    vslam_ctx *ctx = nullptr;
+    hipEvent_t done = nullptr;
+    int32_t *h_flag = nullptr;   // page-locked: the batch's copy of the context's error word
+    int32_t *d_flag = nullptr;
+    int64_t ticket = -1;         // batch in flight on this slot (committed, not yet retired); -1: none
+    bool open = false;           // acquired, not yet committed
+};
+struct Failure {
+    int64_t ticket;
+    int rc;
+    std::string err;
+};
+}  // namespace
+
+struct vslam_pipeline {
+    int device = 0;
+    std::vector<Slot> slots;
+    int64_t next_ticket = 0;
+    std::deque<Failure> failures;   // retired batches that failed and have not been asked about yet (bounded)
+    std::string err;
+    std::mutex mu;
+};
+
+std::string vs_errflag_message(int32_t flag);   // capi.hip
+
+namespace {
+constexpr size_t kMaxFailures = 256;
+
+// wait for the batch in flight on `s` (if any) and file its status
+int retire(vslam_pipeline *p, Slot &s) {
+    if (s.ticket < 0) return VSLAM_OK;
+    const int64_t t = s.ticket;
+    s.ticket = -1;
+    int rc = VSLAM_OK;
+    std::string err;
+    const hipError_t e = hipEventSynchronize(s.done);
+    if (e != hipSuccess) {
+        rc = VSLAM_ERR_HIP;
+        err = std::string("hipEventSynchronize: ") + hipGetErrorString(e);
+    } else if (*s.h_flag) {
+        rc = VSLAM_ERR_CAPACITY;
+        err = vs_errflag_message(*s.h_flag);
+    }
+    if (rc != VSLAM_OK) {
+        if (p->failures.size() >= kMaxFailures) p->failures.pop_front();
+        p->failures.push_back({t, rc, err});
+    }
+    return VSLAM_OK;
+}
+
+int acquire_locked(vslam_pipeline *p, vslam_ctx **ctx_out, int64_t *ticket_out) {
+    const int n = (int)p->slots.size();
+    Slot &s = p->slots[(size_t)(p->next_ticket % n)];
+    if (s.open) {
+        p->err = "vslam_pipeline_acquire: the previous ticket of this slot was never committed";
+        return VSLAM_ERR_INVALID;
+    }
+    if (hipSetDevice(p->device) != hipSuccess) {
+        p->err = "hipSetDevice failed";
+        return VSLAM_ERR_HIP;
+    }
+    retire(p, s);
+    s.open = true;
+    *ctx_out = s.ctx;
+    *ticket_out = p->next_ticket++;
+    return VSLAM_OK;
+}
+
+int commit_locked(vslam_pipeline *p, int64_t ticket) {
+    const int n = (int)p->slots.size();
+    if (ticket < 0 || ticket >= p->next_ticket) {
+        p->err = "vslam_pipeline_commit: no such ticket";
+        return VSLAM_ERR_INVALID;
+    }
+    Slot &s = p->slots[(size_t)(ticket % n)];
+    if (!s.open || ticket + n < p->next_ticket) {
+        p->err = "vslam_pipeline_commit: ticket is not open";
+        return VSLAM_ERR_INVALID;
+    }
+    s.open = false;
+    s.ticket = ticket;
+    vslam_ctx *c = s.ctx;
+    // the batch's own copy of the error word, then a clean word for the next batch -- both behind the batch's last kernel
+    hipError_t e = hipMemcpyAsync(s.h_flag, s.d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_flag, 0, sizeof(int32_t), c->stream);
+    if (e == hipSuccess) e = hipEventRecord(s.done, c->stream);
+    if (e != hipSuccess) {
+        p->err = std::string("vslam_pipeline_commit: ") + hipGetErrorString(e);
+        return VSLAM_ERR_HIP;
+    }
+    return VSLAM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vslam_pipeline_create(int device, int n_ctx, vslam_pipeline **out) {
+    if (!out || n_ctx < 1 || n_ctx > 16) return VSLAM_ERR_INVALID;
+    *out = nullptr;
+    auto *p = new vslam_pipeline();
+    p->device = device;
+    p->slots.resize((size_t)n_ctx);
+    int rc = VSLAM_OK;
+    for (int i = 0; i < n_ctx && rc == VSLAM_OK; i++) {
+        Slot &s = p->slots[(size_t)i];
+        rc = vslam_ctx_create(device, &s.ctx);
+        if (rc) break;
+        if ((rc = vs_device_errflag(s.ctx, &s.d_flag))) break;
+        if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_flag, sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+            rc = VSLAM_ERR_HIP;
+        else
+            *s.h_flag = 0;
+    }
+    if (rc) {
+        vslam_pipeline_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return VSLAM_OK;
+}
+
+int vslam_pipeline_destroy(vslam_pipeline *p) {
+    if (!p) return VSLAM_ERR_INVALID;
+    (void)hipSetDevice(p->device);
+    for (Slot &s : p->slots) {
+        if (s.ctx) (void)hipStreamSynchronize(s.ctx->stream);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.h_flag) (void)hipHostFree(s.h_flag);
+        if (s.ctx) vslam_ctx_destroy(s.ctx);
+    }
+    delete p;
+    return VSLAM_OK;
+}
+
+int vslam_pipeline_size(const vslam_pipeline *p) { return p ? (int)p->slots.size() : 0; }
+
+vslam_ctx *vslam_pipeline_ctx(vslam_pipeline *p, int slot) {
+    return (p && slot >= 0 && slot < (int)p->slots.size()) ? p->slots[(size_t)slot].ctx : nullptr;
+}
+
+const char *vslam_pipeline_last_error(vslam_pipeline *p) { return p ? p->err.c_str() : "null pipeline"; }
+
+int vslam_pipeline_set_option(vslam_pipeline *p, int option, int value) {
+    if (!p) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (Slot &s : p->slots) {
+        const int rc = vslam_ctx_set_option(s.ctx, option, value);
+        if (rc) {
+            p->err = vslam_last_error(s.ctx);
+            return rc;
+        }
+    }
+    return VSLAM_OK;
+}
+
+int vslam_pipeline_acquire(vslam_pipeline *p, vslam_ctx **ctx_out, int64_t *ticket_out) {
+    if (!p || !ctx_out || !ticket_out) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return acquire_locked(p, ctx_out, ticket_out);
+}
+
+int vslam_pipeline_commit(vslam_pipeline *p, int64_t ticket) {
+    if (!p) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return commit_locked(p, ticket);
+}
+
+int vslam_pipeline_submit_pairs(vslam_pipeline *p, const uint8_t *d_bgr, int pairs, int width, int height, int row_stride,
+                                const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                                float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                                int32_t *d_matches, int32_t *d_best, float *d_F, int32_t *d_records, int64_t *ticket_out) {
+    if (!p || !ticket_out) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    *ticket_out = -1;
+    vslam_ctx *c = nullptr;
+    int64_t t = -1;
+    int rc = acquire_locked(p, &c, &t);
+    if (rc) return rc;
+    rc = vslam_frontend_pairs(c, d_bgr, pairs, width, height, row_stride, params, kp_stride, d_seeds, hyp, threshold, d_xy,
+                              d_desc, d_nodes, d_n, d_matches, d_best, d_F);
+    if (rc == VSLAM_OK && d_records) rc = vslam_pack_records(c, d_F, d_best, d_matches, pairs, kp_stride, d_records);
+    // close the batch either way: whatever part of it was queued has to be waited for before the slot is used again (the
+    // caller has the error in hand: it is not filed under the ticket as well)
+    const int crc = commit_locked(p, t);
+    if (rc) {
+        p->err = std::string("ticket ") + std::to_string(t) + ": " + vslam_last_error(c);
+        return rc;
+    }
+    if (crc) return crc;
+    *ticket_out = t;
+    return VSLAM_OK;
+}
+
+int vslam_pipeline_submit_sequence(vslam_pipeline *p, const uint8_t *d_bgr, int frames, int width, int height, int row_stride,
+                                   const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                                   float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                                   int32_t *d_matches, int32_t *d_best, float *d_F, int32_t *d_records, int64_t *ticket_out) {
+    if (!p || !ticket_out) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    *ticket_out = -1;
+    vslam_ctx *c = nullptr;
+    int64_t t = -1;
+    int rc = acquire_locked(p, &c, &t);
+    if (rc) return rc;
+    rc = vslam_frontend_sequence(c, d_bgr, frames, width, height, row_stride, params, kp_stride, d_seeds, hyp, threshold, d_xy,
+                                 d_desc, d_nodes, d_n, d_matches, d_best, d_F);
+    if (rc == VSLAM_OK && d_records) rc = vslam_pack_records(c, d_F, d_best, d_matches, frames - 1, kp_stride, d_records);
+    const int crc = commit_locked(p, t);
+    if (rc) {
+        p->err = std::string("ticket ") + std::to_string(t) + ": " + vslam_last_error(c);
+        return rc;
+    }
+    if (crc) return crc;
+    *ticket_out = t;
+    return VSLAM_OK;
+}
+
+int vslam_pipeline_poll(vslam_pipeline *p, int64_t ticket) {
+    if (!p) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (ticket < 0 || ticket >= p->next_ticket) return VSLAM_ERR_INVALID;
+    Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
+    if (s.open && ticket + (int64_t)p->slots.size() >= p->next_ticket) return 0;   // not even committed
+    if (s.ticket != ticket) return 1;                                               // retired long ago
+    return hipEventQuery(s.done) == hipSuccess ? 1 : 0;
+}
+
+int vslam_pipeline_wait(vslam_pipeline *p, int64_t ticket) {
+    if (!p) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (ticket < 0 || ticket >= p->next_ticket) {
+        p->err = "vslam_pipeline_wait: no such ticket";
+        return VSLAM_ERR_INVALID;
+    }
+    Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
+    if (s.open && ticket + (int64_t)p->slots.size() >= p->next_ticket) {
+        p->err = "vslam_pipeline_wait: ticket was acquired but not committed";
+        return VSLAM_ERR_INVALID;
+    }
+    if (s.ticket == ticket) {
+        (void)hipSetDevice(p->device);
+        retire(p, s);
+    }
+    auto it = std::find_if(p->failures.begin(), p->failures.end(), [&](const Failure &f) { return f.ticket == ticket; });
+    if (it == p->failures.end()) return VSLAM_OK;
+    const int rc = it->rc;
+    p->err = "ticket " + std::to_string(ticket) + ": " + it->err;
+    p->failures.erase(it);
+    return rc;
+}
+
+int vslam_pipeline_drain(vslam_pipeline *p) {
+    if (!p) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    (void)hipSetDevice(p->device);
+    for (Slot &s : p->slots) {
+        if (s.open) {
+            p->err = "vslam_pipeline_drain: a ticket is still open (acquired, not committed)";
+            return VSLAM_ERR_INVALID;
+        }
+        retire(p, s);
+    }
+    if (p->failures.empty()) return VSLAM_OK;
+    const Failure f = p->failures.front();
+    p->err = "ticket " + std::to_string(f.ticket) + ": " + f.err +
+             (p->failures.size() > 1 ? " (+" + std::to_string(p->failures.size() - 1) + " more failed batches)" : "");
+    p->failures.clear();
+    return f.rc;
+}
+
+}  // extern "C"
