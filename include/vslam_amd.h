@@ -431,6 +431,16 @@ int vslam_multi_frontend_pairs(vslam_multi *m, const uint8_t *h_bgr_last, const 
                                int height, int row_stride, const vslam_extract_params *params, const int8_t *h_pattern,
                                int kp_stride, uint32_t base_seed, int hyp, float threshold, int32_t *h_records,
                                int32_t *h_n_keypoints);
+/* Host frames reach each device in chunks of 64 pairs, chunk k + 1 uploading while chunk k computes; all the same a slot is
+ * bound by its host link (57 GB/s page-locked = about 20 k pairs/s at 1280x720 against 90 k for the kernels).  When the
+ * frames are ALREADY on the devices (decoded there, produced by an earlier stage, uploaded ahead of time):
+ * d_bgr[r] = slot r's slice on slot r's device in vslam_frontend_pairs' layout -- the slice's `last` frames, then its
+ * `current` frames, (hi - lo) of each for [lo, hi) = vslam_shard_range(pairs, r, size) -- NULL allowed for an empty slice.
+ * Everything else as above: records and counts come back to host memory in pair order.                                 */
+int vslam_multi_frontend_pairs_resident(vslam_multi *m, const uint8_t *const *d_bgr, int pairs, int width, int height,
+                                        int row_stride, const vslam_extract_params *params, const int8_t *h_pattern,
+                                        int kp_stride, uint32_t base_seed, int hyp, float threshold, int32_t *h_records,
+                                        int32_t *h_n_keypoints);
 
 /* (ii) One process per device (any launcher): every rank runs its slice on its own context; the records are exchanged once,
  * all-gather over RCCL (xGMI inside a node) on the context's stream.  RCCL is loaded when the first of these is called.
@@ -445,6 +455,14 @@ int vslam_comm_create(vslam_ctx *ctx, const void *id, int world, int rank, vslam
 int vslam_comm_destroy(vslam_comm *comm);
 int vslam_gather_records(vslam_ctx *ctx, vslam_comm *comm, const int32_t *d_records, size_t words_per_rank,
                          int32_t *d_all);
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank), not what vslam_comm_create was told.  */
+int vslam_comm_info(vslam_comm *comm, int *world_out, int *rank_out);
+/* Uneven slices and the rooted form.  Rank r contributes h_words[r] int32 words (HOST array of `world` counts, the same on
+ * every rank; 0 allowed); d_all receives them in rank order = pair order.  root < 0: every rank receives everything (an
+ * all-gather with counts); root >= 0: only that rank does -- each peer sends its block once, straight to the root, over its
+ * own xGMI link (d_all may be NULL on the others).  One group of ncclSend / ncclRecv on the context's stream. */
+int vslam_gather_records_v(vslam_ctx *ctx, vslam_comm *comm, const int32_t *d_records, const size_t *h_words, int root,
+                           int32_t *d_all);
 
 #ifdef __cplusplus
 }

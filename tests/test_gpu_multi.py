@@ -85,6 +85,57 @@ def test_more_slots_than_pairs(batch, reference):
         assert np.array_equal(Fm[i].numpy().view(np.uint32), r["F"].view(np.uint32)), i
 
 
+@pytest.mark.parametrize("slots", [[0], [0, 0, 0], [0] * 9])
+def test_multi_device_resident_frames(batch, reference, slots):
+    """Frames already on the slots' devices (vslam_multi_frontend_pairs_resident): same records as from host memory; with
+    nine slots over seven pairs two slices are empty and their pointers NULL."""
+    last, cur = batch
+    ca, sa = synth.keypoint_rotation()
+    md = capi.MultiDevice(slots)
+    try:
+        slices = []
+        for r in range(len(slots)):
+            lo, hi = shard.shard_range(P, r, len(slots))
+            slices.append(torch.from_numpy(np.concatenate([last[lo:hi], cur[lo:hi]])).cuda() if hi > lo else None)
+        torch.cuda.synchronize()
+        rec, n = md.frontend_pairs_resident(slices, P, MAXC, ca, sa, None, SEED, HYP, THR)
+        check_records(rec, n, reference)
+        rec_h, n_h = md.frontend_pairs(last, cur, MAXC, ca, sa, None, SEED, HYP, THR)
+        assert np.array_equal(rec_h[:, :13], rec[:, :13]) and np.array_equal(n, n_h)
+        if len(slots) > 1:
+            slices[1] = None                                      # a slot with pairs but no frames is refused
+            with pytest.raises(capi.VslamError, match="INVALID"):
+                md.frontend_pairs_resident(slices, P, MAXC, ca, sa, None, SEED, HYP, THR)
+    finally:
+        md.close()
+
+
+def test_multi_device_host_frames_in_chunks(oracle):
+    """More pairs per slot than one upload chunk (64): chunk k + 1 uploads while chunk k computes; the records are those of
+    one call over the whole slice (a pair's result does not depend on its batch)."""
+    w, h, maxc, n_pairs = 160, 120, 100, 150
+    base = synth.frames_numpy(321, 6, w, h)
+    idx = np.arange(n_pairs) % 6
+    last, cur = np.ascontiguousarray(base[:6][idx]), np.ascontiguousarray(base[6:][idx])
+    ca, sa = synth.keypoint_rotation()
+    pat = synth.brief_pattern()
+    md = capi.MultiDevice([0, 0])
+    try:
+        rec, n = md.frontend_pairs(last, cur, maxc, ca, sa, None, 5, HYP, THR)
+    finally:
+        md.close()
+    Fm, best, matches = shard.unpack_records(torch.from_numpy(rec), maxc)
+    feats = [(oracle.extract_features(base[i], maxc, ca, sa, pat), oracle.extract_features(base[6 + i], maxc, ca, sa, pat)) for i in range(6)]
+    for i in list(range(0, n_pairs, 7)) + [63, 64, 74, 75, 138, 139, 149]:       # chunk and slice borders included
+        a, b = feats[idx[i]]
+        r = oracle.match_features(a["xy"], a["desc"], b["xy"], b["desc"], 5 ^ i, HYP, THR)
+        k = len(r["matches"])
+        assert (n[i], n[n_pairs + i]) == (a["n"], b["n"]), i
+        assert int(best[i, 3]) == k and np.array_equal(matches[i, :k].numpy(), r["matches"]), i
+        if r["rc"] == 0:
+            assert np.array_equal(Fm[i].numpy().view(np.uint32), r["F"].view(np.uint32)), i
+
+
 def test_multi_device_rejects_bad_arguments(batch):
     last, cur = batch
     with pytest.raises(capi.VslamError):
@@ -142,5 +193,17 @@ def test_gather_records_over_rccl_single_rank(ctx):
         ctx.synchronize()
         assert torch.equal(out, rec)
         assert lib.vslam_gather_records(ctx.handle, comm, None, ctypes.c_size_t(4), ctypes.c_void_p(out.data_ptr())) == -1
+        world, rank = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib.vslam_comm_info(comm, ctypes.byref(world), ctypes.byref(rank)) == 0 and (world.value, rank.value) == (1, 0)
+        # the form with per-rank counts, all-gather (root -1) and rooted (root 0): with one rank the own block is all there is
+        words = (ctypes.c_size_t * 1)(rec.numel() - 11)
+        for root in (-1, 0):
+            out.zero_()
+            assert lib.vslam_gather_records_v(ctx.handle, comm, ctypes.c_void_p(rec.data_ptr()), words, ctypes.c_int(root),
+                                              ctypes.c_void_p(out.data_ptr())) == 0
+            ctx.synchronize()
+            assert torch.equal(out.view(-1)[:rec.numel() - 11], rec.view(-1)[:rec.numel() - 11]) and int(out.view(-1)[-11:].abs().sum()) == 0
+        assert lib.vslam_gather_records_v(ctx.handle, comm, ctypes.c_void_p(rec.data_ptr()), words, ctypes.c_int(1),
+                                          ctypes.c_void_p(out.data_ptr())) == -1       # no such root
     finally:
         assert lib.vslam_comm_destroy(comm) == 0

@@ -28,7 +28,7 @@ SYMBOLS = [
     "vslam_frontend_pairs", "vslam_frontend_sequence", "vslam_pack_records",
     "vslam_host_alloc", "vslam_host_free", "vslam_upload_async", "vslam_upload_fence", "vslam_upload_wait", "vslam_download_async",
     "vslam_shard_range", "vslam_multi_create", "vslam_multi_destroy", "vslam_multi_size", "vslam_multi_ctx", "vslam_multi_last_error",
-    "vslam_multi_frontend_pairs", "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_gather_records",
+    "vslam_multi_frontend_pairs", "vslam_multi_frontend_pairs_resident", "vslam_comm_info", "vslam_gather_records_v", "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_gather_records",
     "vslam_pipeline_create", "vslam_pipeline_destroy", "vslam_pipeline_size", "vslam_pipeline_ctx", "vslam_pipeline_last_error",
     "vslam_pipeline_set_option", "vslam_pipeline_acquire", "vslam_pipeline_commit", "vslam_pipeline_submit_pairs",
     "vslam_pipeline_submit_sequence", "vslam_pipeline_poll", "vslam_pipeline_wait", "vslam_pipeline_drain",
@@ -501,6 +501,27 @@ class MultiDevice:
         rc = self.lib.vslam_multi_frontend_pairs(
             self.handle, last.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p), C.c_int(P), C.c_int(W), C.c_int(H),
             C.c_int(3 * W), C.byref(p), pat.ctypes.data_as(C.c_void_p) if pat is not None else C.c_void_p(0), C.c_int(max_corners),
+            C.c_uint32(base_seed & 0xFFFFFFFF), C.c_int(hyp), C.c_float(threshold), rec.ctypes.data_as(C.c_void_p),
+            n.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise VslamError(f"{ERRORS.get(rc, rc)}: {self.lib.vslam_multi_last_error(self.handle).decode()}")
+        return rec, n
+
+    def frontend_pairs_resident(self, slices, pairs, max_corners, cos_a, sin_a, pattern, base_seed, hyp, threshold):
+        """slices[r]: torch uint8 (2 * ps, H, W, 3) ALREADY on slot r's device = the slot's `last` frames then its `current` ones
+        (None for an empty slice).  Returns (records, keypoint counts) like frontend_pairs."""
+        import numpy as np
+        shape = next(t.shape for t in slices if t is not None)
+        H, W = int(shape[1]), int(shape[2])
+        p = ExtractParams()
+        p.max_corners, p.quality, p.min_distance, p.cos_a, p.sin_a, p.d_pattern = max_corners, 0.01, 3.0, cos_a, sin_a, None
+        rec = np.zeros((pairs, 13 + max_corners), np.int32)
+        n = np.zeros(2 * pairs, np.int32)
+        pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8)
+        ptrs = (C.c_void_p * len(slices))(*[(t.data_ptr() if t is not None else None) for t in slices])
+        rc = self.lib.vslam_multi_frontend_pairs_resident(
+            self.handle, ptrs, C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p),
+            pat.ctypes.data_as(C.c_void_p) if pat is not None else C.c_void_p(0), C.c_int(max_corners),
             C.c_uint32(base_seed & 0xFFFFFFFF), C.c_int(hyp), C.c_float(threshold), rec.ctypes.data_as(C.c_void_p),
             n.ctypes.data_as(C.c_void_p))
         if rc != OK:
