@@ -4,7 +4,11 @@
 A step = one pass of extract(2 frames per pair) + match + RANSAC over one batch of synthetic
 frame pairs already resident in HBM.  N = 1 runs BASELINE.json configs[2] (1280x720, 2000
 keypoints, 4096 hypotheses, batch 256); with N > 1 every rank runs the same per-GPU batch on its
-own shard (weak scaling, configs[3]) and the per-pair result records are gathered over RCCL.
+own shard (weak scaling, configs[3]) and the per-pair result records are gathered with the
+library's own collective (vslam_gather_records: RCCL all-gather on the batch's stream).
+Steps are handed round-robin to the contexts of a vslam_pipeline (--in-flight, default 3): each
+batch in flight has its own frames, outputs and communicator; the timed region ends when every
+batch is complete.  The data is SURVEY 8(d)'s regime (--data hard) since round 5.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of the step,
 timed with HIP events on the stream the kernels run on; `cpu_baseline` is the oracle (a CPU port
@@ -134,6 +138,8 @@ def source_stamp():
     d = os.path.join(ROOT, "vslam_amd", "csrc")
     out, hdr = {}, hashlib.sha256()
     for name in sorted(os.listdir(d)):
+        if not name.endswith((".h", ".hip")):
+            continue
         with open(os.path.join(d, name), "rb") as fh:
             data = fh.read()
         if name.endswith(".h"):
@@ -391,26 +397,27 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU and batch (default: the workload's batch)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="batches in flight per GPU: contexts of the vslam_pipeline the steps are handed to round-robin "
+                         "(1 = one batch after the other on one context, the arrangement of rounds 1-4)")
     ap.add_argument("--cpu-pairs", type=int, default=150,
-                    help="pairs of the timed batch that the oracle recomputes on the host: the CPU baseline and the in-bench parity "
-                         "check at once (0 = no CPU leg; the parity check then still covers 4 pairs)")
-    ap.add_argument("--data", default="easy", choices=["easy", "hard"],
-                    help="easy = translated texture + one moving block (the headline's data since round 1); hard = SURVEY 8(d)'s "
-                         "regime: rotation + parallax, sub-pixel resampling, 40-45 %% outlier matches (synth.frames_torch_hard)")
+                    help="pairs of the timed batches that the oracle recomputes on the host, spread over the contexts: the CPU baseline "
+                         "and the in-bench parity check at once (0 = no CPU leg; the parity check then still covers 4 pairs)")
+    ap.add_argument("--data", default="hard", choices=["easy", "hard"],
+                    help="hard (default since round 5) = SURVEY 8(d)'s regime: rotation + parallax, sub-pixel resampling, 40-45 %% outlier "
+                         "matches (synth.frames_torch_hard); easy = translated texture + one moving block (the headline's data of rounds 1-4)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the secondary measurements (hard-data regime, full-evaluation worst case, C2 / C5)")
+                    help="skip the secondary measurements (other data regime, full-evaluation worst case, in-flight sweep, C2 / C5)")
     ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
                     help="pairs per process for the all-host-cores CPU figure (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--solver", default="exact", choices=["exact", "gram"],
                     help="gram = the opt-in MFMA / normal-matrix 8-point solver (VSLAM_OPT_RANSAC_SOLVER 1): NOT bit-exact, "
                          "never the headline number; the line is labelled")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="split each GPU's batch over this many contexts (own stream + workspaces) that run concurrently")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also run two 1 GiB streaming copies (4 B and 16 B per lane) so FETCH_SIZE/WRITE_SIZE can be calibrated")
     args = ap.parse_args()
@@ -431,31 +438,29 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from vslam_amd import Context, shard, synth
+    from vslam_amd import capi, shard, synth
+    from vslam_amd.capi import Pipeline
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # VSLAM_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, record gather, max-over-ranks timing)
-    # with a single rank, which is how that path is exercised with RCCL on a one-GPU box
+    # VSLAM_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, communicators, record gather, max-over-ranks
+    # timing) with a single rank, which is how that path is exercised with RCCL on a one-GPU box
     multi = world > 1 or bool(os.environ.get("VSLAM_BENCH_FORCE_DIST"))
+    # The record gather -- the only exchange on the path -- goes through the PRODUCT's collective: vslam_comm_* /
+    # vslam_gather_records (RCCL all-gather on the context's stream, include/vslam_amd.h).  torch.distributed is the control
+    # plane only (the unique ids, the barriers around the timed region, the per-rank times) and runs over gloo, so the one
+    # RCCL communicator per context in this process is the library's.  VSLAM_BENCH_GATHER=host rehearses N > 1 on a box with
+    # fewer GPUs than ranks (RCCL refuses two ranks on one device): the records then travel through host memory over gloo.
+    gather_mode = os.environ.get("VSLAM_BENCH_GATHER", "rccl") if multi else "none"
     if args.gpus > 1 or multi:
         if world != args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # VSLAM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks
-        # (ranks then share devices and the record gather goes through host memory)
-        backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
         local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            # no device_id: binding the group to the device at init (eager communicator) was measured to slow every
-            # step of the kernels by 0.33 ms on this stack; the device is the current one (set_device above)
-            dist.init_process_group("nccl")
-        else:
-            dist.init_process_group(backend)
-    backend_label = {"nccl": "RCCL"}.get(dist.get_backend(), dist.get_backend()) if multi else "none"
+        dist.init_process_group(os.environ.get("VSLAM_BENCH_BACKEND", "gloo"))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -464,62 +469,57 @@ def main():
         P = args.pairs
     thr = 10.0                                    # RansacFilter rf(8, 100, 10), src/vslam.cpp:19
     seed = 0x5EED0000 + sorted(WORKLOADS).index(args.workload)
-    ctx = Context(local_rank)
+    n_slots = max(1, min(16, args.in_flight))
+    pipe = Pipeline(local_rank, n_slots)
     if args.solver == "gram":
-        ctx.set_option(ctx.OPT_RANSAC_SOLVER, 1)
-    lanes = max(1, args.lanes)
-    assert P % lanes == 0
-    PL = P // lanes
-    lane_ctx = [ctx] if lanes == 1 else [Context(local_rank, use_torch_stream=False) for _ in range(lanes)]
+        pipe.set_option(capi.Context.OPT_RANSAC_SOLVER, 1)
+    ctx = pipe.contexts[0]
     make_frames = synth.frames_torch if args.data == "easy" else synth.frames_torch_hard
-    bgr = make_frames(seed + 1000 * rank, P, w, h, dev)
     pat = torch.from_numpy(synth.brief_pattern()).to(dev)
     ca, sa = synth.keypoint_rotation()
-    lo, hi = shard.shard_range(world * P, rank, world)          # this rank's slice of the global batch
-    seeds = torch.from_numpy(shard.pair_seeds(seed, lo, hi).view(np.int32)).to(dev)
-    out = None
-    # Two sets of record buffers: the gather of step k runs on the process group's own stream while step k + 1 computes
-    # (nothing in a step reads the gathered records); a set is reused only after its gather has completed.
-    gathered = [torch.empty((world * P, shard.record_words(K)), dtype=torch.int32, device=dev) for _ in range(2)] if multi else None
-    rec_buf = [torch.empty((P, shard.record_words(K)), dtype=torch.int32, device=dev) for _ in range(2)] if multi else None
-    gather_work = [None, None]
-    steps_done = 0
-    if multi and dist.get_backend() == "nccl":
-        # set-up, not a step: the RCCL communicator is created by the first collective (seconds); keep that out of the
-        # steps even when the caller asks for no warm-up
-        rec_buf[0].zero_()
-        dist.all_gather_into_tensor(gathered[0], rec_buf[0])
-        torch.cuda.synchronize(dev)
+    lo, hi = shard.shard_range(world * P, rank, world)          # this rank's slice of a global batch
+    words = shard.record_words(K)
 
-    if lanes > 1:   # lane l owns pairs [l*PL, (l+1)*PL): its "last" and "current" frames made contiguous
-        lane_bgr = [torch.cat([bgr[l * PL:(l + 1) * PL], bgr[P + l * PL:P + (l + 1) * PL]]).contiguous() for l in range(lanes)]
-        lane_seeds = [seeds[l * PL:(l + 1) * PL].contiguous() for l in range(lanes)]
-        lane_out = [None] * lanes
-        torch.cuda.synchronize(dev)
+    # One set per batch in flight: its own frames (different content per context and rank: nothing is shared between the
+    # batches the timed loop hands out), seeds by GLOBAL pair index, outputs, record buffers, communicator.
+    class Slot:
+        pass
+    slots = []
+    uids = [None] * n_slots
+    if gather_mode == "rccl":
+        if rank == 0:
+            uids = [capi.comm_unique_id() for _ in range(n_slots)]
+        dist.broadcast_object_list(uids, src=0)               # 128 bytes per communicator through the torch store
+    for s in range(n_slots):
+        sl = Slot()
+        sl.bgr = make_frames(seed + 1000 * rank + 7919 * s, P, w, h, dev)
+        sl.seeds_np = shard.pair_seeds(seed, lo + s * world * P, hi + s * world * P)
+        sl.seeds = torch.from_numpy(sl.seeds_np.view(np.int32)).to(dev)
+        sl.out = Pipeline.alloc_outputs(torch, 2 * P, P, K, dev)
+        sl.rec = torch.zeros((P, words), dtype=torch.int32, device=dev) if multi else None
+        sl.gathered = torch.zeros((world * P, words), dtype=torch.int32, device=dev) if multi else None
+        sl.comm = capi.Comm(pipe.contexts[s], uids[s], world, rank) if gather_mode == "rccl" else None   # collective: same order on every rank
+        sl.used = 0
+        slots.append(sl)
+    rccl_ranks = slots[0].comm.info()[0] if gather_mode == "rccl" else None
+    torch.cuda.synchronize(dev)
 
-    def step():
-        nonlocal out, steps_done
-        if lanes > 1:
-            for l in range(lanes):
-                lane_out[l] = lane_ctx[l].frontend_pairs(lane_bgr[l], PL, K, ca, sa, pat, lane_seeds[l], H, thr, out=lane_out[l])
-            for l in range(lanes):
-                lane_ctx[l].synchronize()
-            out = {k: torch.cat([lo[k] for lo in lane_out]) for k in ("best", "F", "matches")}
-            # per-frame counts: a lane holds [its last frames, its current frames]; the batch layout is [all last, all current]
-            out["n"] = torch.cat([lo["n"][:PL] for lo in lane_out] + [lo["n"][PL:] for lo in lane_out])
-            return
-        out = ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
+    def step(k):
+        """One pass of the hot path over one batch: handed to the next context of the pipeline (returns once it is queued;
+        acquire waits for the batch that used the context n_slots steps ago)."""
+        sl = slots[k % n_slots]
+        t, c = pipe.acquire()
+        c.frontend_pairs(sl.bgr, P, K, ca, sa, pat, sl.seeds, H, thr, out=sl.out)
         if multi:
-            # the only exchange on the path: fixed-size per-pair result records to every rank
-            i = steps_done & 1
-            steps_done += 1
-            if gather_work[i] is not None:
-                gather_work[i].wait()   # a stream-side wait for the gather of two steps ago: long done
-            rec = ctx.pack_records(out["F"], out["best"], out["matches"], out=rec_buf[i])
-            if dist.get_backend() == "nccl":
-                gather_work[i] = dist.all_gather_into_tensor(gathered[i], rec, async_op=True)   # = shard.gather_records for world > 1
-            else:
-                gathered[i].copy_(shard.gather_records(rec.cpu(), world, n_items=world * P))
+            # the only exchange on the path: fixed-size per-pair result records to every rank, on this batch's own stream
+            c.pack_records(sl.out["F"], sl.out["best"], sl.out["matches"], out=sl.rec)
+            if sl.comm is not None:
+                sl.comm.gather(c, sl.rec, sl.gathered)
+        pipe.commit(t)
+        if multi and sl.comm is None:      # rehearsal through host memory (VSLAM_BENCH_GATHER=host)
+            pipe.wait(t)
+            sl.gathered.copy_(shard.gather_records(sl.rec.cpu(), world, n_items=world * P))
+        sl.used += 1
 
     if args.pmc_calibrate and rank == 0:
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
@@ -529,18 +529,24 @@ def main():
         ctx.synchronize()
         del a, b
 
-    for _ in range(args.warmup):
-        step()
+    # set-up, not steps: every context allocates its workspaces on its first batch (0.1 s each) and RCCL builds its channels on
+    # a communicator's first collective (seconds) -- one untimed pass per context keeps both out of the steps whatever W is
+    for k in range(n_slots):
+        step(k)
+    pipe.drain()
+    for k in range(args.warmup):
+        step(k)
+    pipe.drain()
+    for sl in slots:
+        sl.used = 0
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    for wk in gather_work:
-        if wk is not None:
-            wk.wait()   # the last steps' gathers belong to the timed region
+    for k in range(args.steps):
+        step(k)
+    pipe.drain()                 # every batch complete, its gather included (same stream, in front of the batch's event)
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
@@ -549,29 +555,44 @@ def main():
     rank_ms = None
     if multi:
         # the step time is the slowest rank's; every rank's own time travels along so that a scaling curve shows stragglers
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64)
         all_t = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(all_t, t)
         rank_ms = [float(x.item()) / args.steps * 1e3 for x in all_t]
         dt = max(float(x.item()) for x in all_t)
 
-    # sanity on the timed output: every pair produced keypoints, matches and an accepted model
-    host_out = {k: out[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
-    best = host_out["best"]
-    n_kp = host_out["n"]
-    # (VSLAM_BENCH_ALLOW_DEGENERATE: tools/ab_kernels.py times kernel variants that produce wrong results on purpose)
-    assert os.environ.get("VSLAM_BENCH_ALLOW_DEGENERATE") or (
-        (best[:, 0] >= 0).all() and (best[:, 3] >= 8).all() and (n_kp > K // 2).all()), "bench output degenerate"
+    # sanity on the timed output of every context that took part: each pair produced keypoints, matches and an accepted model
+    used = [sl for sl in slots if sl.used > 0]
+    for sl in used:
+        sl.host = {k: sl.out[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
+        # (VSLAM_BENCH_ALLOW_DEGENERATE: tools/ab_kernels.py times kernel variants that produce wrong results on purpose)
+        assert os.environ.get("VSLAM_BENCH_ALLOW_DEGENERATE") or (
+            (sl.host["best"][:, 0] >= 0).all() and (sl.host["best"][:, 3] >= 8).all() and (sl.host["n"] > K // 2).all()), "bench output degenerate"
+    gather_ok = None
+    if multi:   # what the gather delivered: this rank's block of every used context's last gather is this rank's records
+        gather_ok = all(torch.equal(sl.gathered[lo:hi], sl.rec) for sl in used)
+        flag = torch.tensor([1 if gather_ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_ok = bool(flag.item())
+    host_out = used[0].host
+    best = np.concatenate([sl.host["best"] for sl in used])
+    n_kp = np.concatenate([sl.host["n"] for sl in used])
 
     result = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        metric = "frame-pairs/sec (extract+match+RANSAC) @1280\u00d7720, 2k kp, 4096 hyp; 1/2/4/8 GPU"
+        metric = "frame-pairs/sec (extract+match+RANSAC) @1280×720, 2k kp, 4096 hyp; 1/2/4/8 GPU"
         try:   # BASELINE.json names the metric; use its string verbatim when the file is there
             with open(os.path.join(ROOT, "BASELINE.json")) as fh:
                 metric = json.load(fh).get("metric", metric)
         except OSError:
             pass
+        data_label = {"easy": "easy data: translated texture + one moving block, 13 % outlier matches",
+                      "hard": "SURVEY 8(d) data: rotation + parallax, sub-pixel resampling, 40-45 % outlier matches"}[args.data]
+        par = f"pairs sharded x{world}; {n_slots} batch{'es' if n_slots > 1 else ''} in flight per GPU (vslam_pipeline_*: {n_slots} context{'s' if n_slots > 1 else ''}, steps round-robin)"
+        if multi:
+            par += {"rccl": ", vslam_gather_records (RCCL all-gather of result records on each batch's stream)",
+                    "host": ", records gathered through host memory over gloo (rehearsal)"}[gather_mode]
         result = {
             "metric": metric,
             "value": world * P * args.steps / dt,
@@ -579,40 +600,107 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f32/f64",
-            "data": "synthetic" + ("" if args.data == "easy" else " (hard regime: rotation + parallax, sub-pixel resampling, 40-45 % outlier matches)"),
-            "config": {"workload": f"{args.workload}: {w}x{h}, {K} keypoints, {H} hypotheses, batch {P} pairs per GPU",
-                       "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}" + (f", {backend_label} all_gather of result records" if multi else "")},
+            "data": "synthetic (" + data_label + ")",
+            "config": {"workload": f"{args.workload}: {w}x{h}, {K} keypoints, {H} hypotheses, batch {P} pairs per GPU, {data_label}",
+                       "pairs_per_gpu": P, "batches_in_flight": n_slots, "parallelism": par},
+            "setup_steps": n_slots,   # untimed, before the warm-up: one batch per context (workspace allocation, RCCL channel set-up)
             "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
-            "workspace_bytes": ctx.workspace_bytes(),   # the context's grow-only workspaces for this batch shape (inputs / outputs not counted)
+            "workspace_bytes": pipe.workspace_bytes(),   # the contexts' grow-only workspaces for this batch shape (inputs / outputs not counted)
+            "workspace_bytes_per_context": ctx.workspace_bytes(),
         }
         if rank_ms:
             result["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms}
+        if multi:
+            result["record_gather"] = {"through": gather_mode, "rccl_ranks": rccl_ranks, "own_block_intact_on_every_rank": gather_ok,
+                                       "words_per_rank": P * words, "communicators_per_rank": n_slots if gather_mode == "rccl" else 0}
         if args.solver != "exact":
             result["solver"] = "gram-mfma: opt-in approximate 8-point solver, results NOT bit-exact with the reference path"
             result["metric"] += " [NON-PARITY SOLVER]"
 
-    # ---- separate pass: per-kernel durations with HIP events on the kernels' own stream
-    if rank == 0 and not args.no_profile_pass:
-        ctx.prof_enable(True)
-        ctx.prof_reset()
-        psteps = max(1, min(3, args.steps))
+    exit_code = 0
+    if multi and not gather_ok:
+        exit_code = 4
+
+    def timed_single(c, frames, pairs, kk, hh, sd, steps=10, out=None):
+        """ms per step of one batch after the other on ONE context."""
+        o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=out)
+        for _ in range(2):
+            o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=o)
+        c.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=o)
+        c.synchronize()
+        return (time.perf_counter() - t1) / steps * 1e3, o
+
+    def timed_in_flight(pp, frames, pairs, kk, hh, sd, outs, steps=24):
+        """ms per batch with len(outs) batches in flight on pipeline pp (same frames for every context: a sweep, not the headline)."""
+        n = len(outs)
+        for i in range(2 * n):
+            t, c = pp.acquire()
+            c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=outs[i % n])
+            pp.commit(t)
+        pp.drain()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            t, c = pp.acquire()
+            c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=outs[i % n])
+            pp.commit(t)
+        pp.drain()
+        return (time.perf_counter() - t1) / steps * 1e3
+
+    def profile_pass(c, frames, pairs, kk, hh, sd, psteps):
+        """Per-kernel durations with HIP events on the kernels' own stream; one context, one batch after the other, so that a
+        kernel's time is its own (with batches in flight the kernels of different batches share the chip)."""
+        c.prof_enable(True)
+        c.prof_reset()
         for _ in range(psteps):
-            ctx.frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=out)
-        rep = ctx.prof_report()
-        ctx.prof_enable(False)
-        M = float(best[:, 3].mean())
-        m_prelim = M   # inlier matches; preliminary matches are >= this
-        kernels = []
+            c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr)
+        rep = c.prof_report()
+        c.prof_enable(False)
+        return rep
+
+    def kernel_table(rep, psteps, ww, hh_, kk, hyp_, m_prelim, pairs):
         gray_fused = "bgr2gray_kernel" not in rep
+        ks = []
         for name, (ms, cnt) in rep.items():
             per_launch_ms = ms / max(cnt, 1)
-            alg = algorithmic_bytes(name, w, h, K, H, m_prelim, gray_fused) * P
-            kernels.append({"kernel": name, "ms_per_launch": per_launch_ms, "launches_per_step": cnt / psteps,
-                            "alg_bytes_per_launch": alg,
-                            "alg_GBps": alg / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
-        kernels.sort(key=lambda k: -k["ms_per_launch"] * k["launches_per_step"])
+            alg = algorithmic_bytes(name, ww, hh_, kk, hyp_, m_prelim, gray_fused) * pairs
+            ks.append({"kernel": name, "ms_per_launch": per_launch_ms, "launches_per_step": cnt / psteps,
+                       "alg_bytes_per_launch": alg,
+                       "alg_GBps": alg / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0})
+        ks.sort(key=lambda k: -k["ms_per_launch"] * k["launches_per_step"])
+        return ks
+
+    def units_of(kname, ww, hh_, hyp_, pairs, m_prelim, mean_kp):
+        """units of work one launch processes (M = inlier matches, a lower bound of the evaluated ones)"""
+        if kname == "min_eigen_kernel":
+            return 2.0 * ww * hh_ * pairs
+        if kname == "ransac_solve_kernel":
+            return float(hyp_) * pairs
+        return (hyp_ * m_prelim if kname.startswith("ransac") else mean_kp ** 2) * pairs
+
+    def match_view(mk, units, full_batch):
+        mv = arithmetic_view("match_knn2_kernel", units, mk["ms_per_launch"], full_batch)
+        return {"kernel": "match_knn2_kernel", "bound": "mfma", "achieved": mv["achieved"], "peak": mv["peak"],
+                "unit": "TOP/s (FP4, dense)", "frac": mv["frac"],
+                "frac_of_int8_peak": mv["achieved"] / INT8_MFMA_PEAK_TOPS,   # the form rounds 1-3 used
+                "traffic": pmc_traffic("match_knn2_kernel") if full_batch else None,
+                "avg_launch_ms": mk["ms_per_launch"],
+                "hbm": {"achieved": mk["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mk["alg_GBps"] / HBM_PEAK_GBS},
+                "arithmetic": mv}
+
+    # ---- separate pass: per-kernel durations with HIP events on the kernels' own stream (context 0, its own batch)
+    if rank == 0 and not args.no_profile_pass:
+        s0 = slots[0]
+        psteps = max(1, min(3, args.steps))
+        rep = profile_pass(ctx, s0.bgr, P, K, H, s0.seeds, psteps)
+        M = float(best[:, 3].mean())
+        m_prelim = M   # inlier matches; preliminary matches are >= this
+        kernels = kernel_table(rep, psteps, w, h, K, H, m_prelim, P)
         top = kernels[0]
         full_batch = args.workload == "C3" and P == WORKLOADS["C3"][4]   # the shape the committed counter passes ran
+        clamped = []
         if full_batch:   # every kernel of the step against the vector-pipe and HBM ceilings, where this build's counter rows exist
             for k in kernels:
                 sq = sq_counters(k["kernel"])
@@ -620,7 +708,14 @@ def main():
                 if sq and t_ > 0:
                     k["valu_issue_frac"] = sq[0] * sq[1] / t_ / 1e9 / VALU_PEAK_GINST
                     if sq[2] > 0:
-                        k["valu_busy_frac"] = sq[0] * sq[2] / (SIMDS * t_ * CLOCK_GHZ * 1e9)
+                        # counters per wave come from the committed profile (a property of the build), the launch time from this
+                        # run at a nominal 2.4 GHz: the quotient can come out a few per cent above 1 for a kernel that keeps the
+                        # pipe full.  A fraction is clamped to 1 and the raw quotient kept beside it.
+                        raw = sq[0] * sq[2] / (SIMDS * t_ * CLOCK_GHZ * 1e9)
+                        k["valu_busy_frac"] = min(1.0, raw)
+                        if raw > 1.0:
+                            k["valu_busy_frac_unclamped"] = raw
+                            clamped.append(k["kernel"])
                 tr = pmc_traffic(k["kernel"])
                 if tr is not None:
                     k["hbm_traffic_bytes_per_launch"] = tr
@@ -628,100 +723,108 @@ def main():
         traffic = pmc_traffic(top["kernel"]) if full_batch else None
         hbm_view = {"achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS,
                     "alg_bytes_per_launch": top["alg_bytes_per_launch"]}
-
-        def units_of(kname):   # units of work one launch processes (M = inlier matches, a lower bound of the evaluated ones)
-            if kname == "min_eigen_kernel":
-                return 2.0 * w * h * P
-            if kname == "ransac_solve_kernel":
-                return float(H) * P
-            return (H * m_prelim if kname.startswith("ransac") else float(n_kp.mean()) ** 2) * P
-
+        mean_kp = float(n_kp.mean())
         by_name = {k["kernel"]: k for k in kernels}
-        av = arithmetic_view(top["kernel"], units_of(top["kernel"]), top["ms_per_launch"], full_batch)
-        # The binding ceiling of the dominant kernel.  Both candidates for that place (ransac_solve, min_eigen) are held by
-        # the vector pipe, not by bandwidth: the headline fraction is the vector-instruction issue rate --
-        # waves x instructions per wave (committed SQ counters of this build) / this run's launch time, against the chip's
-        # 1228.8 G wave-instructions/s -- with the pipe-occupancy, flop and HBM views beside it.  Without counter rows
-        # of this build (other shapes, changed sources) only the HBM view can be formed and is what is reported.
+        av = arithmetic_view(top["kernel"], units_of(top["kernel"], w, h, H, P, m_prelim, mean_kp), top["ms_per_launch"], full_batch)
+        if av and "valu_busy" in av and av["valu_busy"]["frac"] > 1.0:
+            av["valu_busy"]["frac_unclamped"] = av["valu_busy"]["frac"]
+            av["valu_busy"]["frac"] = 1.0
+        # The dominant kernel (ransac_solve or min_eigen) is held by the vector pipe, not by bandwidth.  Two
+        # fractions at the top level: `frac` = the vector-instruction issue rate -- waves x instructions per wave (committed
+        # SQ counters of this build) / this run's launch time, against the chip's 1228.8 G wave-instructions/s: how busy the
+        # binding unit is -- and `frac_algorithmic` = SURVEY 8(d)'s quantity: algorithmic flops per unit x units per launch /
+        # launch time against the FP32 vector peak: how much useful work per second.  The HBM view is beside them.
+        flops = {k: av[k] for k in ("unit_of_work", "units_per_launch", "ops_per_unit", "op_kind", "achieved", "peak", "unit", "frac") if k in av} if av else None
         if av and "valu_issue" in av:
             vi = av["valu_issue"]
             result["roofline"] = {"kernel": top["kernel"], "bound": "valu", "achieved": vi["achieved"], "peak": vi["peak"],
-                                  "unit": vi["unit"], "frac": vi["frac"], "traffic": traffic, "avg_launch_ms": top["ms_per_launch"],
+                                  "unit": vi["unit"], "frac": vi["frac"],
+                                  "frac_algorithmic": flops["frac"] if flops else None,
+                                  "traffic": traffic, "avg_launch_ms": top["ms_per_launch"],
                                   "how": f"{vi['waves_per_launch']:.0f} waves x {vi['valu_insts_per_wave']:.0f} VALU instructions per wave "
                                          f"({vi['source']}) / {top['ms_per_launch']:.4f} ms / 1e6 = achieved; peak = 1024 SIMDs x 2.4 GHz / 2 "
-                                         "cycles per wave instruction",
-                                  "valu_busy": av.get("valu_busy"), "hbm": hbm_view,
-                                  "flops": {k: av[k] for k in ("unit_of_work", "units_per_launch", "ops_per_unit", "op_kind", "achieved",
-                                                               "peak", "unit", "frac") if k in av} or None}
+                                         "cycles per wave instruction; frac_algorithmic = flops.frac (counted flop per hypothesis x "
+                                         "hypotheses per launch / launch time / 157.3 TFLOP/s)",
+                                  "valu_busy": av.get("valu_busy"), "hbm": hbm_view, "flops": flops or None}
         else:
             result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                                  "avg_launch_ms": top["ms_per_launch"],
-                                  "note": "no counter rows of this build and shape under profiles/: only the bandwidth view can be formed; "
-                                          "the kernel is bound by its vector arithmetic (DESIGN.md 5)"}
+                                  "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS,
+                                  "frac_algorithmic": flops["frac"] if flops else None,
+                                  "traffic": traffic, "avg_launch_ms": top["ms_per_launch"],
+                                  "note": "no counter rows of this build and shape under profiles/: only the bandwidth view and the "
+                                          "algorithmic flop fraction can be formed; the kernel is bound by its vector arithmetic (DESIGN.md 5)"}
             if av:
                 result["roofline"]["arithmetic"] = av
+        result["roofline"]["measured"] = ("per-kernel times: HIP events on the kernels' own stream, one context, one batch after the other "
+                                          "(with batches in flight the kernels of different batches share the chip)")
         if "match_knn2_kernel" in by_name:   # north_star names the match kernel: always report it
-            mk = by_name["match_knn2_kernel"]
-            mv = arithmetic_view("match_knn2_kernel", units_of("match_knn2_kernel"), mk["ms_per_launch"], full_batch)
-            result["roofline_match"] = {"kernel": "match_knn2_kernel", "bound": "mfma", "achieved": mv["achieved"], "peak": mv["peak"],
-                                        "unit": "TOP/s (FP4, dense)", "frac": mv["frac"],
-                                        "frac_of_int8_peak": mv["achieved"] / INT8_MFMA_PEAK_TOPS,   # the form rounds 1-3 used
-                                        "traffic": pmc_traffic("match_knn2_kernel") if full_batch else None,
-                                        "avg_launch_ms": mk["ms_per_launch"],
-                                        "hbm": {"achieved": mk["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mk["alg_GBps"] / HBM_PEAK_GBS},
-                                        "arithmetic": mv}
+            result["roofline_match"] = match_view(by_name["match_knn2_kernel"],
+                                                  units_of("match_knn2_kernel", w, h, H, P, m_prelim, mean_kp), full_batch)
         # the HBM-class (stencil) kernel that moves the most bytes, for the bandwidth view of the step
         stencil = [k for k in kernels if k["kernel"] in ("min_eigen_kernel", "gaussian7_kernel", "bgr2gray_kernel")]
         if stencil:
             st = max(stencil, key=lambda k: k["alg_bytes_per_launch"])
             result["roofline_stencil"] = {"kernel": st["kernel"], "bound": "hbm", "achieved": st["alg_GBps"],
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["alg_GBps"] / HBM_PEAK_GBS,
-                                          "traffic": pmc_traffic(st["kernel"]) if (args.workload == "C3" and P == WORKLOADS["C3"][4]) else None,
+                                          "traffic": pmc_traffic(st["kernel"]) if full_batch else None,
                                           "avg_launch_ms": st["ms_per_launch"]}
         result["counter_profiles"] = {"tag": PROFILE_TAG, "match_this_build": counters_current(),
                                       "dominant_kernel_rows_match": counters_current(top["kernel"]),
+                                      "valu_busy_clamped_to_1": clamped,
                                       "note": "traffic / valu_issue / valu_busy come from the committed rocprofv3 PMC summaries and are "
                                               "omitted (null) for a kernel whose source file, or the shared headers, changed since"}
         result["kernels"] = kernels
         result["profile_pass_ms_per_step"] = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels)
 
-    # ---- the oracle on the timed batch's own bytes: parity of what was timed, and the CPU baseline, in one go
-    exit_code = 0
+    # ---- the oracle on the timed batches' own bytes: parity of what was timed -- a share from EVERY context -- and the CPU baseline
     if rank == 0:
-        n_cpu = min(P, args.cpu_pairs if (world == 1 and args.cpu_pairs > 0) else 4)
-        fa = bgr[:n_cpu].cpu().numpy()
-        fb = bgr[P:P + n_cpu].cpu().numpy()
-        pair_seeds = shard.pair_seeds(seed, lo, hi)[:n_cpu]
-        base, parity = oracle_on_frames(fa, fb, pair_seeds, K, H, thr, host_out, 0, args.workload + ", " + args.data + " data")
-        result["parity_in_bench"] = parity
+        n_cpu = min(P * len(used), args.cpu_pairs if (world == 1 and args.cpu_pairs > 0) else 4)
+        share = [n_cpu // len(used) + (1 if i < n_cpu % len(used) else 0) for i in range(len(used))]
+        pairs_done, secs, bad, per_ctx = 0, 0.0, [], []
+        for i, (sl, n_chk) in enumerate(zip(used, share)):
+            if n_chk == 0:
+                continue
+            base, parity = oracle_on_frames(sl.bgr[:n_chk].cpu().numpy(), sl.bgr[P:P + n_chk].cpu().numpy(), sl.seeds_np[:n_chk], K, H, thr,
+                                            sl.host, 0, args.workload + ", " + args.data + " data")
+            pairs_done += n_chk
+            secs += n_chk / base["value"]
+            per_ctx.append({"context": slots.index(sl), "pairs": n_chk, "bit_exact": parity["bit_exact"]})
+            bad += [(slots.index(sl), g) for g in parity.get("mismatching_pairs", [])]
+        result["parity_in_bench"] = {"pairs": pairs_done, "bit_exact": not bad, "per_context": per_ctx,
+                                     "checked": "keypoint counts, inlier-match lists and F (as uint32) of the timed steps' output vs the oracle "
+                                                "on the same bytes, a share of the pairs from the last batch of every context"}
+        if bad:
+            result["parity_in_bench"]["mismatching_context_pair"] = bad[:16]
+            exit_code = 3
         if world == 1 and args.cpu_pairs > 0:
-            result["cpu_baseline"] = base
+            result["cpu_baseline"] = {"value": pairs_done / secs, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                                      "sample": f"{pairs_done} pairs of the timed batches themselves ({args.workload}, {args.data} data: {w}x{h}, {K} kp, "
+                                                f"{H} hyp) copied back from the device, oracle single thread, {secs:.1f} s"}
             if args.cpu_all_cores_pairs > 0:
                 result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload, args.cpu_all_cores_pairs, seed)
-        if not parity["bit_exact"]:
-            exit_code = 3
-        del fa, fb
 
-    # ---- secondary measurements (rank 0, one GPU): the harder data regime, the full-evaluation worst case, the other workloads
-    if rank == 0 and world == 1 and not args.no_extras and lanes == 1:
-        def timed(c, frames, pairs, kk, hh, sd, steps=10):
-            o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr)
-            for _ in range(2):
-                o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=o)
-            c.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(steps):
-                o = c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=o)
-            c.synchronize()
-            return (time.perf_counter() - t1) / steps * 1e3, o
+    # ---- secondary measurements (rank 0, one GPU): one context, the in-flight sweep, the other data regime, the
+    # full-evaluation worst case, the other workloads with their own per-kernel pass
+    if rank == 0 and world == 1 and not args.no_extras:
+        s0 = slots[0]
+        ms1, _ = timed_single(ctx, s0.bgr, P, K, H, s0.seeds, out=s0.out)
+        result["single_context"] = {"ms_per_step": ms1, "frame_pairs_per_s": P / ms1 * 1e3,
+                                    "what": "one batch after the other on one context (the headline arrangement of rounds 1-4), same data"}
+        sweep = {}
+        for d in (1, 2, 3, 4):
+            pp = pipe if d == n_slots else Pipeline(local_rank, d)
+            outs = [sl.out for sl in slots[:d]] + [Pipeline.alloc_outputs(torch, 2 * P, P, K, dev) for _ in range(max(0, d - n_slots))]
+            ms = timed_in_flight(pp, s0.bgr, P, K, H, s0.seeds, outs[:d])
+            same = all(torch.equal(o[k], outs[0][k]) for o in outs[1:d] for k in ("best", "F", "n"))
+            sweep[str(d)] = {"contexts": d, "ms_per_batch": ms, "frame_pairs_per_s": P / ms * 1e3, "outputs_identical_across_contexts": bool(same)}
+            if pp is not pipe:
+                pp.close()
+            del outs
+            torch.cuda.empty_cache()
+        result["in_flight_sweep"] = sweep
 
         def kernel_ms(c, frames, pairs, kk, hh, sd, names):
-            c.prof_enable(True)
-            c.prof_reset()
-            c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr)
-            rep = c.prof_report()
-            c.prof_enable(False)
+            rep = profile_pass(c, frames, pairs, kk, hh, sd, 1)
             return {nm: rep[nm][0] / max(rep[nm][1], 1) for nm in names if nm in rep}
 
         scoring = ("ransac_rank_kernel", "ransac_screen_kernel", "ransac_cand_kernel", "ransac_count_kernel",
@@ -729,22 +832,22 @@ def main():
         regimes = {}
         other = "hard" if args.data == "easy" else "easy"
         for kind in (args.data, other):
-            frames = bgr if kind == args.data else (synth.frames_torch if kind == "easy" else synth.frames_torch_hard)(seed, P, w, h, dev)
-            ms, o = timed(ctx, frames, P, K, H, seeds)
+            frames = s0.bgr if kind == args.data else (synth.frames_torch if kind == "easy" else synth.frames_torch_hard)(seed, P, w, h, dev)
+            ms, o = timed_single(ctx, frames, P, K, H, s0.seeds)
             ho = {k: o[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
-            entry = {"ms_per_step": ms, "frame_pairs_per_s": P / ms * 1e3, "mean_keypoints": float(ho["n"].mean()),
+            entry = {"ms_per_step": ms, "frame_pairs_per_s": P / ms * 1e3, "contexts": 1, "mean_keypoints": float(ho["n"].mean()),
                      "mean_inlier_matches": float(ho["best"][:, 3].mean()),
-                     "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, seeds, scoring)}
+                     "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring)}
             # worst case of the data-dependent scoring kernels: every (hypothesis, match) pair evaluated, every sum formed
             ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, True)
-            ms_all, _ = timed(ctx, frames, P, K, H, seeds, steps=5)
-            entry["full_evaluation"] = {"ms_per_step": ms_all, "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, seeds, scoring),
+            ms_all, _ = timed_single(ctx, frames, P, K, H, s0.seeds, steps=5)
+            entry["full_evaluation"] = {"ms_per_step": ms_all, "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring),
                                         "what": "VSLAM_OPT_RANSAC_ALL_SUMS: no bail-out, no screen: the count and residual sum of every hypothesis"}
             ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
-            if kind != args.data:   # the timed batch itself was checked above; check this regime's output too
+            if kind != args.data:   # the timed batches were checked above; check this regime's output too
                 nchk = min(P, 24)
-                _, par = oracle_on_frames(frames[:nchk].cpu().numpy(), frames[P:P + nchk].cpu().numpy(),
-                                          shard.pair_seeds(seed, lo, hi)[:nchk], K, H, thr, ho, 0, args.workload + ", " + kind + " data")
+                _, par = oracle_on_frames(frames[:nchk].cpu().numpy(), frames[P:P + nchk].cpu().numpy(), s0.seeds_np[:nchk], K, H, thr, ho, 0,
+                                          args.workload + ", " + kind + " data")
                 entry["parity_in_bench"] = par
                 if not par["bit_exact"]:
                     exit_code = 3
@@ -756,53 +859,44 @@ def main():
             if wl == args.workload:
                 continue
             w2, h2, K2, H2, P2 = WORKLOADS[wl]
-            c2 = Context(local_rank)
-            f2 = synth.frames_torch(0x5EED0000 + sorted(WORKLOADS).index(wl), P2, w2, h2, dev)
-            s2 = torch.from_numpy(shard.pair_seeds(0x5EED0000 + sorted(WORKLOADS).index(wl), 0, P2).view(np.int32)).to(dev)
-            ms2, o2 = timed(c2, f2, P2, K2, H2, s2)
-            b2 = o2["best"].cpu().numpy()
-            others[wl] = {"workload": f"{w2}x{h2}, {K2} keypoints, {H2} hypotheses, batch {P2} pairs", "ms_per_step": ms2,
-                          "workspace_bytes": c2.workspace_bytes(),
-                          "frame_pairs_per_s": P2 / ms2 * 1e3, "steps": 10, "mean_inlier_matches": float(b2[:, 3].mean()),
-                          "degenerate": bool((b2[:, 0] < 0).any())}
-            c2.close()
-            del f2, o2, c2
+            sd2 = 0x5EED0000 + sorted(WORKLOADS).index(wl)
+            p2 = Pipeline(local_rank, n_slots)
+            f2 = make_frames(sd2, P2, w2, h2, dev)
+            s2 = torch.from_numpy(shard.pair_seeds(sd2, 0, P2).view(np.int32)).to(dev)
+            o2 = [Pipeline.alloc_outputs(torch, 2 * P2, P2, K2, dev) for _ in range(n_slots)]
+            ms2 = timed_in_flight(p2, f2, P2, K2, H2, s2, o2, steps=12)
+            ms2_single, _ = timed_single(p2.contexts[0], f2, P2, K2, H2, s2, steps=6, out=o2[0])
+            b2 = o2[0]["best"].cpu().numpy()
+            nk2 = float(o2[0]["n"].float().mean().item())
+            m2 = float(b2[:, 3].mean())
+            rep2 = profile_pass(p2.contexts[0], f2, P2, K2, H2, s2, 1)
+            kt2 = kernel_table(rep2, 1, w2, h2, K2, H2, m2, P2)
+            entry = {"workload": f"{w2}x{h2}, {K2} keypoints, {H2} hypotheses, batch {P2} pairs, {args.data} data", "ms_per_step": ms2,
+                     "frame_pairs_per_s": P2 / ms2 * 1e3, "batches_in_flight": n_slots,
+                     "single_context": {"ms_per_step": ms2_single, "frame_pairs_per_s": P2 / ms2_single * 1e3},
+                     "workspace_bytes_per_context": p2.contexts[0].workspace_bytes(), "steps": 12, "mean_inlier_matches": m2,
+                     "degenerate": bool((b2[:, 0] < 0).any()),
+                     "kernels_ms_per_launch": {k["kernel"]: round(k["ms_per_launch"], 5) for k in kt2}}
+            by2 = {k["kernel"]: k for k in kt2}
+            top2 = kt2[0]
+            av2 = arithmetic_view(top2["kernel"], units_of(top2["kernel"], w2, h2, H2, P2, m2, nk2), top2["ms_per_launch"], False)
+            entry["dominant_kernel"] = {"kernel": top2["kernel"], "ms_per_launch": top2["ms_per_launch"],
+                                        "frac_algorithmic": av2["frac"] if av2 and "frac" in av2 else None,
+                                        "hbm_frac_algorithmic": top2["alg_GBps"] / HBM_PEAK_GBS}
+            if "match_knn2_kernel" in by2:
+                entry["roofline_match"] = match_view(by2["match_knn2_kernel"], units_of("match_knn2_kernel", w2, h2, H2, P2, m2, nk2), False)
+            others[wl] = entry
+            p2.close()
+            del f2, o2, p2
             torch.cuda.empty_cache()
         result["other_workloads"] = others
-        # Batches in flight: the entry points are stream-ordered, so a caller with a queue of batches can hand the next one
-        # to a second (third) context while the first is still running; the latency-bound stages of one batch then overlap
-        # the arithmetic of another.  Not the headline (that is one batch after the other on one context): reported beside it.
-        pipe = {}
-        for n_ctx in (2, 3):
-            cs = [Context(local_rank, use_torch_stream=False) for _ in range(n_ctx)]
-            os_ = [None] * n_ctx
-            for i in range(2 * n_ctx):
-                os_[i % n_ctx] = cs[i % n_ctx].frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=os_[i % n_ctx])
-            torch.cuda.synchronize(dev)
-            nb = 24
-            t1 = time.perf_counter()
-            for i in range(nb):
-                os_[i % n_ctx] = cs[i % n_ctx].frontend_pairs(bgr, P, K, ca, sa, pat, seeds, H, thr, out=os_[i % n_ctx])
-            for c in cs:
-                c.synchronize()
-            ms = (time.perf_counter() - t1) / nb * 1e3
-            same = True
-            for o in os_:
-                ho = {k: o[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
-                same = same and all(np.array_equal(ho[k], host_out[k]) for k in ("best", "n", "F"))
-                same = same and all(np.array_equal(ho["matches"][p_, :host_out["best"][p_, 3]], host_out["matches"][p_, :host_out["best"][p_, 3]])
-                                    for p_ in range(P))
-            pipe[str(n_ctx)] = {"contexts": n_ctx, "batches": nb, "ms_per_batch": ms, "frame_pairs_per_s": P / ms * 1e3,
-                                "outputs_equal_the_timed_step": bool(same)}
-            for c in cs:
-                c.close()
-            del cs, os_
-            torch.cuda.empty_cache()
-        result["batches_in_flight"] = pipe
     if multi:
         dist.barrier()
+        for sl in slots:
+            if sl.comm is not None:
+                sl.comm.close()
         dist.destroy_process_group()
-    ctx.close()
+    pipe.close()
     sys.stdout.flush()
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())

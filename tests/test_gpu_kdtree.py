@@ -139,3 +139,34 @@ def test_nearest_batch_matches_oracle(ctx, oracle):
             assert n_none == B * Q          # strict '<' against 0 never holds
         if max_d2 == 0.75:
             assert 0 < n_none < B * Q
+
+
+@pytest.mark.parametrize("all_sums", [False, True])
+def test_trees_of_the_batched_front_end_for_every_fork_point(ctx, oracle, all_sums):
+    """VSLAM_OPT_TREE_FORK moves the k-d build (an output nobody reads) to another point of the matching stages; point 4
+    lies in a branch that VSLAM_OPT_RANSAC_ALL_SUMS does not take, where the build used to be dropped silently (advisor,
+    round 4).  Every fork point, both scoring modes, pairs and sequence form: the trees are the oracle's."""
+    from vslam_amd import synth
+    w, h, maxc, hyp = 320, 240, 300, 64
+    bgr_np = synth.frames_numpy(4242, 3, w, h)
+    bgr = torch.from_numpy(bgr_np).cuda()
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    seeds = torch.arange(3, dtype=torch.int32).cuda()
+    ref = [oracle.extract_features(f, maxc, ca, sa, pat) for f in bgr_np]
+    ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, all_sums)
+    try:
+        for fork in (-1, 0, 1, 2, 3, 4):
+            ctx.set_option(ctx.OPT_TREE_FORK, fork)
+            for form in ("pairs", "sequence"):
+                if form == "pairs":
+                    out = ctx.frontend_pairs(bgr, 3, maxc, ca, sa, None, seeds, hyp, 10.0)
+                else:
+                    out = ctx.frontend_sequence(bgr, maxc, ca, sa, None, torch.arange(5, dtype=torch.int32).cuda(), hyp, 10.0)
+                ctx.synchronize()
+                nodes, n = out["nodes"].cpu().numpy(), out["n"].cpu().numpy()
+                for f, r in enumerate(ref):
+                    assert n[f] == r["n"] and np.array_equal(nodes[f, :r["n"]], r["nodes"]), (fork, form, f)
+    finally:
+        ctx.set_option(ctx.OPT_TREE_FORK, -1)
+        ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)

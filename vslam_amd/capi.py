@@ -655,3 +655,50 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+
+def comm_unique_id(lib=None):
+    """128 bytes from vslam_comm_unique_id (rank 0 makes it, every rank passes the same bytes to Comm)."""
+    lib = lib or load_library()
+    uid = (C.c_ubyte * 128)()
+    rc = lib.vslam_comm_unique_id(uid)
+    if rc != OK:
+        raise VslamError(f"{ERRORS.get(rc, rc)}: vslam_comm_unique_id (is librccl.so there?)")
+    return bytes(uid)
+
+
+class Comm:
+    """ctypes stub of vslam_comm_* / vslam_gather_records*: the library's own RCCL communicator, made on a context's device."""
+
+    def __init__(self, ctx, uid, world, rank):
+        self.lib = ctx.lib
+        self.world, self.rank = world, rank
+        self.handle = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        ctx._check(self.lib.vslam_comm_create(ctx.handle, buf, C.c_int(world), C.c_int(rank), C.byref(self.handle)))
+
+    def info(self):
+        w, r = C.c_int(-1), C.c_int(-1)
+        rc = self.lib.vslam_comm_info(self.handle, C.byref(w), C.byref(r))
+        if rc != OK:
+            raise VslamError(f"{ERRORS.get(rc, rc)}: vslam_comm_info")
+        return w.value, r.value
+
+    def gather(self, ctx, rec, out):
+        """Equal blocks: ncclAllGather of rec (this rank's records) into out (world x rec), on ctx's stream."""
+        ctx._check(self.lib.vslam_gather_records(ctx.handle, self.handle, _ptr(rec), C.c_size_t(rec.numel()), _ptr(out)))
+
+    def gather_v(self, ctx, rec, words, out, root=-1):
+        arr = (C.c_size_t * len(words))(*words)
+        ctx._check(self.lib.vslam_gather_records_v(ctx.handle, self.handle, _ptr(rec), arr, C.c_int(root), _ptr(out)))
+
+    def close(self):
+        if self.handle:
+            self.lib.vslam_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

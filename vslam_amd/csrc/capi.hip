@@ -582,10 +582,16 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     {
         hipStream_t main_stream = ctx->stream;
         if (overlap) ctx->stream = ctx->aux_stream;
-        if (overlap && width % 4 == 0)   // the table the description stage will want: off the main stream's critical path
+        // The table the description stage will want: off the main stream's critical path.  It sits in FRONT of the blur on
+        // purpose.  The 8-wave kernel finds every CU held by the selection's 1024-thread workgroups and waits about 65 us
+        // for a slot (profiles/r04_step_timeline.txt), which is what lets the selection take its places before the blur's
+        // waves arrive: queued at the head of the auxiliary stream instead (round 5, tools/ab_lib.py, same process,
+        // alternating) the blur starts at the fork and the step is unchanged with one batch in flight (2.950 vs 2.950 ms) and
+        // SLOWER with three (2.764 -> 2.800 ms on the hard data, 2.604 -> 2.664 on the easy data).
+        if (overlap && width % 4 == 0)
             rc = vs_launch_rbrief_rotate(ctx, params->d_pattern, params->cos_a, params->sin_a);
         if (rc == VSLAM_OK)
-        rc = vs_launch_gaussian7(ctx, gray, frames, width, height, blur);                                // ORB::compute
+            rc = vs_launch_gaussian7(ctx, gray, frames, width, height, blur);                            // ORB::compute
         ctx->stream = main_stream;
         if (rc) return rc;
         if (overlap) {
@@ -741,6 +747,9 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     rc = vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * half, d_desc + VSLAM_DESC_BYTES * half,
                               d_n + pairs, pairs, kp_stride, d_seeds, hyp, threshold, d_matches, d_best,
                               d_F, nullptr);
+    // a fork point the matching stages never passed (point 4 lies in the branch VSLAM_OPT_RANSAC_ALL_SUMS does not take): the
+    // build still has to run, or the join below waits on an event of an earlier call and d_nodes stays unwritten
+    if (rc == VSLAM_OK && overlap && ctx->aux_job) rc = vs_aux_job_point(ctx, ctx->aux_job_at);
     if (overlap) VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return rc;
 }
@@ -796,6 +805,7 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
     const size_t one = (size_t)kp_stride;
     rc = vslam_match_features(ctx, d_xy, d_desc, d_n, d_xy + 2 * one, d_desc + VSLAM_DESC_BYTES * one, d_n + 1,
                               frames - 1, kp_stride, d_seeds, hyp, threshold, d_matches, d_best, d_F, nullptr);
+    if (rc == VSLAM_OK && overlap && ctx->aux_job) rc = vs_aux_job_point(ctx, ctx->aux_job_at);   // see vslam_frontend_pairs
     if (overlap) VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return rc;
 }
