@@ -75,6 +75,7 @@ def test_pipeline_equals_single_context_and_oracle(ctx, batches, reference, n_ct
             n = bgr.shape[0] // 2
             o = capi.Pipeline.alloc_outputs(torch, 2 * n, n, MAXC, bgr.device)
             r = torch.zeros((n, 13 + MAXC), dtype=torch.int32, device=bgr.device)
+            torch.cuda.synchronize()       # the pipeline's streams do not wait for torch's fill kernels
             tickets.append(pipe.submit_pairs(bgr, n, MAXC, ca, sa, pat if len(outs) % 2 else None, seeds, HYP, THR, o, records=r))
             outs.append(o)
             recs.append(r)
@@ -123,6 +124,7 @@ def test_an_error_in_one_batch_does_not_poison_the_next(oracle):
     pipe = capi.Pipeline(0, 2)
     try:
         outs = [capi.Pipeline.alloc_outputs(torch, 8, 4, maxc, bgr.device) for _ in range(5)]
+        torch.cuda.synchronize()
         t0 = pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[0])
         t1, c1 = pipe.acquire()                                # slot 1, by hand: the bound applies to this batch only
         c1.set_option(c1.OPT_CORNER_LIST_CAP, 40)
@@ -186,6 +188,7 @@ def test_pipeline_sequence_form(ctx):
             f = clip.shape[0]
             seeds = torch.arange(10 * i, 10 * i + f - 1, dtype=torch.int32).cuda()
             o = capi.Pipeline.alloc_outputs(torch, f, f - 1, MAXC, clip.device)
+            torch.cuda.synchronize()
             pipe.submit_sequence(clip, MAXC, ca, sa, pat, seeds, HYP, THR, o)
             outs.append((clip, seeds, o))
         pipe.drain()

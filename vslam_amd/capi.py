@@ -75,9 +75,16 @@ class Context:
         if rc != OK:
             raise VslamError(f"vslam_ctx_create failed: {ERRORS.get(rc, rc)} (no HIP device? there is no CPU fallback)")
         self.device = torch.device("cuda", device)
+        self.own_stream = not use_torch_stream
         if use_torch_stream:
             s = torch.cuda.current_stream(self.device)
             self._check(self.lib.vslam_ctx_set_stream(self.handle, C.c_void_p(s.cuda_stream)))
+
+    def _ready(self):
+        """Tensors torch has just filled (kernels on torch's stream) are handed to a context that runs on a stream of its own,
+        which does not wait for torch's: wait here, or a fill can land on top of the results."""
+        if getattr(self, "own_stream", True):
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def close(self):
         if self.handle:
@@ -327,6 +334,7 @@ class Context:
                        nodes=torch.full((F, K), -1, dtype=torch.int32, device=dev),
                        n=torch.zeros((F,), dtype=torch.int32, device=dev),
                        n_detected=torch.zeros((F,), dtype=torch.int32, device=dev))
+            self._ready()
         p = self._params(max_corners, cos_a, sin_a, pattern)
         self._check(self.lib.vslam_extract_features(self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H),
                                                     C.c_int(row_bytes), C.byref(p), C.c_int(K), _ptr(out["xy"]),
@@ -425,6 +433,7 @@ class Context:
                        matches=torch.zeros((pairs, K, 2), dtype=torch.int32, device=dev),
                        best=torch.zeros((pairs, 4), dtype=torch.int32, device=dev),
                        F=torch.zeros((pairs, 9), dtype=torch.float32, device=dev))
+            self._ready()
         p = self._params(max_corners, cos_a, sin_a, pattern)
         self._check(self.lib.vslam_frontend_pairs(
             self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K),
@@ -456,6 +465,7 @@ class Context:
                        matches=torch.zeros((F - 1, K, 2), dtype=torch.int32, device=dev),
                        best=torch.zeros((F - 1, 4), dtype=torch.int32, device=dev),
                        F=torch.zeros((F - 1, 9), dtype=torch.float32, device=dev))
+            self._ready()
         p = self._params(max_corners, cos_a, sin_a, pattern)
         self._check(self.lib.vslam_frontend_sequence(
             self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K),
@@ -544,7 +554,9 @@ class Pipeline:
     """ctypes stub of vslam_pipeline_* (include/vslam_amd.h): k contexts on one device, batches handed to them round-robin.
 
     `acquire()` returns (ticket, Context view of the slot's vslam_ctx); enqueue the batch on it, then `commit(ticket)`.
-    `submit_pairs` is the one-call form.  Output tensors are the caller's: keep one set per batch in flight."""
+    `submit_pairs` is the one-call form.  Output tensors are the caller's: keep one set per batch in flight, alive until the
+    batch has been waited for, and complete on torch's side before they are handed over (the contexts run on streams of their
+    own that do not wait for torch's: `alloc_outputs` synchronizes, inputs made with torch kernels need the same)."""
 
     class _Borrowed(Context):
         """A Context object over a vslam_ctx the pipeline owns (never destroyed from here)."""
@@ -615,6 +627,15 @@ class Pipeline:
 
     @staticmethod
     def alloc_outputs(torch, frames, pairs, K, device):
+        """One set of output tensors, READY for a context's own stream: torch fills them with kernels on ITS stream, which the
+        pipeline's streams do not wait for -- without the synchronize below a fill can land after the batch has written its
+        results (seen: keypoint counts reading 0 with five batches in flight)."""
+        out = Pipeline._alloc_outputs(torch, frames, pairs, K, device)
+        torch.cuda.current_stream(device).synchronize()
+        return out
+
+    @staticmethod
+    def _alloc_outputs(torch, frames, pairs, K, device):
         return dict(xy=torch.zeros((frames, K, 2), dtype=torch.float32, device=device),
                     desc=torch.zeros((frames, K, 32), dtype=torch.uint8, device=device),
                     nodes=torch.full((frames, K), -1, dtype=torch.int32, device=device),

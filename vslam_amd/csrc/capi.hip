@@ -60,7 +60,7 @@ int vs_aux_job_point(vslam_ctx *ctx, int point) {
 // is the longer one, 1.30 against 1.08 ms) 15.26 in front, 15.31 behind.  So: behind the matcher up to 2048 keypoint slots.
 static int vs_defer_tree_build(vslam_ctx *ctx, const float *d_xy, const int32_t *d_n, int frames, int kp_stride, int32_t *d_nodes) {
     ctx->aux_job = [=]() { return vs_launch_kdtree_build(ctx, d_xy, d_n, frames, kp_stride, d_nodes); };
-    ctx->aux_job_at = ctx->tree_fork >= 0 ? ctx->tree_fork : (kp_stride <= 2048 ? 1 : 0);
+    ctx->aux_job_at = ctx->tree_fork >= 0 ? ctx->tree_fork : (ctx->call_small ? 0 : (kp_stride <= 2048 ? 1 : 0));
     return vs_aux_job_point(ctx, 0);
 }
 struct VsAuxGuard {   // a job that was never forked (an error return in between) must not outlive the call that made it
@@ -166,7 +166,28 @@ int vslam_debug_stream_copy(vslam_ctx *ctx, const void *d_src, void *d_dst, size
 const char *vslam_version(void) { return "vslam_amd 0.1 (gfx950)"; }
 const int8_t *vslam_brief_pattern_31(void) { return vslam_brief_pattern_31_table; }
 
-int vslam_ctx_create(int device, vslam_ctx **out) {
+int vslam_ctx_create(int device, vslam_ctx **out) { return vs_ctx_create(device, false, out); }
+
+}  // extern "C"
+
+// shared_chip: the context is one of several that keep batches in flight on the same device (vslam_pipeline_create).  What
+// pays for one batch at a time -- the blur and the k-d build forked onto a low-priority auxiliary stream so that they fill
+// the holes of the batch's own latency-bound stages -- costs with three: the holes are filled by the other batches, and
+// every fork / join between queues is a hand-over of 50-120 us.  Measured, three batches in flight, hard data, one process,
+// alternating blocks (tools/ab_env.py, tools/ab_lib.py): C3 (512 frames of 1280x720) the single-batch arrangement 2.751 ms per
+// batch; blur on the main stream, k-d build in front of the matcher, all streams at one priority 2.643 (each alone: +0.001 /
+// -0.054 / -0.042); C2 (128 frames of 640x480) 0.412 -> 0.343.  At C5 (1024 frames of 1920x1080) the kernels are five
+// times longer, the hand-overs weigh less and the forks still pay: 14.32 ms against 14.51 without them.  So a shared-chip
+// context decides per call, by the pixels of the batch (vs_arrange_call); its main stream runs at the default priority and
+// it owns two auxiliary streams, one below that and one level with it.
+constexpr double kSharedSmallPixels = 1.0e9;
+void vs_arrange_call(vslam_ctx *ctx, long long frames, int w, int h) {
+    if (!ctx->shared_chip) return;
+    ctx->call_small = (double)frames * w * h <= kSharedSmallPixels;
+    ctx->aux_stream = ctx->call_small ? ctx->aux_flat : ctx->aux_low;
+}
+
+int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
     if (!out) return VSLAM_ERR_INVALID;
     *out = nullptr;
     int count = 0;
@@ -181,11 +202,18 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (const char *e = getenv("VSLAM_STREAM_PRIORITY"))
         if (e[0] == '0') prio_least = prio_greatest = 0;
+    if (shared_chip) prio_greatest = 0;   // the main streams of all the contexts at the default priority
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
     ctx->own_stream = true;
+    if (shared_chip) {
+        if (hipStreamCreateWithPriority(&ctx->aux_flat, hipStreamNonBlocking, 0) != hipSuccess) {
+            delete ctx;
+            return VSLAM_ERR_HIP;
+        }
+    }
     if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -198,10 +226,18 @@ int vslam_ctx_create(int device, vslam_ctx **out) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
-    if (const char *e = getenv("VSLAM_OVERLAP_BLUR")) ctx->overlap_blur = e[0] - '0';
+    ctx->shared_chip = shared_chip;
+    ctx->aux_low = ctx->aux_stream;
+    if (const char *e = getenv("VSLAM_OVERLAP_BLUR")) {
+        ctx->overlap_blur = e[0] - '0';
+        ctx->blur_forced = true;
+    }
+    if (const char *e = getenv("VSLAM_SETS_PREFETCH")) ctx->sets_prefetch = e[0] != '0';
     *out = ctx;
     return VSLAM_OK;
 }
+
+extern "C" {
 
 int vslam_ctx_make_current(vslam_ctx *ctx) {
     if (!ctx) return VSLAM_ERR_INVALID;
@@ -220,10 +256,11 @@ int vslam_ctx_destroy(vslam_ctx *ctx) {
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    if (ctx->aux_stream) {
-        (void)hipStreamSynchronize(ctx->aux_stream);
-        (void)hipStreamDestroy(ctx->aux_stream);
-    }
+    for (hipStream_t a : {ctx->shared_chip ? ctx->aux_low : ctx->aux_stream, ctx->aux_flat})
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
@@ -307,7 +344,7 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
         return VSLAM_OK;
     }
     if (option == VSLAM_OPT_TREE_FORK) {
-        VS_REQUIRE(ctx, value >= -1 && value <= 4, VSLAM_ERR_INVALID);
+        VS_REQUIRE(ctx, value >= -1 && value <= 5, VSLAM_ERR_INVALID);
         ctx->tree_fork = value;
         return VSLAM_OK;
     }
@@ -572,7 +609,8 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     // cvtColor (:56) is the detector's first kernel (or a launch of its own in front of it, for layouts that one does not take).
     // The blur needs only the gray image: run it on the auxiliary stream beside corner detection, whose
     // selection stage is latency-bound and leaves most of the chip idle (not while per-kernel timing is on).
-    const bool overlap = ctx->overlap_blur > 0 && !ctx->prof;
+    vs_arrange_call(ctx, frames, width, height);
+    const bool overlap = ctx->overlap_blur > 0 && !ctx->prof && !(ctx->call_small && !ctx->blur_forced);
     const VsBgrSource src{d_bgr, row_stride};
     ctx->fork_after_eigen = overlap;
     rc = vs_launch_good_features(ctx, gray, frames, width, height, params->max_corners,                  // :56, :61
@@ -703,6 +741,7 @@ int vslam_match_features(vslam_ctx *ctx, const float *d_xy1, const uint8_t *d_de
 static int vs_sets_prefetch(vslam_ctx *ctx, const uint32_t *d_seeds, int batch, int hyp) {
     ctx->raw_seeds = nullptr;
     if (!d_seeds || batch <= 0 || hyp <= 0) return VSLAM_OK;   // the entry point proper reports bad arguments
+    if (!ctx->sets_prefetch) return VSLAM_OK;                  // the generator then runs in line, in front of the mapping
     uint32_t *raw = nullptr;
     int rc = vs_arena_get(ctx, "mf.raw", sizeof(uint32_t) * vs_ransac_raw_words(hyp) * (size_t)batch, (void **)&raw);
     if (rc) return rc;
@@ -734,7 +773,8 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     // The k-d trees are an output of the path but not an input of match/RANSAC: build them on the
     // auxiliary stream beside the matching stages (fork after extraction, join at the end).  With
     // per-kernel timing on, everything stays on one stream so the event brackets are clean.
-    const bool overlap = d_nodes && !ctx->prof;
+    const bool overlap = d_nodes && !ctx->prof && ctx->tree_fork != 5;   // 5: in line on the main stream, at the end of extraction
+    vs_arrange_call(ctx, 2LL * pairs, width, height);
     int rc = vs_sets_prefetch(ctx, d_seeds, pairs, hyp);
     if (rc) return rc;
     rc = vslam_extract_features(ctx, d_bgr, 2 * pairs, width, height, row_stride, params, kp_stride,
@@ -793,7 +833,8 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
     if (!ctx) return VSLAM_ERR_INVALID;
     VsPrefetchGuard prefetch_guard{ctx};
     VS_REQUIRE(ctx, frames >= 2, VSLAM_ERR_INVALID);
-    const bool overlap = d_nodes && !ctx->prof;   // k-d trees beside the matching stages, as in vslam_frontend_pairs
+    const bool overlap = d_nodes && !ctx->prof && ctx->tree_fork != 5;   // k-d trees beside the matching stages, as in vslam_frontend_pairs
+    vs_arrange_call(ctx, frames, width, height);
     int rc = vs_sets_prefetch(ctx, d_seeds, frames - 1, hyp);
     if (rc) return rc;
     rc = vslam_extract_features(ctx, d_bgr, frames, width, height, row_stride, params, kp_stride, d_xy, d_desc,

@@ -47,6 +47,13 @@ struct vslam_ctx {
     int aux_job_at = 0;
     int tree_fork = -1;   // VSLAM_OPT_TREE_FORK: where the batched front-end forks the k-d build (-1: by size; 0 in front of the matcher)
     int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, otherwise on the auxiliary stream from min_eigen (where the gray image is complete) on
+    // One of several contexts with batches in flight on this device (vs_ctx_create).  Such a context picks its arrangement
+    // per call (vs_arrange_call): small batches run without the intra-batch forks that only pay alone, large ones keep them.
+    bool shared_chip = false;
+    hipStream_t aux_low = nullptr, aux_flat = nullptr;   // shared_chip: the auxiliary stream at low / at the main stream's priority (aux_stream is one of them)
+    bool call_small = false;                             // shared_chip: this call takes the no-fork arrangement
+    bool blur_forced = false;                            // VSLAM_OVERLAP_BLUR given: the environment decides, not the call's size
+    bool sets_prefetch = true;  // VSLAM_SETS_PREFETCH: the raw mt19937 outputs generated ahead of time on the auxiliary stream
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     bool rbrief_table_ready = false; // transient: the rotated rBRIEF table of the coming describe call is already queued
     int ransac_min_matches = VSLAM_SET_SIZE;   // VSLAM_OPT_RANSAC_MIN_MATCHES
@@ -94,6 +101,8 @@ struct vslam_ctx {
 // sticky device-side error word (bit 0: a fixed-size candidate list overflowed); vslam_ctx_synchronize
 // reads and clears it and reports VSLAM_ERR_CAPACITY
 int vs_device_errflag(vslam_ctx *ctx, int32_t **out);
+int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out);   // vslam_ctx_create = (device, false, out)
+void vs_arrange_call(vslam_ctx *ctx, long long frames, int w, int h);   // shared_chip contexts: choose this call's arrangement
 std::string vs_errflag_message(int32_t flag);
 
 // fork the pending auxiliary job (if it was asked for at `point`) onto the auxiliary stream behind everything queued so far

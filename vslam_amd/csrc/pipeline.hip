@@ -125,7 +125,7 @@ int vslam_pipeline_create(int device, int n_ctx, vslam_pipeline **out) {
     int rc = VSLAM_OK;
     for (int i = 0; i < n_ctx && rc == VSLAM_OK; i++) {
         Slot &s = p->slots[(size_t)i];
-        rc = vslam_ctx_create(device, &s.ctx);
+        rc = vs_ctx_create(device, n_ctx > 1, &s.ctx);   // with company: the arrangement for a shared chip (capi.hip)
         if (rc) break;
         if ((rc = vs_device_errflag(s.ctx, &s.d_flag))) break;
         if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
