@@ -23,3 +23,15 @@ using f64 = double;
 #ifndef f32_maximum
 #define f32_maximum FLT_MAX
 #endif
+
+// the reference's three names for `static` (include/vslam_internal.h:29-32; defined there, used nowhere in its tree): kept so
+// that this header can stand in for that one whatever a consumer does with them
+#ifndef internal_function
+#define internal_function static
+#endif
+#ifndef local_persist
+#define local_persist static
+#endif
+#ifndef global_variable
+#define global_variable static
+#endif

@@ -35,6 +35,12 @@ CONFIGS = {
     "no priorities, trees behind matcher, blur on main": (dict(NP, VSLAM_OVERLAP_BLUR="0"), {C.OPT_TREE_FORK: 1}, True),
     "no priorities, no trees, blur on main": (dict(NP, VSLAM_OVERLAP_BLUR="0"), {}, False),
 }
+if os.environ.get("AB_SET") == "prio":
+    CONFIGS = {
+        "default": ({}, {}, True),
+        "main at default priority, aux low": (dict(VSLAM_STREAM_PRIORITY="2"), {}, True),
+        "no priorities": (dict(NP), {}, True),
+    }
 if os.environ.get("AB_SET") == "small":   # large shapes: fewer configurations (every one holds its own workspaces)
     CONFIGS = {
         "default": ({}, {}, True),

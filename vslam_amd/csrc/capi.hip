@@ -200,8 +200,10 @@ int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
     // stream's workgroups go first whenever both have some ready (VSLAM_STREAM_PRIORITY=0: both at the default priority).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (const char *e = getenv("VSLAM_STREAM_PRIORITY"))
+    if (const char *e = getenv("VSLAM_STREAM_PRIORITY")) {
         if (e[0] == '0') prio_least = prio_greatest = 0;
+        if (e[0] == '2') prio_greatest = 0;   // main at the default priority, auxiliary below it
+    }
     if (shared_chip) prio_greatest = 0;   // the main streams of all the contexts at the default priority
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
         delete ctx;
