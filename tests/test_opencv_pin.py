@@ -61,6 +61,31 @@ def test_extraction_matches_opencv(oracle):
         assert np.array_equal(e["desc"], D[f"cv_desc{f}"]), "rBRIEF descriptors"
 
 
+def test_photographs_match_opencv(oracle):
+    """The same stages on the photographic frames of tests/golden/real_v1.npz, plus knnMatch + ratio test per pair."""
+    D = _dump()
+    if "cv_p_gray0" not in D.files:
+        pytest.skip("PARITY UNPINNED on photographs: the dump predates tools/opencv_dump.cpp's p_ block")
+    case = opencv_case.case_inputs()
+    bgr, maxc = case["p_bgr"], int(case["p_maxc"][0])
+    P = bgr.shape[0] // 2
+    pat = G["e_pattern"]
+    ca, sa = map(float, G["e_rot"])
+    feats = []
+    for f in range(2 * P):
+        gray = oracle.bgr2gray(bgr[f])
+        assert np.array_equal(gray, D[f"cv_p_gray{f}"]), "cvtColor(BGR2GRAY)"
+        assert np.array_equal(bits(oracle.min_eigen(gray)), bits(D[f"cv_p_eig{f}"])), "cornerMinEigenVal"
+        assert np.array_equal(oracle.good_features(gray, maxc), D[f"cv_p_corners{f}"]), "goodFeaturesToTrack"
+        assert np.array_equal(oracle.gaussian7(gray), D[f"cv_p_blur{f}"]), "GaussianBlur 7x7 sigma 2"
+        e = oracle.extract_features(bgr[f], maxc, ca, sa, pat)
+        assert np.array_equal(e["xy"], D[f"cv_p_kept_xy{f}"]) and np.array_equal(e["desc"], D[f"cv_p_desc{f}"]), "ORB::compute"
+        feats.append(e)
+    for i in range(P):
+        p, rc = oracle.match_knn2_ratio(feats[i]["desc"], feats[P + i]["desc"])
+        assert rc == 0 and np.array_equal(p, D[f"cv_p_pairs{i}"]), "knnMatch + ratio test"
+
+
 def test_matching_matches_opencv(oracle):
     D = _dump()
     assert np.array_equal(np.stack(oracle.match_knn2(G["m_d1"], G["m_d2"]), 1), D["cv_knn"]), "BFMatcher::knnMatch(k=2)"

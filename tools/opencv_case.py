@@ -48,7 +48,13 @@ def case_inputs():
     # the pose helpers' inputs: the golden pair's fundamental matrix and inlier matches, intrinsics as src/vslam.cpp:29-33
     K = np.array([[525.0, 0, w / 2.0], [0, 525.0, h / 2.0], [0, 0, 1]], np.float32)
     pm = G["p_matches"]
+    # the photographic pairs of tests/golden/real_v1.npz (round 5), remade from the stored crops
+    sys.path.insert(0, ROOT)
+    from vslam_amd import synth
+    R = np.load(os.path.join(ROOT, "tests", "golden", "real_v1.npz"))
+    real = [synth.real_pair(R[f"crop{i}"], tuple(R["motions"][i])) for i in range(len(R["names"]))]
     return {
+        "p_bgr": np.stack([a for a, _ in real] + [b for _, b in real]), "p_maxc": np.array([int(R["params"][0])], np.int32),
         "g_bgr": G2["g_bgr"], "g_grid": np.array([2, 2], np.int32),                    # make_golden.py: a 2 x 2 grid
         "t_F": G["p_F"].reshape(3, 3), "t_K": K,
         "t_p1": np.ascontiguousarray(G["e_xy0"][pm[:, 0]]), "t_p2": np.ascontiguousarray(G["e_xy1"][pm[:, 1]]),

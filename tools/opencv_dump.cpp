@@ -97,33 +97,54 @@ int main(int argc, char **argv) {
         put("opencv_have_lapack_macro", 0, {1}, &lapack);
 
         // ---------------------------------------------------------------- extraction, src/Frame.cpp:53-80
-        const Arr &bgr = in.at("e_bgr");   // [2][h][w][3] u8
-        const int frames = (int)bgr.dims[0], h = (int)bgr.dims[1], w = (int)bgr.dims[2];
-        const int maxc = in.at("e_maxc").as<int32_t>()[0];
-        for (int f = 0; f < frames; f++) {
-            const std::string t = std::to_string(f);
-            cv::Mat image(h, w, CV_8UC3, const_cast<uint8_t *>(bgr.as<uint8_t>()) + (size_t)f * h * w * 3);
-            cv::Mat gray;
-            cv::cvtColor(image, gray, cv::COLOR_BGR2GRAY);                                  // :56
-            put_mat("cv_gray" + t, gray);
-            cv::Mat eig;
-            cv::cornerMinEigenVal(gray, eig, 3, 3);                                          // inside goodFeaturesToTrack
-            put_mat("cv_eig" + t, eig);
-            std::vector<cv::Point2f> corners;
-            cv::goodFeaturesToTrack(gray, corners, maxc, 0.01, 3);                           // :61 (3000 there)
-            put("cv_corners" + t, 2, {(uint32_t)corners.size(), 2}, corners.data());
-            cv::Mat blurred;
-            cv::GaussianBlur(gray, blurred, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);    // ORB::compute's blur
-            put_mat("cv_blur" + t, blurred);
-            std::vector<cv::KeyPoint> kps;
-            for (const cv::Point2f &p : corners) kps.push_back(cv::KeyPoint(p, 20));          // :64-67
-            cv::Ptr<cv::ORB> orb = cv::ORB::create();                                         // :57
-            cv::Mat desc;
-            orb->compute(gray, kps, desc);                                                    // :68 (may drop border keypoints)
-            std::vector<cv::Point2f> kept;
-            for (const cv::KeyPoint &k : kps) kept.push_back(k.pt);                           // :69-72
-            put("cv_kept_xy" + t, 2, {(uint32_t)kept.size(), 2}, kept.data());
-            put_mat("cv_desc" + t, desc);                                                     // OpenCV's own learned pattern
+        // `prefix` "" = the seeded synthetic pair of frontend_v1.npz; "p_" = the photographic frames of real_v1.npz
+        // (round 5: plateaus, gradients and JPEG structure, which the synthetic textures lack)
+        auto extraction = [&](const std::string &prefix, const Arr &bgr, int maxc, std::vector<cv::Mat> *descs) {
+            const int frames = (int)bgr.dims[0], h = (int)bgr.dims[1], w = (int)bgr.dims[2];
+            for (int f = 0; f < frames; f++) {
+                const std::string t = std::to_string(f);
+                cv::Mat image(h, w, CV_8UC3, const_cast<uint8_t *>(bgr.as<uint8_t>()) + (size_t)f * h * w * 3);
+                cv::Mat gray;
+                cv::cvtColor(image, gray, cv::COLOR_BGR2GRAY);                                  // :56
+                put_mat("cv_" + prefix + "gray" + t, gray);
+                cv::Mat eig;
+                cv::cornerMinEigenVal(gray, eig, 3, 3);                                          // inside goodFeaturesToTrack
+                put_mat("cv_" + prefix + "eig" + t, eig);
+                std::vector<cv::Point2f> corners;
+                cv::goodFeaturesToTrack(gray, corners, maxc, 0.01, 3);                           // :61 (3000 there)
+                put("cv_" + prefix + "corners" + t, 2, {(uint32_t)corners.size(), 2}, corners.data());
+                cv::Mat blurred;
+                cv::GaussianBlur(gray, blurred, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);    // ORB::compute's blur
+                put_mat("cv_" + prefix + "blur" + t, blurred);
+                std::vector<cv::KeyPoint> kps;
+                for (const cv::Point2f &p : corners) kps.push_back(cv::KeyPoint(p, 20));          // :64-67
+                cv::Ptr<cv::ORB> orb = cv::ORB::create();                                         // :57
+                cv::Mat desc;
+                orb->compute(gray, kps, desc);                                                    // :68 (may drop border keypoints)
+                std::vector<cv::Point2f> kept;
+                for (const cv::KeyPoint &k : kps) kept.push_back(k.pt);                           // :69-72
+                put("cv_" + prefix + "kept_xy" + t, 2, {(uint32_t)kept.size(), 2}, kept.data());
+                put_mat("cv_" + prefix + "desc" + t, desc);                                       // OpenCV's own learned pattern
+                if (descs) descs->push_back(desc.clone());
+            }
+        };
+        extraction("", in.at("e_bgr"), in.at("e_maxc").as<int32_t>()[0], nullptr);
+        if (in.count("p_bgr")) {   // [2 P][480][640][3]: frames [0, P) "last", [P, 2 P) "current"; knnMatch + ratio test per pair (:83-94)
+            std::vector<cv::Mat> descs;
+            extraction("p_", in.at("p_bgr"), in.at("p_maxc").as<int32_t>()[0], &descs);
+            const int P = (int)descs.size() / 2;
+            for (int i = 0; i < P; i++) {
+                cv::Ptr<cv::BFMatcher> matcher = cv::BFMatcher::create(cv::NORM_HAMMING);
+                std::vector<std::vector<cv::DMatch>> knn;
+                matcher->knnMatch(descs[(size_t)i], descs[(size_t)(P + i)], knn, 2);
+                std::vector<int32_t> pairs;
+                for (auto &m : knn)
+                    if (m.size() == 2 && m[0].distance < m[1].distance * 0.7) {
+                        pairs.push_back(m[0].queryIdx);
+                        pairs.push_back(m[0].trainIdx);
+                    }
+                put("cv_p_pairs" + std::to_string(i), 1, {(uint32_t)(pairs.size() / 2), 2}, pairs.data());
+            }
         }
 
         // ---------------------------------------------------------------- matching, src/Frame.cpp:83-94

@@ -207,3 +207,45 @@ def frames_torch_hard(seed, n_pairs, width, height, device, outlier_area=0.55):
                 noise = torch.randint(-6, 7, (height, width, 3), generator=g, device=device).float()
                 out[f] = torch.clamp(img[:, :, None] + noise + tint, 0, 255).to(torch.uint8)
     return out
+
+
+def resample_fixed(img, height, width, a, b, c, d, tx, ty):
+    """Bilinear resampling of an (H, W, 3) uint8 image in INTEGER arithmetic (16.16 fixed point): output pixel (x, y) reads
+    the source at (a x + b y + tx, c x + d y + ty), clamped to the image.  The same bytes on every machine -- this is how
+    tests/golden/real_v1.npz's second frames are remade from its first frames (tests/golden/make_real.py) -- and the
+    sub-pixel interpolation gives the smooth, slightly blurred content photographs have after any resampling."""
+    img = np.asarray(img)
+    H, W = img.shape[:2]
+    Q = 1 << 16
+    fx = (np.int64(round(a * Q)) * np.arange(width, dtype=np.int64)[None, :] + np.int64(round(b * Q)) * np.arange(height, dtype=np.int64)[:, None]
+          + np.int64(round(tx * Q)))
+    fy = (np.int64(round(c * Q)) * np.arange(width, dtype=np.int64)[None, :] + np.int64(round(d * Q)) * np.arange(height, dtype=np.int64)[:, None]
+          + np.int64(round(ty * Q)))
+    fx = np.clip(fx, 0, (W - 1) * Q)
+    fy = np.clip(fy, 0, (H - 1) * Q)
+    x0, y0 = fx >> 16, fy >> 16
+    x1, y1 = np.minimum(x0 + 1, W - 1), np.minimum(y0 + 1, H - 1)
+    wx, wy = (fx & (Q - 1)) >> 8, (fy & (Q - 1)) >> 8          # 8-bit weights
+    src = img.astype(np.int64)
+    out = np.empty((height, width, img.shape[2]), np.uint8)
+    for ch in range(img.shape[2]):
+        p = src[:, :, ch]
+        top = p[y0, x0] * (256 - wx) + p[y0, x1] * wx
+        bot = p[y1, x0] * (256 - wx) + p[y1, x1] * wx
+        out[:, :, ch] = ((top * (256 - wy) + bot * wy + (1 << 15)) >> 16).astype(np.uint8)
+    return out
+
+
+def real_pair(first, motion):
+    """The two 640 x 480 BGR frames of a photographic pair: both are windows of the source photograph `first` (H, W, 3; at
+    least 720 x 560), the second after a small camera motion (rotation in degrees about the window centre, shift in pixels)."""
+    rot, dx, dy = motion
+    H, W = first.shape[:2]
+    x0, y0 = (W - 640) // 2, (H - 480) // 2
+    a = resample_fixed(first, 480, 640, 1.0, 0.0, 0.0, 1.0, x0, y0)
+    th = np.deg2rad(rot)
+    ca, sa = float(np.cos(th)), float(np.sin(th))
+    cx, cy = x0 + 320.0, y0 + 240.0
+    # source position of output (x, y): rotate (x - 320, y - 240) by rot, add centre + shift
+    b = resample_fixed(first, 480, 640, ca, -sa, sa, ca, cx + dx - 320 * ca + 240 * sa, cy + dy - 320 * sa - 240 * ca)
+    return a, b
