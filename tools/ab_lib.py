@@ -16,7 +16,9 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from vslam_amd import capi, shard, synth  # noqa: E402
 
-paths = [os.path.abspath(p) for p in sys.argv[1:3]]
+specs = [a.split(":", 1) for a in sys.argv[1:3]]   # lib.so[:NAME=VALUE,...]: environment its contexts read when they are made
+paths = [os.path.abspath(sp[0]) for sp in specs]
+envs = [dict(kv.split("=", 1) for kv in sp[1].split(",")) if len(sp) > 1 else {} for sp in specs]
 wl = sys.argv[3] if len(sys.argv) > 3 else "C3"
 depth = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 6
@@ -25,7 +27,12 @@ dev = torch.device("cuda:0")
 ca, sa = synth.keypoint_rotation()
 seeds = torch.from_numpy(shard.pair_seeds(0x5EED0002, 0, P).view(np.int32)).to(dev)
 data = {"hard": synth.frames_torch_hard(0x5EED0002, P, w, h, dev), "easy": synth.frames_torch(0x5EED0002, P, w, h, dev)}
-pipes = [capi.Pipeline(0, depth, lib=capi.load_library(p)) for p in paths]
+pipes = []
+for p, e in zip(paths, envs):
+    os.environ.update(e)
+    pipes.append(capi.Pipeline(0, depth, lib=capi.load_library(p)))
+    for k in e:
+        os.environ.pop(k)
 outs = [capi.Pipeline.alloc_outputs(torch, 2 * P, P, K, dev) for _ in range(depth)]
 steps = 30 if wl != "C5" else 9
 

@@ -235,6 +235,7 @@ int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
         ctx->blur_forced = true;
     }
     if (const char *e = getenv("VSLAM_SETS_PREFETCH")) ctx->sets_prefetch = e[0] != '0';
+    if (const char *e = getenv("VSLAM_RANSAC_SOLVE_SPLIT")) ctx->solve_split = atoi(e);
     *out = ctx;
     return VSLAM_OK;
 }

@@ -53,6 +53,7 @@ struct vslam_ctx {
     hipStream_t aux_low = nullptr, aux_flat = nullptr;   // shared_chip: the auxiliary stream at low / at the main stream's priority (aux_stream is one of them)
     bool call_small = false;                             // shared_chip: this call takes the no-fork arrangement
     bool blur_forced = false;                            // VSLAM_OVERLAP_BLUR given: the environment decides, not the call's size
+    int solve_split = 0;        // VSLAM_RANSAC_SOLVE_SPLIT (read when the context is made): 0 one solve kernel, 4 / 5 sweeps + closing kernel
     bool sets_prefetch = true;  // VSLAM_SETS_PREFETCH: the raw mt19937 outputs generated ahead of time on the auxiliary stream
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     bool rbrief_table_ready = false; // transient: the rotated rBRIEF table of the coming describe call is already queued

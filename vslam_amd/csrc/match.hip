@@ -397,11 +397,17 @@ template <int RT, bool PRE, int CT>
 __global__ __launch_bounds__(64 * kMQ / (32 * RT)) void match_knn2_fp4_kernel(
     const uint8_t *__restrict__ desc1, const int32_t *__restrict__ n1, const uint8_t *__restrict__ desc2,
     const int32_t *__restrict__ n2, int kp_stride, int32_t *__restrict__ sel, int32_t *__restrict__ knn,
-    const uint8_t *__restrict__ tx, int kp_pad) {
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const uint8_t *__restrict__ tx, int kp_pad, int batch, int per_pair) {
+    // 1-D grid, remapped so that the workgroups of a pair share an XCD: they all stream the pair's train rows, and each XCD
+    // has its own L2 -- dealt round-robin (blockIdx.y = pair), the seven workgroups of a pair sat on seven XCDs and each
+    // fetched the rows from the fabric for itself (round 4: 425 MB of reads per launch for 57 MB of rows).
+    int b, qt;
+    vs_xcd_item_block(blockIdx.x, per_pair, b, qt);
+    if (b >= batch) return;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nq = n1[b], nt = n2[b];
-    const int qbase = blockIdx.x * kMQ;
+    const int qbase = qt * kMQ;
     if (qbase >= nq) return;   // uniform for the whole workgroup
 
     static_assert(CT == 1 || PRE, "two tiles per trip only with pre-spread train rows");
@@ -644,6 +650,8 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
                 //   8 x 32 / 4 x 64 spreading in place     0.198 / 1.51 and 0.208 / 1.44
                 // (8 x 32: 5 waves per SIMD; the pre-spread rows pay more the more workgroups share them)
                 const bool wide4 = pick == 2;
+                const int per_pair = vs_div_up(kp_stride, kMQ);
+                const int xgrid = vs_xcd_grid(batch, per_pair);
                 static const char *nopre = getenv("VSLAM_MATCH_NO_PRESPREAD");   // A/B timing: every workgroup spreads for itself
                 static const char *ct_env = getenv("VSLAM_MATCH_TILES_PER_TRIP");
                 const int ct = ct_env ? atoi(ct_env) : 2;
@@ -652,14 +660,14 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
                     uint8_t *tx = nullptr;
                     if ((rc = vs_arena_get(ctx, "match.spread", (size_t)batch * kp_pad * 128, (void **)&tx))) return rc;
                     match_spread_kernel<<<dim3(vs_div_up(kp_stride * 8, 256), batch), 256, 0, ctx->stream>>>(d2, n2, kp_stride, kp_pad, tx);
-                    if (wide4 && ct == 2) match_knn2_fp4_kernel<2, true, 2><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
-                    else if (wide4) match_knn2_fp4_kernel<2, true, 1><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
-                    else if (ct == 2) match_knn2_fp4_kernel<1, true, 2><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
-                    else match_knn2_fp4_kernel<1, true, 1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad);
+                    if (wide4 && ct == 2) match_knn2_fp4_kernel<2, true, 2><<<xgrid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad, batch, per_pair);
+                    else if (wide4) match_knn2_fp4_kernel<2, true, 1><<<xgrid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad, batch, per_pair);
+                    else if (ct == 2) match_knn2_fp4_kernel<1, true, 2><<<xgrid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad, batch, per_pair);
+                    else match_knn2_fp4_kernel<1, true, 1><<<xgrid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad, batch, per_pair);
                 } else if (wide4) {
-                    match_knn2_fp4_kernel<2, false, 1><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, nullptr, 0);
+                    match_knn2_fp4_kernel<2, false, 1><<<xgrid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, nullptr, 0, batch, per_pair);
                 } else {
-                    match_knn2_fp4_kernel<1, false, 1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, nullptr, 0);
+                    match_knn2_fp4_kernel<1, false, 1><<<xgrid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, nullptr, 0, batch, per_pair);
                 }
             } else if (wide) match_knn2_mfma_kernel<2><<<grid, 256, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
             else match_knn2_mfma_kernel<1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);

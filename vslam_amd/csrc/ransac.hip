@@ -668,8 +668,51 @@ __device__ __forceinline__ void jacobi_null_row_8x9(float *pA, float (&R)[8][9],
     for (int k = 0; k < M; k++) f0[k] = v[k] * s;
 }
 
+// The part of compute_fundamental behind the first SVD (src/RansacFilter.cpp:98-101): the 3 x 3 SVD of F0 (working rows =
+// its columns), D[2] = 0, F = U diag(D) Vt.  sA / sV: this wave's 9 + 9 float columns in LDS; `tid` = the lane.
+__device__ __forceinline__ void fundamental_rank2(const float (&f0)[9], float *sA, float *sV, int tid, float (&F)[9]) {
+    {
+        constexpr int M = 3;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) VS_A(i, k) = f0[3 * k + i];
+    }
+    float d3[3];
+    jacobi_svd_lanes<3, 3, 3, true>(sA, sV, tid, d3, nullptr);
+    d3[2] = 0.f;   // :99
+
+    float U[9], Vt[9];
+    {
+        constexpr int M = 3, N = 3;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                U[r * 3 + c] = VS_A(c, r);   // u = transpose(temp_u)
+                Vt[r * 3 + c] = VS_V(r, c);
+            }
+    }
+    // temp_F = U * diag(D) * V_t (:101) through OpenCV's 3x3 float fast path (a0*b0 + a1*b1 + a2*b2)
+    const float Dg[9] = {d3[0], 0.f, 0.f, 0.f, d3[1], 0.f, 0.f, 0.f, d3[2]};
+    float UD[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            UD[i * 3 + j] = U[i * 3 + 0] * Dg[0 * 3 + j] + U[i * 3 + 1] * Dg[1 * 3 + j] + U[i * 3 + 2] * Dg[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            F[i * 3 + j] = UD[i * 3 + 0] * Vt[0 * 3 + j] + UD[i * 3 + 1] * Vt[1 * 3 + j] + UD[i * 3 + 2] * Vt[2 * 3 + j];
+}
+
 // One lane per hypothesis, one wave per workgroup.  grid = (ceil(hyp / 64), batch).
-__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void ransac_solve_kernel(
+// SPLIT (round 5, VSLAM_RANSAC_SOLVE_SPLIT): the kernel stops behind the first SVD and leaves F0 = V_t.row(8) in hypF;
+// ransac_close_kernel turns it into F in place.  WPE: waves per SIMD the register budget is cut for.
+template <bool SPLIT, int WPE>
+__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ransac_solve_kernel(
     const float *__restrict__ xy1, const float *__restrict__ xy2, const int32_t *__restrict__ pairs,
     const int32_t *__restrict__ m_arr, int min_m, const int32_t *__restrict__ sets, int kp_stride, int hyp,
     float *__restrict__ hypF) {
@@ -711,46 +754,36 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         jacobi_null_row_8x9(sA + tid, R, f0);
     }
 
-    // second SVD on the 3x3 (:98): working rows are the COLUMNS of F0 (m == n -> transpose)
-    float *sV = sA + 9 * kSolveThreads;
-    {
-        constexpr int M = 3;
+    float F[9];
+    if (SPLIT) {
 #pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) VS_A(i, k) = f0[3 * k + i];
+        for (int k = 0; k < 9; k++) F[k] = f0[k];
+    } else {
+        fundamental_rank2(f0, sA, sA + 9 * kSolveThreads, tid, F);   // second SVD on the 3x3 (:98) and F = U diag Vt (:101)
     }
-    float d3[3];
-    jacobi_svd_lanes<3, 3, 3, true>(sA, sV, tid, d3, nullptr);
-    d3[2] = 0.f;   // :99
-
-    float U[9], Vt[9];
-    {
-        constexpr int M = 3, N = 3;
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                U[r * 3 + c] = VS_A(c, r);   // u = transpose(temp_u)
-                Vt[r * 3 + c] = VS_V(r, c);
-            }
-    }
-    // temp_F = U * diag(D) * V_t (:101) through OpenCV's 3x3 float fast path (a0*b0 + a1*b1 + a2*b2)
-    const float Dg[9] = {d3[0], 0.f, 0.f, 0.f, d3[1], 0.f, 0.f, 0.f, d3[2]};
-    float UD[9], F[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            UD[i * 3 + j] = U[i * 3 + 0] * Dg[0 * 3 + j] + U[i * 3 + 1] * Dg[1 * 3 + j] + U[i * 3 + 2] * Dg[2 * 3 + j];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            F[i * 3 + j] = UD[i * 3 + 0] * Vt[0 * 3 + j] + UD[i * 3 + 1] * Vt[1 * 3 + j] + UD[i * 3 + 2] * Vt[2 * 3 + j];
-
     if (live) {
         float *o = hypF + ((size_t)b * hyp + h) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = F[k];
+    }
+}
+
+// The closing part of the split form: four waves per workgroup, a lane per hypothesis, F0 in, F out, in place.
+constexpr int kCloseThreads = 256;
+__global__ __launch_bounds__(kCloseThreads) void ransac_close_kernel(const int32_t *__restrict__ m_arr, int min_m, int hyp,
+                                                                     float *__restrict__ hypF) {
+    const int b = blockIdx.y;
+    if (m_arr[b] < min_m) return;
+    __shared__ float s[kCloseThreads / 64][18 * kSolveThreads];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = blockIdx.x * kCloseThreads + threadIdx.x;
+    const bool live = h < hyp;
+    float *o = hypF + ((size_t)b * hyp + (live ? h : hyp - 1)) * 9;
+    float f0[9], F[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f0[k] = o[k];
+    fundamental_rank2(f0, s[wave], s[wave] + 9 * kSolveThreads, lane, F);
+    if (live) {
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = F[k];
     }
@@ -2384,8 +2417,19 @@ int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, c
         VS_HIP(ctx, hipGetLastError());
         return VSLAM_OK;
     }
+    // VSLAM_RANSAC_SOLVE_SPLIT: 0 one kernel (rounds 2-4); 4 / 5: sweeps + null-space row at 4 / 5 waves per SIMD, then
+    // ransac_close_kernel (the 3 x 3 SVD and U diag Vt, a launch of its own at full occupancy).  Same bits either way.
+    const int split = ctx->solve_split;
     VsProfScope ps(ctx, "ransac_solve_kernel");
-    ransac_solve_kernel<<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
+    if (split == 0) {
+        ransac_solve_kernel<false, 4><<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
+    } else {
+        if (split == 5)
+            ransac_solve_kernel<true, 5><<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
+        else
+            ransac_solve_kernel<true, 4><<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
+        ransac_close_kernel<<<dim3(vs_div_up(hyp, kCloseThreads), batch), kCloseThreads, 0, ctx->stream>>>(m, ctx->ransac_min_matches, hyp, hypF);
+    }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }
