@@ -81,6 +81,11 @@ struct SequenceOptions {
 struct SequenceStats {
     uint64_t frames = 0, pairs = 0, batches = 0;
     double seconds = 0;          // wall time of the loop, file reads and uploads included
+    // Batches in which more frames overflowed the corner detector's bounded candidate lists (response plateaus, pure noise:
+    // not image data) than its whole-image fallback pool holds (max(4, frames / 16) sets).  The device reports that as
+    // VSLAM_ERR_CAPACITY when the batch is waited for; the loop then repeats the batch with every list sized for the whole
+    // image (VSLAM_OPT_CORNER_LIST_CAP = -1), so the records are exact either way -- such a batch costs twice its time.
+    uint64_t batches_redone = 0;
 };
 
 // The reference's capture loop without the map and the viewer: read `video_path`, run the front-end on every
@@ -110,3 +115,5 @@ extern "C" int vslam_host_run_sequence_devices(const char *video_path, const cha
                                                uint32_t seed, uint64_t max_frames, const int *devices, int n_devices,
                                                uint64_t *frames_out, uint64_t *pairs_out, double *seconds_out, char *err,
                                                int err_cap);
+// SequenceStats::batches_redone of the last call through one of the two entry points above
+extern "C" uint64_t vslam_host_last_batches_redone(void);

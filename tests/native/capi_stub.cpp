@@ -7,6 +7,7 @@
 // once and a worker thread copies later (so a host buffer refilled too early is a data race TSan sees, and a wrong record);
 // vslam_frontend_sequence runs on the same worker, behind the uploads it was fenced on.  What it "computes" is a checksum
 // of each frame pair, which the driver recomputes from the file.
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@ struct vslam_ctx {
     int copy_busy = 0, compute_busy = 0;
     uint64_t copy_issued = 0, copy_done = 0, compute_waits_for = 0;
     bool stop = false;
+    bool whole_image_lists = false;
     std::thread copy_thread, compute_thread;
 };
 
@@ -108,6 +110,33 @@ int vslam_ctx_destroy(vslam_ctx *c) {
     return VSLAM_OK;
 }
 int vslam_ctx_make_current(vslam_ctx *c) { return c ? VSLAM_OK : VSLAM_ERR_INVALID; }
+// Every `period`-th batch status reads VSLAM_ERR_CAPACITY while the corner lists are bounded (the driver sets the period):
+// the capture loop must then repeat the batch with VSLAM_OPT_CORNER_LIST_CAP = -1, under the same sanitizers.
+static std::atomic<int> g_capacity_period{0}, g_status_calls{0};
+void vslam_stub_set_capacity_period(int period) { g_capacity_period = period; }
+int vslam_ctx_set_option(vslam_ctx *c, int option, int value) {
+    if (!c) return VSLAM_ERR_INVALID;
+    if (option == VSLAM_OPT_CORNER_LIST_CAP) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->whole_image_lists = value == -1;
+    }
+    return VSLAM_OK;
+}
+int vslam_ctx_synchronize(vslam_ctx *c) {
+    if (!c) return VSLAM_ERR_INVALID;
+    compute_sync(c);
+    const int period = g_capacity_period.load();
+    bool bounded;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        bounded = !c->whole_image_lists;
+    }
+    if (period > 0 && bounded && (++g_status_calls % period) == 0) {
+        c->err = "stub: corner pool exhausted";
+        return VSLAM_ERR_CAPACITY;
+    }
+    return VSLAM_OK;
+}
 const char *vslam_last_error(vslam_ctx *c) { return c ? c->err.c_str() : "null context"; }
 int vslam_host_alloc(vslam_ctx *, size_t bytes, void **h_out) { return (*h_out = std::malloc(bytes ? bytes : 1)) ? VSLAM_OK : VSLAM_ERR_HIP; }
 int vslam_host_free(vslam_ctx *, void *p) {

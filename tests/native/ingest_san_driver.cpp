@@ -15,6 +15,7 @@
 #include "vslam/Ingest.h"
 
 extern "C" uint32_t vslam_stub_pair_value(const uint8_t *a, const uint8_t *b, size_t frame_bytes, uint32_t seed);
+extern "C" void vslam_stub_set_capacity_period(int period);
 
 // the four helpers ingest.cpp takes from adapters.cpp (which drags in the whole C ABI)
 namespace vslam {
@@ -97,6 +98,19 @@ int main(int argc, char **argv) {
                 }
                 run++;
             }
+        // every third batch reports VSLAM_ERR_CAPACITY once: the loop repeats it with whole-image lists; same records
+        {
+            vslam_stub_set_capacity_period(3);
+            vslam::SequenceOptions o;
+            o.width = w, o.height = h, o.batch_frames = 6, o.max_corners = K, o.hypotheses = 8, o.threshold = 10.f, o.seed = 0x77;
+            const vslam::SequenceStats st = vslam::run_sequence(vpath, dir + "/cap.bin", o);
+            if (st.batches_redone < 3) throw std::runtime_error("no batch was redone");
+            verify(dir + "/cap.bin", o.seed, frames);
+            const vslam::SequenceStats sd = vslam::run_sequence_devices(vpath, dir + "/capd.bin", o, {0, 0, 0});
+            if (sd.batches_redone < 2) throw std::runtime_error("no batch was redone (devices)");
+            verify(dir + "/capd.bin", o.seed, frames);
+            vslam_stub_set_capacity_period(0);
+        }
         // max_frames, and a file shorter than one pair
         vslam::SequenceOptions o;
         o.width = w, o.height = h, o.batch_frames = 5, o.max_corners = K, o.hypotheses = 8, o.threshold = 10.f, o.seed = 5, o.max_frames = 11;

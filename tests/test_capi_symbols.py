@@ -63,5 +63,6 @@ def test_host_library_exports_its_c_entry_points():
     text = open(os.path.join(ROOT, "include", "vslam", "Ingest.h")).read()
     names = sorted(set(re.findall(r'extern "C" int (vslam_host_[a-z_]+)\(', text)))
     assert names == ["vslam_host_run_sequence", "vslam_host_run_sequence_devices"]
+    assert hasattr(host, "vslam_host_last_batches_redone")
     for n in names:
         assert hasattr(host, n), n

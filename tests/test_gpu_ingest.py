@@ -195,3 +195,37 @@ def test_blank_frames_give_empty_records_whatever_the_batch(tmp_path, monkeypatc
         assert recs[i]["winner"] == -1 and recs[i]["inliers"] == 0 and len(recs[i]["matches"]) == 0
         assert not recs[i]["F"].any()
     assert recs[0]["winner"] >= 0 and recs[4]["winner"] >= 0 and recs[0]["F"].any()   # frames (0,1) and (4,5) are real pairs
+
+
+def test_a_batch_that_exhausts_the_corner_pool_is_redone_not_lost(oracle, tmp_path):
+    """Pure noise at a small corner budget: every frame overflows the bounded corner lists (16 x max_corners + 4096 entries
+    against about one 3 x 3 maximum per nine pixels) and a 16-frame batch has a fallback pool of four whole-image sets.  The
+    device reports VSLAM_ERR_CAPACITY for the batch; the capture loop repeats it with whole-image lists, so the record file
+    is the oracle's all the same (it used to go on with frames that had come back without corners -- the advisor's finding
+    of round 4 was that it aborts; it did not even notice)."""
+    maxc, hyp, w, h = 60, 32, 640, 480           # 640 x 480 noise: about 34 k maxima per frame against 5056 list entries
+    rng = np.random.default_rng(99)
+    base = rng.integers(0, 256, (h + 8, w + 8, 3), dtype=np.uint8)
+    clip = np.stack([np.ascontiguousarray(base[(i % 3):(i % 3) + h, (i % 5):(i % 5) + w]) for i in range(17)])   # shifted noise: neighbours match
+    vid = tmp_path / "noise.bgr"
+    clip.tofile(vid)
+    out = tmp_path / "noise.bin"
+    frames, pairs, _, redone = records.run_sequence(vid, out, w, h, 16, maxc, hyp, THR, 0xBEE)
+    assert (frames, pairs) == (17, 16) and redone >= 1
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    feats = [oracle.extract_features(f, maxc, ca, sa, pat) for f in clip]
+    assert min(f["n"] for f in feats) > 0
+    _, recs = records.read_records(out)
+    assert len(recs) == 16
+    for i, r in enumerate(recs):
+        a, b = feats[i], feats[i + 1]
+        ref = oracle.match_features(a["xy"], a["desc"], b["xy"], b["desc"], int(np.uint32(0xBEE) ^ np.uint32(i)), hyp, THR)
+        assert np.array_equal(r["matches"], ref["matches"]), i
+        if ref["rc"] == 0:
+            assert np.array_equal(r["F"].view(np.uint32), np.asarray(ref["F"], np.float32).view(np.uint32)), i
+    # an ordinary clip redoes nothing
+    clip2 = video(9, 3)
+    vid2 = tmp_path / "plain.bgr"
+    clip2.tofile(vid2)
+    assert records.run_sequence(vid2, tmp_path / "plain.bin", W, H, 8, MAXC, HYP, THR, 1)[3] == 0

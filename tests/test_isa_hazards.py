@@ -40,6 +40,37 @@ _Zk:
     assert isa_hazards.scan(bad.replace(";;#ASMSTART", "").replace(";;#ASMEND", "")) == []
 
 
+def test_scanner_follows_fall_through_into_a_labelled_block():
+    """A writer at the end of one block and an asm reader at the top of the next: entered by fall-through there is no
+    branch in between (advisor, round 4: the scanner used to forget every writer at a label)."""
+    split = """
+_Zkernel:
+	v_dot4_u32_u8 v7, v49, s29, v7
+	s_cbranch_scc1 .LBB0_9
+.LBB0_2:
+	;;#ASMSTART
+	v_cvt_f32_ubyte2 v11, v7
+	;;#ASMEND
+"""
+    found = isa_hazards.scan(split)
+    assert len(found) == 1 and found[0][3] == "v_dot4_u32_u8" and found[0][1] == 1
+    # the block above ends in an unconditional branch: this block is only ever reached by a taken branch
+    assert isa_hazards.scan(split.replace("s_cbranch_scc1 .LBB0_9", "s_branch .LBB0_9")) == []
+    # enough instructions in between, across the label
+    assert isa_hazards.scan(split.replace(".LBB0_2:", "v_mov_b32 v1, v2\n.LBB0_2:\n\tv_mov_b32 v3, v4")) == []
+    # a loop: the writer at the bottom, the reader at the head, the back edge a taken branch -- but the first entry falls in
+    loop = """
+_Zk2:
+	v_mfma_f32_32x32x8_f16 v[0:15], v[20:21], v[22:23], v[0:15]
+.LBB1_1:
+	;;#ASMSTART
+	v_add_f32 v30, v3, v31
+	;;#ASMEND
+	s_cbranch_vccnz .LBB1_1
+"""
+    assert len(isa_hazards.scan(loop)) == 1
+
+
 def sources_with_asm_instructions():
     from vslam_amd import build
     out = []

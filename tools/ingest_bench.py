@@ -45,7 +45,7 @@ def main():
     for label in ("warm-up", "timed"):
         t0 = time.perf_counter()
         try:
-            frames, pairs, secs = records.run_sequence(vid, rec, args.width, args.height, args.batch, args.keypoints, args.hyp,
+            frames, pairs, secs, _ = records.run_sequence(vid, rec, args.width, args.height, args.batch, args.keypoints, args.hyp,
                                                        10.0, 1, devices=[0] * args.slots if args.slots > 0 else None)
         except RuntimeError as e:
             sys.exit(str(e))

@@ -29,7 +29,7 @@ def _regs(tok):
 
 def scan(text, need=3):
     found = []
-    fn, last, pos, in_asm = None, {}, 0, False
+    fn, last, pos, in_asm, prev_op = None, {}, 0, False, None
     for ln in text.splitlines():
         s = ln.strip()
         if not s:
@@ -45,16 +45,24 @@ def scan(text, need=3):
         if s.endswith(":") or (":" in s and s.split(":")[0].startswith((".LBB", "_Z"))):
             name = s.split(":")[0]
             if name.startswith(".LBB") or name.startswith(".L"):
-                last = {}            # a label: predecessors unknown; the compiler pads across blocks for its own instructions,
-                continue             # and an asm statement at a block's head is at least a branch away from any writer
+                # A label.  A block entered by FALL-THROUGH (a loop header, the join behind an if) adds no cycles: a writer at
+                # the end of the block above is as close to a reader at the top of this one as the instruction count says, so
+                # the writer table is kept (advisor, round 4: it used to be dropped at every label -- the stale-VGPR fault seen in
+                # blur.hip could have hidden behind one).  Only when the block above cannot fall through -- it ends in an
+                # unconditional s_branch, s_setpc or s_endpgm -- is every way in a taken branch, which is more wait states
+                # than any of these hazards needs, and the table starts empty.
+                if prev_op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                    last = {}
+                continue
             if not name.startswith("."):
-                fn, last, pos = name, {}, 0
+                fn, last, pos, prev_op = name, {}, 0, None
             continue
         if s.startswith("."):
             continue
         parts = s.split(None, 1)
         op = parts[0]
         args = parts[1].split(",") if len(parts) > 1 else []
+        prev_op = op
         if op == "s_nop":
             pos += int(args[0].split(";")[0]) + 1
             continue

@@ -362,10 +362,13 @@ SequenceStats run_range(vslam_ctx *ctx, int in, bool regular, uint64_t first_fra
         const int pairs = frames - 1;
         for (int i = 0; i < pairs; i++) h_seeds[i] = o.seed ^ (uint32_t)(first + (uint64_t)i);
         check(ctx, vslam_copy_h2d(ctx, d_seeds.p, h_seeds.data(), sizeof(uint32_t) * (size_t)pairs), "seed upload");
-        check(ctx, vslam_frontend_sequence(ctx, dbuf[b], frames, o.width, o.height, 3 * o.width, &params, K, d_seeds.p,
-                                              o.hypotheses, o.threshold, d_xy.p, d_desc.p, d_nodes.p, d_n.p, d_matches.p,
-                                              d_best.p, d_F.p),
-                      "frontend_sequence");
+        auto enqueue_batch = [&] {
+            check(ctx, vslam_frontend_sequence(ctx, dbuf[b], frames, o.width, o.height, 3 * o.width, &params, K, d_seeds.p,
+                                                  o.hypotheses, o.threshold, d_xy.p, d_desc.p, d_nodes.p, d_n.p, d_matches.p,
+                                                  d_best.p, d_F.p),
+                          "frontend_sequence");
+        };
+        enqueue_batch();
         t_enq = ms_since(t_iter);
         // the next batch goes up while this one is computed
         bool have_next = false;
@@ -374,6 +377,24 @@ SequenceStats run_range(vslam_ctx *ctx, int in, bool regular, uint64_t first_fra
             if (have_next) check(ctx, vslam_upload_async(ctx, dbuf[b ^ 1], hbuf[b ^ 1], frame_bytes * (size_t)next_frames), "upload");
         }
         t_filled = ms_since(t_iter);
+        {
+            // The batch's status.  The one failure a well-formed call can meet is VSLAM_ERR_CAPACITY: more frames of this batch
+            // overflowed the corner detector's bounded lists (plateaus, pure noise) than its whole-image fallback pool holds;
+            // those frames came back without corners.  The frames are still on the device: do the batch again with every list
+            // sized for the whole image (nothing can overflow; 16 bytes per pixel and frame of workspace, for this batch
+            // shape from now on) -- the records are then what an unbounded run gives, and the file goes on.
+            const int rc = vslam_ctx_synchronize(ctx);
+            if (rc == VSLAM_ERR_CAPACITY) {
+                check(ctx, vslam_ctx_set_option(ctx, VSLAM_OPT_CORNER_LIST_CAP, -1), "set_option");
+                enqueue_batch();
+                const int rc2 = vslam_ctx_synchronize(ctx);
+                (void)vslam_ctx_set_option(ctx, VSLAM_OPT_CORNER_LIST_CAP, 0);
+                check(ctx, rc2, "frontend_sequence (whole-image corner lists)");
+                stats.batches_redone++;
+            } else {
+                check(ctx, rc, "frontend_sequence");
+            }
+        }
         check(ctx, vslam_copy_d2h(ctx, h_best.data(), d_best.p, sizeof(int32_t) * 4 * (size_t)pairs), "download");
         check(ctx, vslam_copy_d2h(ctx, h_F.data(), d_F.p, sizeof(float) * 9 * (size_t)pairs), "download");
         check(ctx, vslam_copy_d2h(ctx, h_matches.data(), d_matches.p, sizeof(int32_t) * 2 * (size_t)pairs * K), "download");
@@ -506,6 +527,7 @@ SequenceStats run_sequence_devices(const std::string &video_path, const std::str
         for (const PairRecord &r : s.records) writer.append(r);
         stats.pairs += s.stats.pairs;
         stats.batches += s.stats.batches;
+        stats.batches_redone += s.stats.batches_redone;
     }
     writer.close();
     stats.frames = stats.pairs ? stats.pairs + 1 : std::min<uint64_t>(input.frames, 1);
@@ -514,6 +536,11 @@ SequenceStats run_sequence_devices(const std::string &video_path, const std::str
 }
 
 }  // namespace vslam
+
+namespace {
+std::atomic<uint64_t> g_last_redone{0};   // SequenceStats::batches_redone of the last call through a C entry point
+}
+extern "C" uint64_t vslam_host_last_batches_redone(void) { return g_last_redone.load(); }
 
 extern "C" int vslam_host_run_sequence(const char *video_path, const char *record_path, int width, int height,
                                        int batch_frames, int max_corners, int hypotheses, float threshold,
@@ -530,6 +557,7 @@ extern "C" int vslam_host_run_sequence(const char *video_path, const char *recor
         o.seed = seed;
         o.max_frames = max_frames;
         const vslam::SequenceStats s = vslam::run_sequence(video_path ? video_path : "", record_path ? record_path : "", o);
+        g_last_redone = s.batches_redone;
         if (frames_out) *frames_out = s.frames;
         if (pairs_out) *pairs_out = s.pairs;
         if (seconds_out) *seconds_out = s.seconds;
@@ -561,6 +589,7 @@ extern "C" int vslam_host_run_sequence_devices(const char *video_path, const cha
         o.max_frames = max_frames;
         const vslam::SequenceStats s = vslam::run_sequence_devices(video_path ? video_path : "", record_path ? record_path : "", o,
                                                                    std::vector<int>(devices, devices + n_devices));
+        g_last_redone = s.batches_redone;
         if (frames_out) *frames_out = s.frames;
         if (pairs_out) *pairs_out = s.pairs;
         if (seconds_out) *seconds_out = s.seconds;

@@ -55,7 +55,8 @@ def read_records(path):
 def run_sequence(video_path, record_path, width, height, batch_frames, max_corners, hypotheses, threshold, seed,
                  max_frames=0, devices=None):
     """vslam::run_sequence (devices None) / vslam::run_sequence_devices (a list of device indices, one context each) through
-    their C entry points in libvslam_host.so: raw BGR24 file in, record file out.  -> (frames, pairs, seconds).
+    their C entry points in libvslam_host.so: raw BGR24 file in, record file out.  -> (frames, pairs, seconds,
+    batches redone with whole-image corner lists after a VSLAM_ERR_CAPACITY).
     Raises RuntimeError with the library's message."""
     import ctypes
     from . import build
@@ -73,4 +74,5 @@ def run_sequence(video_path, record_path, width, height, batch_frames, max_corne
         rc = lib.vslam_host_run_sequence_devices(*head, dev, len(devices), *tail)
     if rc != 0:
         raise RuntimeError(err.value.decode())
-    return frames.value, pairs.value, secs.value
+    lib.vslam_host_last_batches_redone.restype = ctypes.c_uint64
+    return frames.value, pairs.value, secs.value, int(lib.vslam_host_last_batches_redone())
