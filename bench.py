@@ -84,7 +84,7 @@ INT32_PEAK_TOPS = FP32_PEAK_TFLOPS / 2.0       # one 32-bit integer op per lane 
 INT8_MFMA_PEAK_TOPS = 5000.0                   # dense int8 MFMA (MI355X_MICROARCH.md: about 2x the 2.5 PFLOP/s bf16 rate)
 FP4_MFMA_PEAK_TOPS = 10000.0                   # dense FP4 / FP6 MFMA (MI355X_MICROARCH.md: about 10 PF; v_mfma_scale_f32_32x32x64_f8f6f4)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 SQ_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.csv")
 PMC_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_hbm_traffic.csv")
 STAMP_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_source_stamp.txt")
@@ -94,7 +94,8 @@ SOLVE_WORK = os.path.join(ROOT, "profiles", PROFILE_TAG + "_solve_work.json")
 def solve_flops():
     """Floating-point operations of one compute_fundamental (src/RansacFilter.cpp:69-103) on the bench's data, COUNTED:
     tools/solve_flops.py has the oracle count Jacobi visits and rotations of both SVDs over 24 576 hypotheses and applies
-    the per-visit / per-rotation operation counts written out there (profiles/r04_solve_work.json; SURVEY 8(d) guessed 3000)."""
+    the per-visit / per-rotation operation counts written out there (profiles/r05_solve_work.json = round 4's count: the
+    arithmetic has not changed; SURVEY 8(d) guessed 3000)."""
     try:
         with open(SOLVE_WORK) as fh:
             return float(json.load(fh)["flop_per_hypothesis"])
