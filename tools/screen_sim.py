@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""could an APPROXIMATE 8-point solve (the Gram / MFMA one of DESIGN 5.3, or any other) serve as
+"""could an APPROXIMATE 8-point solve (the Gram / MFMA one -- DESIGN.md 5, HISTORY.md notes 5.3 -- or any other) serve as
 a SCREEN in front of the exact Jacobi replay?  Idea: solve every hypothesis approximately (F~), bound every match's
 residual from below over all F within delta of F~, and run the exact solve only for hypotheses whose certified upper bound
 of the inlier count still reaches the best verified count.  That is sound only if |F_exact - F~| <= delta is KNOWN for the
