@@ -52,7 +52,7 @@ def algorithmic_bytes(kernel, w, h, K, H, M, gray_fused=False):
         "corner_select_kernel": 2 * (K * 8),
         "gaussian7_kernel": 2 * (px + px),
         "keypoint_border_kernel": 2 * (K * 8 * 2),
-        "rbrief_kernel": 2 * (K * 8 + K * 32),
+        "rbrief_kernel": 2 * (px + K * 8 + K * 32),   # the blurred image in (every 128 x 128 tile holds keypoints), keypoints in, descriptors out
         "kdtree_build_kernel": 2 * (K * 8 + K * 4),
         "match_knn2_kernel": 2 * K * 32 + K * 4,
         "match_compact_kernel": K * 4 + K * 8,

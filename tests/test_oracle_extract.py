@@ -26,6 +26,12 @@ def images():
     step[:, 50:] = 255
     step[40:, :] = 255 - step[40:, :]
     yield "checker-corner", step
+    # photographs (tests/golden/real_v1.npz: public-domain images, round 5): windows with a saturated night sky, skin and
+    # porcelain gradients, JPEG block structure -- content the synthetic textures do not have
+    import os
+    real = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_v1.npz"))
+    for i, (y0, x0) in enumerate([(40, 60), (200, 300), (100, 10), (300, 200)]):
+        yield f"photo-{str(real['names'][i]).split('.')[0]}", np.ascontiguousarray(real[f"crop{i}"][y0:y0 + 150, x0:x0 + 200])
 
 
 # ------------------------------------------------------------------------------------------------ cvtColor (:56)
