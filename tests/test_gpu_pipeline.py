@@ -228,3 +228,16 @@ def test_pipeline_cpp_surface(batches, reference, tmp_path):
         if r["rc"] == 0:
             assert np.array_equal(Fm.view(np.uint32), r["F"].view(np.uint32)) and inl == k, i
     assert off == len(buf)
+
+
+def test_the_cpp_example_runs(tmp_path):
+    """examples/batches_in_flight.cpp builds against the installed headers and library and collects every record."""
+    exe = str(tmp_path / "batches_in_flight")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "examples", "batches_in_flight.cpp"),
+                    "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vslam_amd"), "-lvslam_amd",
+                    "-Wl,-rpath," + os.path.join(ROOT, "vslam_amd")], check=True)
+    r = subprocess.run([exe, "7", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "21 records" in r.stdout
+    first = [ln for ln in r.stdout.splitlines() if ln.startswith("pair 0:")]
+    assert first and "hypothesis -1" not in first[0], r.stdout       # the shifted scene gives a model
