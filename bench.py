@@ -6,7 +6,7 @@ frame pairs already resident in HBM.  N = 1 runs BASELINE.json configs[2] (1280x
 keypoints, 4096 hypotheses, batch 256); with N > 1 every rank runs the same per-GPU batch on its
 own shard (weak scaling, configs[3]) and the per-pair result records are gathered with the
 library's own collective (vslam_gather_records: RCCL all-gather on the batch's stream).
-Steps are handed round-robin to the contexts of a vslam_pipeline (--in-flight, default 3): each
+Steps are handed round-robin to the contexts of a vslam_pipeline (--in-flight, default 4): each
 batch in flight has its own frames, outputs and communicator; the timed region ends when every
 batch is complete.  The data is SURVEY 8(d)'s regime (--data hard) since round 5.
 
@@ -402,7 +402,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU and batch (default: the workload's batch)")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU: contexts of the vslam_pipeline the steps are handed to round-robin "
                          "(1 = one batch after the other on one context, the arrangement of rounds 1-4)")
     ap.add_argument("--cpu-pairs", type=int, default=150,

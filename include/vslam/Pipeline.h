@@ -2,7 +2,7 @@
 //
 // The reference's capture loop takes a frame, extracts, matches it against the previous one and only then looks at the
 // next (src/vslam.cpp:53-77).  A device wants several batches queued at once: the stages of one batch that leave most of
-// the chip idle are filled by the arithmetic of another (2.87 -> 2.60 ms per batch of 256 pairs at 1280x720 with three
+// the chip idle are filled by the arithmetic of another (2.90 -> 2.61 ms per batch of 256 pairs at 1280x720 with four
 // in flight).  vslam::Pipeline keeps `in_flight` contexts and, per context, the device and page-locked buffers of one
 // batch; submit_pairs() returns at once with a ticket, collect() waits for that batch and hands back its records.
 //

@@ -370,8 +370,8 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
  * The reference's capture loop (src/vslam.cpp:53-77) finishes one frame pair before it looks at the next.  On the device
  * a batch runs through stages that fill the chip and stages of one workgroup per frame or pair that leave most of it
  * idle; the entry points are stream-ordered and a context owns its streams and workspaces, so a caller with a queue of
- * batches keeps k of them in flight on k contexts and the idle parts of one are filled by another (2.87 -> 2.60 ms per
- * batch at the headline shape with k = 3).  A TICKET is one batch:
+ * batches keeps k of them in flight on k contexts and the idle parts of one are filled by another (2.90 -> 2.61 ms per
+ * batch at the headline shape with k = 4; contexts made here are arranged for company: DESIGN.md 6).  A TICKET is one batch:
  *   vslam_pipeline_acquire   next context, round-robin; waits for the batch that used it k tickets ago (at most k batches
  *                            are ever queued) and files that batch's status.  Enqueue the batch on the context returned --
  *                            any entry points of this header, uploads and vslam_gather_records included;

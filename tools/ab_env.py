@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Context-level knobs with batches in flight, one process, alternating blocks: what helped one batch at a time (forks onto
+"""TRAP (round 5): pipelines made one after the other in ONE process do not get the same hardware queues -- three identical
+ones ran at 2.917 / 2.669 / 2.749 ms per batch -- so this tool cannot compare anything that touches streams or their order of
+creation; use tools/ab_proc.sh (fresh process per configuration) for that.
+
+Context-level knobs with batches in flight, one process, alternating blocks: what helped one batch at a time (forks onto
 the auxiliary stream, stream priorities) may not with three batches filling each other's holes.
     python tools/ab_env.py [C3] [in_flight] [rounds] [hard|easy]"""
 import os
@@ -35,6 +39,19 @@ CONFIGS = {
     "no priorities, trees behind matcher, blur on main": (dict(NP, VSLAM_OVERLAP_BLUR="0"), {C.OPT_TREE_FORK: 1}, True),
     "no priorities, no trees, blur on main": (dict(NP, VSLAM_OVERLAP_BLUR="0"), {}, False),
 }
+if os.environ.get("AB_SET") == "shared":   # variations around what vslam_pipeline_create chooses by itself (no knob forced)
+    CONFIGS = {
+        "default": (None, {}, True),
+        "matcher 4 x 64": (None, {C.OPT_MATCH_SHAPE: 2}, True),
+        "trees behind the matcher": (None, {C.OPT_TREE_FORK: 1}, True),
+        "trees in line": (None, {C.OPT_TREE_FORK: 5}, True),
+        "generator in line": ({"VSLAM_SETS_PREFETCH": "0"}, {}, True),
+        "corner window 120 %": (None, {C.OPT_CORNER_WINDOW_PCT: 120}, True),
+        "corner window 160 %": (None, {C.OPT_CORNER_WINDOW_PCT: 160}, True),
+        "default again (order check)": (None, {}, True),
+    }
+if os.environ.get("AB_SET") == "order":   # is the first pipeline made in a process slower than the same made later?
+    CONFIGS = {"default": (None, {}, True), "same, made second": (None, {}, True), "same, made third": (None, {}, True)}
 if os.environ.get("AB_SET") == "prio":
     CONFIGS = {
         "default": ({}, {}, True),
@@ -53,9 +70,14 @@ pipes = {}
 for name, (env, opts, _) in CONFIGS.items():
     # explicit values for every knob: "default" here is the ONE-batch-at-a-time arrangement (priorities, blur and k-d build
     # forked), whatever vslam_pipeline_create would choose by itself
-    os.environ.update({"VSLAM_OVERLAP_BLUR": "2", "VSLAM_STREAM_PRIORITY": "1", "VSLAM_SETS_PREFETCH": "1"})
-    os.environ.update(env)
-    opts = {**{C.OPT_TREE_FORK: 1 if K <= 2048 else 0}, **opts}
+    for k_ in ("VSLAM_OVERLAP_BLUR", "VSLAM_STREAM_PRIORITY", "VSLAM_SETS_PREFETCH"):
+        os.environ.pop(k_, None)
+    if os.environ.get("AB_SET") in ("shared", "order"):
+        os.environ.update(env or {})
+    else:
+        os.environ.update({"VSLAM_OVERLAP_BLUR": "2", "VSLAM_STREAM_PRIORITY": "1", "VSLAM_SETS_PREFETCH": "1"})
+        os.environ.update(env)
+        opts = {**{C.OPT_TREE_FORK: 1 if K <= 2048 else 0}, **opts}
     pipes[name] = capi.Pipeline(0, depth)
     for o, v in opts.items():
         pipes[name].set_option(o, v)

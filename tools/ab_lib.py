@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Step time of TWO BUILDS of the library in one process, alternating in short blocks (clock drift and box-to-box
+"""TRAP (round 5): pipelines made one after the other in ONE process do not get the same hardware queues -- three identical
+ones ran at 2.917 / 2.669 / 2.749 ms per batch -- so this tool cannot compare anything that touches streams or their order of
+creation; use tools/ab_proc.sh (fresh process per configuration) for that.
+
+Step time of TWO BUILDS of the library in one process, alternating in short blocks (clock drift and box-to-box
 differences cancel): each build runs the bench's arrangement -- a vslam_pipeline with N batches in flight -- on the hard and
 the easy data at C3 (or C5 / C2).
     python tools/ab_lib.py tools/_ab/base.so vslam_amd/libvslam_amd.so [C3] [in_flight] [rounds]

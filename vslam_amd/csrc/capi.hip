@@ -60,7 +60,7 @@ int vs_aux_job_point(vslam_ctx *ctx, int point) {
 // is the longer one, 1.30 against 1.08 ms) 15.26 in front, 15.31 behind.  So: behind the matcher up to 2048 keypoint slots.
 static int vs_defer_tree_build(vslam_ctx *ctx, const float *d_xy, const int32_t *d_n, int frames, int kp_stride, int32_t *d_nodes) {
     ctx->aux_job = [=]() { return vs_launch_kdtree_build(ctx, d_xy, d_n, frames, kp_stride, d_nodes); };
-    ctx->aux_job_at = ctx->tree_fork >= 0 ? ctx->tree_fork : (ctx->call_small ? 0 : (kp_stride <= 2048 ? 1 : 0));
+    ctx->aux_job_at = ctx->tree_fork >= 0 ? ctx->tree_fork : (kp_stride <= 2048 ? 1 : 0);
     return vs_aux_job_point(ctx, 0);
 }
 struct VsAuxGuard {   // a job that was never forked (an error return in between) must not outlive the call that made it
@@ -171,25 +171,33 @@ int vslam_ctx_create(int device, vslam_ctx **out) { return vs_ctx_create(device,
 }  // extern "C"
 
 // shared_chip: the context is one of several that keep batches in flight on the same device (vslam_pipeline_create).  What
-// pays for one batch at a time -- the blur and the k-d build forked onto a low-priority auxiliary stream so that they fill
-// the holes of the batch's own latency-bound stages -- costs with three: the holes are filled by the other batches, and
-// every fork / join between queues is a hand-over of 50-120 us.  Measured, three batches in flight, hard data, one process,
-// alternating blocks (tools/ab_env.py, tools/ab_lib.py): C3 (512 frames of 1280x720) the single-batch arrangement 2.751 ms per
-// batch; blur on the main stream, k-d build in front of the matcher, all streams at one priority 2.643 (each alone: +0.001 /
-// -0.054 / -0.042); C2 (128 frames of 640x480) 0.412 -> 0.343.  At C5 (1024 frames of 1920x1080) the kernels are five
-// times longer, the hand-overs weigh less and the forks still pay: 14.32 ms against 14.51 without them.  So a shared-chip
-// context decides per call, by the pixels of the batch (vs_arrange_call); its main stream runs at the default priority and
-// it owns two auxiliary streams, one below that and one level with it.
-constexpr double kSharedSmallPixels = 1.0e9;
-void vs_arrange_call(vslam_ctx *ctx, long long frames, int w, int h) {
-    if (!ctx->shared_chip) return;
-    ctx->call_small = (double)frames * w * h <= kSharedSmallPixels;
-    ctx->aux_stream = ctx->call_small ? ctx->aux_flat : ctx->aux_low;
+// pays for one batch at a time -- the blur forked onto a low-priority auxiliary stream so that it fills the holes of the
+// batch's own latency-bound stages -- does not with several: the holes are filled by the other batches, and every fork / join
+// between queues is a hand-over of 50-120 us.  Such a context keeps its blur on the main stream, runs its auxiliary stream
+// (generator, k-d build) at the main stream's priority, and makes no stream it may never use (vs_copy_stream).
+// Measured with FRESH PROCESSES per configuration (tools/ab_proc.sh; which hardware queue a stream lands on depends on what
+// the process created before it, and that alone moves a step by up to 9 %, so configurations compared inside one process
+// are not comparable), SURVEY 8(d) data, ms per batch, four in flight: C3 2.61 against 2.69-2.74 for plain contexts, C2 0.304
+// against 0.35-0.37, C5 14.2-14.5 either way.  Variations at C3, three in flight (this arrangement 2.65): blur forked 2.68,
+// k-d build in front of the matcher 2.69, behind the set mapping 2.70, behind the solves 2.73, in line with the generator
+// in line 2.72-2.76; the main streams at high priority (a hardware-queue pool of their own) 2.79; an idle fourth stream per
+// context 2.85; GPU_MAX_HW_QUEUES 2 / 3 / 6 instead of the runtime's 4: 2.81 / 2.73 / 2.71.
+
+// The copy stream of a context that keeps batches in flight is made on first use.  Every stream a process holds takes a
+// place in the runtime's pool of hardware queues (GPU_MAX_HW_QUEUES = 4 per priority level, streams beyond that share the
+// least used one), so streams that are never used still decide which of the USED streams end up sharing a queue -- and two
+// streams on one hardware queue run one after the other.  Measured in fresh processes (tools/ab_proc.sh, three batches in
+// flight at C3): the same kernels and forks 2.69 ms per batch with three streams per context, 2.85 with a fourth that is idle.
+static int vs_copy_stream(vslam_ctx *ctx, hipStream_t *out) {
+    if (!ctx->copy_stream) VS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    *out = ctx->copy_stream;
+    return VSLAM_OK;
 }
 
 int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
     if (!out) return VSLAM_ERR_INVALID;
     *out = nullptr;
+    if (const char *e = getenv("VSLAM_SHARED_CHIP")) shared_chip = shared_chip && e[0] != '0';   // A/B: pipeline contexts as plain ones
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return VSLAM_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return VSLAM_ERR_INVALID;
@@ -204,37 +212,36 @@ int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
         if (e[0] == '0') prio_least = prio_greatest = 0;
         if (e[0] == '2') prio_greatest = 0;   // main at the default priority, auxiliary below it
     }
-    if (shared_chip) prio_greatest = 0;   // the main streams of all the contexts at the default priority
+    bool shared_main_high = false;
+    if (const char *e = getenv("VSLAM_STREAM_PRIORITY")) shared_main_high = e[0] == '3';   // A/B: shared-chip mains above their auxiliaries
+    if (shared_chip) {
+        prio_least = 0;   // the auxiliary stream level with the main one, the main streams of all contexts at the default priority
+        if (!shared_main_high) prio_greatest = 0;
+    }
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
     ctx->own_stream = true;
-    if (shared_chip) {
-        if (hipStreamCreateWithPriority(&ctx->aux_flat, hipStreamNonBlocking, 0) != hipSuccess) {
-            delete ctx;
-            return VSLAM_ERR_HIP;
-        }
-    }
     if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
-    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+    ctx->lazy_streams = shared_chip;   // streams a context may never use are made on first use (see vs_copy_stream)
+    if (const char *e = getenv("VSLAM_LAZY_STREAMS")) ctx->lazy_streams = e[0] != '0';
+    if ((!ctx->lazy_streams && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&ctx->ev_raw, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return VSLAM_ERR_HIP;
     }
     ctx->shared_chip = shared_chip;
-    ctx->aux_low = ctx->aux_stream;
-    if (const char *e = getenv("VSLAM_OVERLAP_BLUR")) {
-        ctx->overlap_blur = e[0] - '0';
-        ctx->blur_forced = true;
-    }
+    if (shared_chip) ctx->overlap_blur = 0;
+    if (const char *e = getenv("VSLAM_OVERLAP_BLUR")) ctx->overlap_blur = e[0] - '0';
     if (const char *e = getenv("VSLAM_SETS_PREFETCH")) ctx->sets_prefetch = e[0] != '0';
+    if (const char *e = getenv("VSLAM_TREE_FORK")) ctx->tree_fork = atoi(e);   // A/B across processes (the option does the same)
     if (const char *e = getenv("VSLAM_RANSAC_SOLVE_SPLIT")) ctx->solve_split = atoi(e);
     *out = ctx;
     return VSLAM_OK;
@@ -259,11 +266,10 @@ int vslam_ctx_destroy(vslam_ctx *ctx) {
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    for (hipStream_t a : {ctx->shared_chip ? ctx->aux_low : ctx->aux_stream, ctx->aux_flat})
-        if (a) {
-            (void)hipStreamSynchronize(a);
-            (void)hipStreamDestroy(a);
-        }
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
@@ -410,11 +416,14 @@ int vslam_host_free(vslam_ctx *ctx, void *h_ptr) {
 int vslam_upload_async(vslam_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (!ctx) return VSLAM_ERR_INVALID;
     VS_REQUIRE(ctx, d_dst && h_src, VSLAM_ERR_INVALID);
-    if (bytes) VS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    hipStream_t cs = nullptr;
+    if (int rc = vs_copy_stream(ctx, &cs)) return rc;
+    if (bytes) VS_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, cs));
     return VSLAM_OK;
 }
 int vslam_upload_fence(vslam_ctx *ctx) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    if (!ctx->copy_stream) return VSLAM_OK;   // nothing was ever uploaded
     VS_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->copy_stream));
     VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
     return VSLAM_OK;
@@ -427,7 +436,7 @@ int vslam_download_async(vslam_ctx *ctx, void *h_dst, const void *d_src, size_t 
 }
 int vslam_upload_wait(vslam_ctx *ctx) {
     if (!ctx) return VSLAM_ERR_INVALID;
-    VS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->copy_stream) VS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return VSLAM_OK;
 }
 
@@ -612,8 +621,7 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     // cvtColor (:56) is the detector's first kernel (or a launch of its own in front of it, for layouts that one does not take).
     // The blur needs only the gray image: run it on the auxiliary stream beside corner detection, whose
     // selection stage is latency-bound and leaves most of the chip idle (not while per-kernel timing is on).
-    vs_arrange_call(ctx, frames, width, height);
-    const bool overlap = ctx->overlap_blur > 0 && !ctx->prof && !(ctx->call_small && !ctx->blur_forced);
+    const bool overlap = ctx->overlap_blur > 0 && !ctx->prof;
     const VsBgrSource src{d_bgr, row_stride};
     ctx->fork_after_eigen = overlap;
     rc = vs_launch_good_features(ctx, gray, frames, width, height, params->max_corners,                  // :56, :61
@@ -777,7 +785,6 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     // auxiliary stream beside the matching stages (fork after extraction, join at the end).  With
     // per-kernel timing on, everything stays on one stream so the event brackets are clean.
     const bool overlap = d_nodes && !ctx->prof && ctx->tree_fork != 5;   // 5: in line on the main stream, at the end of extraction
-    vs_arrange_call(ctx, 2LL * pairs, width, height);
     int rc = vs_sets_prefetch(ctx, d_seeds, pairs, hyp);
     if (rc) return rc;
     rc = vslam_extract_features(ctx, d_bgr, 2 * pairs, width, height, row_stride, params, kp_stride,
@@ -837,7 +844,6 @@ int vslam_frontend_sequence(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, in
     VsPrefetchGuard prefetch_guard{ctx};
     VS_REQUIRE(ctx, frames >= 2, VSLAM_ERR_INVALID);
     const bool overlap = d_nodes && !ctx->prof && ctx->tree_fork != 5;   // k-d trees beside the matching stages, as in vslam_frontend_pairs
-    vs_arrange_call(ctx, frames, width, height);
     int rc = vs_sets_prefetch(ctx, d_seeds, frames - 1, hyp);
     if (rc) return rc;
     rc = vslam_extract_features(ctx, d_bgr, frames, width, height, row_stride, params, kp_stride, d_xy, d_desc,

@@ -47,12 +47,10 @@ struct vslam_ctx {
     int aux_job_at = 0;
     int tree_fork = -1;   // VSLAM_OPT_TREE_FORK: where the batched front-end forks the k-d build (-1: by size; 0 in front of the matcher)
     int overlap_blur = 2;       // VSLAM_OVERLAP_BLUR: 0 blur on the main stream, otherwise on the auxiliary stream from min_eigen (where the gray image is complete) on
-    // One of several contexts with batches in flight on this device (vs_ctx_create).  Such a context picks its arrangement
-    // per call (vs_arrange_call): small batches run without the intra-batch forks that only pay alone, large ones keep them.
+    // One of several contexts with batches in flight on this device (vs_ctx_create): blur on the main stream, the auxiliary
+    // stream at the main stream's priority, streams it may never use made on first use.
     bool shared_chip = false;
-    hipStream_t aux_low = nullptr, aux_flat = nullptr;   // shared_chip: the auxiliary stream at low / at the main stream's priority (aux_stream is one of them)
-    bool call_small = false;                             // shared_chip: this call takes the no-fork arrangement
-    bool blur_forced = false;                            // VSLAM_OVERLAP_BLUR given: the environment decides, not the call's size
+    bool lazy_streams = false;   // the copy stream is made on first use
     int solve_split = 0;        // VSLAM_RANSAC_SOLVE_SPLIT (read when the context is made): 0 one solve kernel, 4 / 5 sweeps + closing kernel
     bool sets_prefetch = true;  // VSLAM_SETS_PREFETCH: the raw mt19937 outputs generated ahead of time on the auxiliary stream
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
@@ -103,7 +101,6 @@ struct vslam_ctx {
 // reads and clears it and reports VSLAM_ERR_CAPACITY
 int vs_device_errflag(vslam_ctx *ctx, int32_t **out);
 int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out);   // vslam_ctx_create = (device, false, out)
-void vs_arrange_call(vslam_ctx *ctx, long long frames, int w, int h);   // shared_chip contexts: choose this call's arrangement
 std::string vs_errflag_message(int32_t flag);
 
 // fork the pending auxiliary job (if it was asked for at `point`) onto the auxiliary stream behind everything queued so far

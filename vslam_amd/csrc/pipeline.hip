@@ -5,7 +5,7 @@
 // 8-point solves) and kernels of one workgroup per frame or pair that leave most of it idle (selection, the closing RANSAC
 // stages).  Every entry point is stream-ordered and a context owns its streams and workspaces, so the idle parts of one
 // batch can be filled by the arithmetic of another: k contexts, batches handed to them round-robin, each batch's outputs
-// in buffers the caller owns.  Measured at the headline shape, SURVEY 8(d) data: 2.90 ms per batch on one context, 2.64 with three.
+// in buffers the caller owns.  Measured at the headline shape, SURVEY 8(d) data: 2.90 ms per batch on one context, 2.61 with four in flight.
 //
 // A ticket is one batch.  acquire() hands out the next context (waiting for the batch that used it k tickets ago, which
 // bounds the queue at k batches), the caller enqueues whatever belongs to the batch on it, commit() closes the batch: the
