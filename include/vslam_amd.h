@@ -115,7 +115,8 @@ const int8_t *vslam_brief_pattern_31(void);
 /*   VSLAM_OPT_TREE_FORK  where vslam_frontend_pairs / _sequence start the k-d build (an output of the path that no later
  *       stage reads) on the auxiliary stream: -1 (default) by size (behind the matcher up to 2048 keypoint slots, in front
  *       of it above), 0 in front of the matcher, 1 behind it, 2 behind the set mapping, 3 behind the 8-point solves,
- *       4 behind the screen.  The call's last kernel waits for it.  Same results; a tuning knob.                       */
+ *       4 behind the screen, 5 not forked at all (in line on the main stream, at the end of extraction).  The call's last
+ *       kernel waits for it.  Same results; a tuning knob.                                                             */
 #define VSLAM_OPT_TREE_FORK 9
 int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value);
 

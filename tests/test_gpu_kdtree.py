@@ -156,7 +156,7 @@ def test_trees_of_the_batched_front_end_for_every_fork_point(ctx, oracle, all_su
     ref = [oracle.extract_features(f, maxc, ca, sa, pat) for f in bgr_np]
     ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, all_sums)
     try:
-        for fork in (-1, 0, 1, 2, 3, 4):
+        for fork in (-1, 0, 1, 2, 3, 4, 5):
             ctx.set_option(ctx.OPT_TREE_FORK, fork)
             for form in ("pairs", "sequence"):
                 if form == "pairs":

@@ -2,7 +2,7 @@
 # calibration copies), SQ counters.  Usage (on the GPU box): bash tools/prof_all.sh <tag> [C3|C5|C2]
 # The counter passes and the per-kernel stats run ONE batch at a time on one context (--in-flight 1): rocprofv3 serialises
 # dispatches under --pmc anyway, and a kernel's duration is its own only when no other batch shares the chip -- which is
-# also how bench.py's HIP-event pass measures it.  A second stats pass takes the default command (three batches in flight).
+# also how bench.py's HIP-event pass measures it.  A second stats pass takes the default command (four batches in flight).
 set -e
 TAG=${1:-r05}
 WL=${2:-C3}
@@ -24,7 +24,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 echo sq done
 cd $R
 python3 tools/prof_summary.py $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_summary.csv > /dev/null
-python3 tools/prof_summary.py $(find $O/stats3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_in_flight3_summary.csv > /dev/null
+python3 tools/prof_summary.py $(find $O/stats3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_in_flight_summary.csv > /dev/null
 python3 tools/pmc_summary.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_hbm_traffic.csv > /dev/null
 python3 tools/sq_summary.py $(find $O/sq -name "*counter_collection.csv" | head -1) $O/sq_counters.csv
 python3 -c "import sys, json; sys.path.insert(0, '.'); import bench; print(json.dumps(bench.source_stamp(), indent=1))" > $O/source_stamp.txt
