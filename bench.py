@@ -634,22 +634,6 @@ def main():
         c.synchronize()
         return (time.perf_counter() - t1) / steps * 1e3, o
 
-    def timed_in_flight(pp, frames, pairs, kk, hh, sd, outs, steps=24):
-        """ms per batch with len(outs) batches in flight on pipeline pp (same frames for every context: a sweep, not the headline)."""
-        n = len(outs)
-        for i in range(2 * n):
-            t, c = pp.acquire()
-            c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=outs[i % n])
-            pp.commit(t)
-        pp.drain()
-        t1 = time.perf_counter()
-        for i in range(steps):
-            t, c = pp.acquire()
-            c.frontend_pairs(frames, pairs, kk, ca, sa, pat, sd, hh, thr, out=outs[i % n])
-            pp.commit(t)
-        pp.drain()
-        return (time.perf_counter() - t1) / steps * 1e3
-
     def profile_pass(c, frames, pairs, kk, hh, sd, psteps):
         """Per-kernel durations with HIP events on the kernels' own stream; one context, one batch after the other, so that a
         kernel's time is its own (with batches in flight the kernels of different batches share the chip)."""
@@ -808,21 +792,33 @@ def main():
     # full-evaluation worst case, the other workloads with their own per-kernel pass
     if rank == 0 and world == 1 and not args.no_extras:
         s0 = slots[0]
-        ms1, _ = timed_single(ctx, s0.bgr, P, K, H, s0.seeds, out=s0.out)
-        result["single_context"] = {"ms_per_step": ms1, "frame_pairs_per_s": P / ms1 * 1e3,
-                                    "what": "one batch after the other on one context (the headline arrangement of rounds 1-4), same data"}
+
+        def child(extra, timeout=600):
+            """Another configuration of this bench in a FRESH PROCESS (child, never exec): which hardware queue a stream lands on
+            depends on what a process created before it, and that mapping moves a step by several per cent -- a second pipeline made
+            in this process would not be comparable with the first (HISTORY.md, round 5).  Returns the child's line."""
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras", "--cpu-pairs", "0", "--cpu-all-cores-pairs", "0",
+                   "--data", args.data, "--solver", args.solver] + extra
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return None
+            return json.loads(lines[-1])
+
         sweep = {}
-        for d in (1, 2, 3, 4):
-            pp = pipe if d == n_slots else Pipeline(local_rank, d)
-            outs = [sl.out for sl in slots[:d]] + [Pipeline.alloc_outputs(torch, 2 * P, P, K, dev) for _ in range(max(0, d - n_slots))]
-            ms = timed_in_flight(pp, s0.bgr, P, K, H, s0.seeds, outs[:d])
-            same = all(torch.equal(o[k], outs[0][k]) for o in outs[1:d] for k in ("best", "F", "n"))
-            sweep[str(d)] = {"contexts": d, "ms_per_batch": ms, "frame_pairs_per_s": P / ms * 1e3, "outputs_identical_across_contexts": bool(same)}
-            if pp is not pipe:
-                pp.close()
-            del outs
-            torch.cuda.empty_cache()
+        for d in (1, 2, 3, 4, 6):
+            if d == n_slots and args.steps >= 20:
+                sweep[str(d)] = {"contexts": d, "ms_per_batch": ms_step, "frame_pairs_per_s": P / ms_step * 1e3, "from": "the timed loop above"}
+                continue
+            c = child(["--workload", args.workload, "--pairs", str(P), "--in-flight", str(d), "--steps", "40", "--warmup", "8", "--no-profile-pass"])
+            if c:
+                sweep[str(d)] = {"contexts": d, "ms_per_batch": c["ms_per_step"], "frame_pairs_per_s": c["value"],
+                                 "parity_in_bench": c["parity_in_bench"]["bit_exact"], "from": "a fresh process, 40 steps"}
         result["in_flight_sweep"] = sweep
+        if "1" in sweep:
+            result["single_context"] = {"ms_per_step": sweep["1"]["ms_per_batch"], "frame_pairs_per_s": sweep["1"]["frame_pairs_per_s"],
+                                        "what": "one batch after the other on one context (the headline arrangement of rounds 1-4), same data regime, fresh process"}
 
         def kernel_ms(c, frames, pairs, kk, hh, sd, names):
             rep = profile_pass(c, frames, pairs, kk, hh, sd, 1)
@@ -856,40 +852,28 @@ def main():
             regimes[kind] = entry
         result["data_regimes"] = regimes
         others = {}
-        for wl in sorted(WORKLOADS):
+        for wl in sorted(WORKLOADS):   # each in a process of its own (see child): headline arrangement, own per-kernel pass
             if wl == args.workload:
                 continue
             w2, h2, K2, H2, P2 = WORKLOADS[wl]
-            sd2 = 0x5EED0000 + sorted(WORKLOADS).index(wl)
-            p2 = Pipeline(local_rank, n_slots)
-            f2 = make_frames(sd2, P2, w2, h2, dev)
-            s2 = torch.from_numpy(shard.pair_seeds(sd2, 0, P2).view(np.int32)).to(dev)
-            o2 = [Pipeline.alloc_outputs(torch, 2 * P2, P2, K2, dev) for _ in range(n_slots)]
-            ms2 = timed_in_flight(p2, f2, P2, K2, H2, s2, o2, steps=12)
-            ms2_single, _ = timed_single(p2.contexts[0], f2, P2, K2, H2, s2, steps=6, out=o2[0])
-            b2 = o2[0]["best"].cpu().numpy()
-            nk2 = float(o2[0]["n"].float().mean().item())
-            m2 = float(b2[:, 3].mean())
-            rep2 = profile_pass(p2.contexts[0], f2, P2, K2, H2, s2, 1)
-            kt2 = kernel_table(rep2, 1, w2, h2, K2, H2, m2, P2)
-            entry = {"workload": f"{w2}x{h2}, {K2} keypoints, {H2} hypotheses, batch {P2} pairs, {args.data} data", "ms_per_step": ms2,
-                     "frame_pairs_per_s": P2 / ms2 * 1e3, "batches_in_flight": n_slots,
-                     "single_context": {"ms_per_step": ms2_single, "frame_pairs_per_s": P2 / ms2_single * 1e3},
-                     "workspace_bytes_per_context": p2.contexts[0].workspace_bytes(), "steps": 12, "mean_inlier_matches": m2,
-                     "degenerate": bool((b2[:, 0] < 0).any()),
-                     "kernels_ms_per_launch": {k["kernel"]: round(k["ms_per_launch"], 5) for k in kt2}}
-            by2 = {k["kernel"]: k for k in kt2}
-            top2 = kt2[0]
-            av2 = arithmetic_view(top2["kernel"], units_of(top2["kernel"], w2, h2, H2, P2, m2, nk2), top2["ms_per_launch"], False)
-            entry["dominant_kernel"] = {"kernel": top2["kernel"], "ms_per_launch": top2["ms_per_launch"],
-                                        "frac_algorithmic": av2["frac"] if av2 and "frac" in av2 else None,
-                                        "hbm_frac_algorithmic": top2["alg_GBps"] / HBM_PEAK_GBS}
-            if "match_knn2_kernel" in by2:
-                entry["roofline_match"] = match_view(by2["match_knn2_kernel"], units_of("match_knn2_kernel", w2, h2, H2, P2, m2, nk2), False)
+            c = child(["--workload", wl, "--in-flight", str(n_slots), "--steps", "24" if wl != "C5" else "12", "--warmup", "4"])
+            c1 = child(["--workload", wl, "--in-flight", "1", "--steps", "12" if wl != "C5" else "6", "--warmup", "2", "--no-profile-pass"])
+            if not c:
+                others[wl] = {"failed": True}
+                continue
+            kt = c.get("kernels", [])
+            entry = {"workload": c["config"]["workload"], "ms_per_step": c["ms_per_step"], "frame_pairs_per_s": c["value"],
+                     "batches_in_flight": n_slots, "steps": c["steps"], "parity_in_bench": c["parity_in_bench"],
+                     "single_context": {"ms_per_step": c1["ms_per_step"], "frame_pairs_per_s": c1["value"]} if c1 else None,
+                     "workspace_bytes_per_context": c["workspace_bytes_per_context"], "mean_inlier_matches": c["mean_inlier_matches"],
+                     "kernels_ms_per_launch": {k["kernel"]: round(k["ms_per_launch"], 5) for k in kt}}
+            if "roofline" in c:
+                rf = c["roofline"]
+                entry["dominant_kernel"] = {"kernel": rf["kernel"], "ms_per_launch": rf["avg_launch_ms"], "frac_algorithmic": rf.get("frac_algorithmic"),
+                                            "hbm_frac_algorithmic": (rf.get("hbm") or {}).get("frac", rf["frac"] if rf["bound"] == "hbm" else None)}
+            if "roofline_match" in c:
+                entry["roofline_match"] = c["roofline_match"]
             others[wl] = entry
-            p2.close()
-            del f2, o2, p2
-            torch.cuda.empty_cache()
         result["other_workloads"] = others
     if multi:
         dist.barrier()
