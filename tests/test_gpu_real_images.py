@@ -83,3 +83,60 @@ def test_stage_outputs_on_photographs(ctx, oracle, real):
         assert np.array_equal(gray[f], ref), f
         assert np.array_equal(eig[f].view(np.uint32), oracle.min_eigen(ref).view(np.uint32)), f
         assert np.array_equal(blur[f], oracle.gaussian7(ref)), f
+
+
+def test_grid_orb_extractor_on_photographs(ctx, oracle, real):
+    """extract_features(Frame&, nrows, ncols) (src/Frame.cpp:16-51: outlines drawn into the image, ORB's pyramid, FAST, Harris
+    ranking, retainBest, intensity-centroid angles, steered BRIEF) on the photographic frames: everything bit-exact."""
+    _, bgr = real
+    pat = synth.brief_pattern()
+    for nrows, ncols, frames in ((3, 4, bgr[:4]), (1, 2, bgr[4:6])):
+        dev = torch.from_numpy(np.ascontiguousarray(frames).copy()).cuda()
+        out = ctx.extract_features_grid(dev, nrows, ncols, torch.from_numpy(pat).cuda(), 16384)
+        ctx.synchronize()
+        out = {k: v.cpu().numpy() for k, v in out.items()}
+        outlined = dev.cpu().numpy()
+        for f in range(frames.shape[0]):
+            ref_img, xy, desc, ao = oracle.extract_features_grid(frames[f], nrows, ncols, pat)
+            n = len(xy)
+            assert np.array_equal(outlined[f], ref_img), f
+            assert n > 50 and out["n"][f] == n, (f, out["n"][f], n)
+            assert np.array_equal(out["xy"][f, :n].view(np.uint32), xy.view(np.uint32)), f
+            assert np.array_equal(out["angle_octave"][f, :n].view(np.uint32), ao.view(np.uint32)), f
+            assert np.array_equal(out["desc"][f, :n], desc), f
+
+
+def test_pose_chain_on_photographs(ctx, oracle, real):
+    """What the reference does with match_features' result (src/vslam.cpp:77-186): extract_Rt, the camera matrix,
+    triangulate, the reprojection filter -- fed by the photographs' own F and inlier matches."""
+    g, bgr = real
+    P = bgr.shape[0] // 2
+    maxc, hyp, seed = (int(v) for v in g["params"])
+    ca, sa = synth.keypoint_rotation()
+    seeds = torch.from_numpy((np.uint32(seed) ^ np.arange(P, dtype=np.uint32)).view(np.int32)).cuda()
+    out = ctx.frontend_pairs(torch.from_numpy(bgr).cuda(), P, maxc, ca, sa, None, seeds, hyp, float(g["threshold"][0]))
+    Kmat = np.array([[525.0, 0, 320], [0, 525.0, 240], [0, 0, 1]], np.float32)
+    xy1, xy2 = out["xy"][:P].contiguous(), out["xy"][P:].contiguous()
+    R, tv, c2 = ctx.extract_Rt(out["F"], out["best"], Kmat)
+    pts = ctx.triangulate(xy1, xy2, out["matches"], out["best"], Kmat, c2)
+    ids = np.full((P, maxc), -1, np.int32)
+    ids[:, ::5] = 1
+    ridx, rn, rerr = ctx.reprojection_filter(pts, xy1, xy2, out["matches"], out["best"], Kmat, c2, torch.from_numpy(ids).cuda(), 4.0)
+    ctx.synchronize()
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    R, tv, c2, pts, ridx, rn, rerr = (a.cpu().numpy() for a in (R, tv, c2, pts, ridx, rn, rerr))
+    c1 = np.c_[Kmat, np.zeros(3, np.float32)]
+    for b in range(P):
+        assert o["best"][b, 0] >= 0 and np.array_equal(bits(o["F"][b]), bits(g[f"F{b}"]))
+        Rr, tr = oracle.extract_Rt(o["F"][b], Kmat)
+        assert np.array_equal(bits(R[b]), bits(Rr.reshape(9))) and np.array_equal(bits(tv[b]), bits(tr)), b
+        c2r = oracle.camera_matrix(Kmat, Rr, tr)
+        assert np.array_equal(bits(c2[b]), bits(c2r.reshape(12))), b
+        k = o["best"][b, 3]
+        mm = o["matches"][b, :k]
+        p1, p2 = o["xy"][b][mm[:, 0]], o["xy"][P + b][mm[:, 1]]
+        ref = oracle.triangulate(p1, p2, c1, c2r)
+        assert np.array_equal(bits(pts[b, :k]), bits(ref)), b
+        kept, err = oracle.reprojection_filter(ref, p1, p2, c1, c2r, ids[b, :k], 4.0)
+        assert rn[b] == len(kept) and np.array_equal(ridx[b, :rn[b]], kept) and rerr[b] == err, b
