@@ -800,7 +800,8 @@ def main():
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras", "--cpu-pairs", "0", "--cpu-all-cores-pairs", "0",
                    "--data", args.data, "--solver", args.solver] + extra
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VSLAM_BENCH_FORCE_DIST")}
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout, env=env)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
                 return None
