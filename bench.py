@@ -503,6 +503,8 @@ def main():
         sl.used = 0
         slots.append(sl)
     rccl_ranks = slots[0].comm.info()[0] if gather_mode == "rccl" else None
+    if rccl_ranks is not None and rccl_ranks != world:   # what RCCL itself counts (ncclCommCount), not what the launcher said
+        sys.exit(f"bench.py: the communicator holds {rccl_ranks} ranks, WORLD_SIZE is {world}")
     torch.cuda.synchronize(dev)
 
     def step(k):
