@@ -7,17 +7,31 @@
 // than 500 were found (:33-36); keypoints shifted to image coordinates (:37-40); then
 // ORB::compute over the whole (outlined) image (:43).
 //
-// The OpenCV internals follow the oracle (oracle/vso_orb.cpp) step for step:
-//   pyramid of every cell (8 levels, 32-px REFLECT_101 frame, INTER_LINEAR_EXACT resize in Q8/Q16)
-//   FAST-9/16: one pass stores M = max(dark arc score, bright arc score) per pixel; a pixel is a
-//     corner at threshold t iff M > t and its OpenCV score is M - 1 for every t, so both detectors
-//     (t = 20 and t = 5) share the map; 3x3 non-max suppression and the raster-order list per t
-//   KeyPointsFilter::retainBest = std::nth_element + std::partition: replayed with introselect.h so
-//     the surviving ORDER is libstdc++'s (it decides descriptor row order)
-//   Harris response (7x7, k = 0.04), second retainBest, intensity-centroid angle with fastAtan2's
-//     polynomial, steered BRIEF at the keypoint's pyramid level with pinned sin/cos.
-// This path is built for coverage and exactness, not yet tuned: the selection replays are serial
-// per (cell, level) by nature.
+// The OpenCV internals follow the oracle (oracle/vso_orb.cpp) result for result.  What the arrangement
+// below rests on (round 6; the first-correct form of rounds 1-5 took 239 us per 1280x720 frame):
+//   * ORB::detect never reads the 32-px reflect frame of a cell's pyramid: FAST keeps corners >= 31 px inside
+//     a level (runByImageBorder), its circle reaches 3 px, Harris 4, the intensity centroid 15.  Cell pyramids
+//     are therefore tight images; level 0 is a window of the gray frame.  Levels whose inner region is empty
+//     (a side <= 62) produce nothing, nothing depends on them, and they are not built.
+//   * FAST-9/16: M = max(dark arc score, bright arc score) per pixel; a pixel is a corner at threshold t iff
+//     M > t, its OpenCV score is M - 1 for every t, and the 3x3 non-max test on scores is "M greater than its
+//     eight neighbours' M" for every t >= 5 -- so one pass over the inner region (+ a 1-px ring) yields both
+//     detectors' raster-ordered lists.  One workgroup per (cell, level) walks row strips: source tile and M
+//     tile in LDS, ballot masks per 64-pixel chunk, one scan per strip, ordered writes.
+//   * src/Frame.cpp:34-36 keeps the threshold-20 result only if it holds >= 500 keypoints.  With c1 = the
+//     count after the first retainBest (known from a histogram of FAST scores, no replay needed) the final
+//     count of a level lies in [min(c1, quota), c1]: a cell whose upper bounds sum below 500 takes the
+//     threshold-5 detector without running the other, one whose lower bounds reach 500 the reverse; only
+//     cells in between run both.
+//   * KeyPointsFilter::retainBest = std::nth_element + std::partition: replayed (introselect.h) so the
+//     surviving ORDER is libstdc++'s -- it decides descriptor row order.  One wave per list, several lists
+//     per workgroup, LDS sized by tier of list length; std::partition's swap pairing is the same
+//     two-stopper-list scheme as the Hoare step and runs wave-wide.
+//   * Harris only where the second retainBest has something to decide; intensity centroid: half a wave
+//     per keypoint, a lane per patch column (rows are contiguous bytes), integer sums reduced by shuffles.
+//   * ORB::compute: frame pyramid levels >= 1 carry a 3-row / 4-column reflect margin so the 7x7 blur needs
+//     no border logic and every row is dword-aligned; a descriptor sample outside a level's image reads the
+//     UNBLURRED reflect value (OpenCV blurs the level in place inside its bordered buffer).
 #include "ctx.h"
 #include "introselect.h"
 
@@ -27,47 +41,85 @@
 namespace {
 
 constexpr int kMaxLevels = 8;
+constexpr int kEdge = 31;         // edgeThreshold = patchSize
+constexpr int kNFeatures = 500;   // src/Frame.cpp:22-23
+constexpr int kFastMin = 5;       // lowest FAST threshold any detector here uses
+constexpr int kThr[2] = {20, 5};  // list t = 0: fastThreshold 20, t = 1: the fallback's 5
 
-struct PyrLayout {
-    int nlevels, border, bufw, bufh;
-    int lx[kMaxLevels], ly[kMaxLevels], lw[kMaxLevels], lh[kMaxLevels];
+struct Geom {
+    int w, h, cw, ch, ncols, nrows, cells;
+    int nlv;   // levels that can hold keypoints: both sides of the cell's level > 62
     float scale[kMaxLevels];
-    int roi_prefix[kMaxLevels + 1];   // running sum of lw*lh
-    int ext_prefix[kMaxLevels + 1];   // running sum of (lw+2b)*(lh+2b)
+    // cell pyramid: level 0 = window of the gray frame; levels 1..nlv-1 tight, row stride a multiple of 4
+    int clw[kMaxLevels], clh[kMaxLevels], cstride[kMaxLevels], coff[kMaxLevels], cunit;
+    // frame pyramid: level 0 = the gray frame; levels 1..nlv-1 with a margin of 3 rows and 4 (left) / >= 4 (right) columns
+    int flw[kMaxLevels], flh[kMaxLevels], fstride[kMaxLevels], foff[kMaxLevels], fframe;
+    // inner regions (corners at least 31 px inside the level) and list slots per (unit, threshold)
+    int rw[kMaxLevels], rh[kMaxLevels], cap[kMaxLevels], loff[kMaxLevels + 1];
+    int per_level[kMaxLevels];   // computeKeyPoints' nfeaturesPerLevel
+    // INTER_LINEAR_EXACT tables (ofs | c1 << 16 per destination index): frame x / y, cell x / y, levels 1..nlv-1
+    int tXF[kMaxLevels], tYF[kMaxLevels], tXC[kMaxLevels], tYC[kMaxLevels], ttotal;
 };
 
-// orb.cpp pyramid layout (host arithmetic only)
-PyrLayout make_layout(int w, int h, int nlevels, double scaleFactor) {
-    PyrLayout P{};
-    const int patchSize = 31, edgeThreshold = 31, HARRIS_BLOCK_SIZE = 9;
-    const int halfPatchSize = patchSize / 2;
-    const int descPatchSize = (int)std::ceil(halfPatchSize * std::sqrt(2.0));
-    P.border = std::max(edgeThreshold, std::max(descPatchSize, HARRIS_BLOCK_SIZE / 2)) + 1;
-    P.nlevels = nlevels;
-    P.bufw = ((w + P.border * 2) + 15) & ~15;
-    int level_dy = h + P.border * 2, ox = 0, oy = 0;
-    P.roi_prefix[0] = P.ext_prefix[0] = 0;
-    for (int l = 0; l < nlevels; l++) {
-        const float sc = (float)std::pow(scaleFactor, (double)l);
-        P.scale[l] = sc;
+int make_geom(int w, int h, int nrows, int ncols, Geom &G) {
+    G = Geom{};
+    G.w = w;
+    G.h = h;
+    G.ncols = ncols;
+    G.nrows = nrows;
+    G.cells = nrows * ncols;
+    G.cw = w / ncols;   // src/Frame.cpp:20
+    G.ch = h / nrows;
+    G.nlv = 0;
+    bool open = true;
+    for (int l = 0; l < kMaxLevels; l++) {   // orb.cpp: Size(cvRound(w / scale), cvRound(h / scale)) with float scale
+        const float sc = (float)std::pow(1.2, (double)l);
+        G.scale[l] = sc;
         const float inv = 1.0f / sc;
-        const int sw = (int)std::lrint(w * inv), sh = (int)std::lrint(h * inv);
-        const int ww = sw + P.border * 2, wh = sh + P.border * 2;
-        if (ox + ww > P.bufw) {
-            ox = 0;
-            oy += level_dy;
-            level_dy = wh;
-        }
-        P.lx[l] = ox + P.border;
-        P.ly[l] = oy + P.border;
-        P.lw[l] = sw;
-        P.lh[l] = sh;
-        ox += ww;
-        P.roi_prefix[l + 1] = P.roi_prefix[l] + sw * sh;
-        P.ext_prefix[l + 1] = P.ext_prefix[l] + ww * wh;
+        G.clw[l] = (int)std::lrint(G.cw * inv);
+        G.clh[l] = (int)std::lrint(G.ch * inv);
+        G.flw[l] = (int)std::lrint(w * inv);
+        G.flh[l] = (int)std::lrint(h * inv);
+        G.rw[l] = G.clw[l] - 2 * kEdge;
+        G.rh[l] = G.clh[l] - 2 * kEdge;
+        open = open && G.rw[l] > 0 && G.rh[l] > 0;
+        if (open) G.nlv = l + 1;
     }
-    P.bufh = oy + level_dy;
-    return P;
+    int co = 0, fo = 0, lo = 0, to = 0;
+    G.loff[0] = 0;
+    for (int l = 0; l < G.nlv; l++) {
+        G.cstride[l] = l == 0 ? w : (G.clw[l] + 3) & ~3;
+        G.coff[l] = co;
+        if (l > 0) co += G.cstride[l] * G.clh[l];
+        G.fstride[l] = l == 0 ? w : ((G.flw[l] + 3) & ~3) + 8;
+        G.foff[l] = fo;
+        if (l > 0) fo += G.fstride[l] * (G.flh[l] + 6);
+        // NMS survivors are isolated: at most ceil(rw / 2) * ceil(rh / 2) of them
+        G.cap[l] = ((G.rw[l] + 1) / 2) * ((G.rh[l] + 1) / 2);
+        lo += G.cap[l];
+        G.loff[l + 1] = lo;
+        if (l > 0) {
+            G.tXF[l] = to; to += G.flw[l];
+            G.tYF[l] = to; to += G.flh[l];
+            G.tXC[l] = to; to += G.clw[l];
+            G.tYC[l] = to; to += G.clh[l];
+        }
+    }
+    G.cunit = (co + 15) & ~15;
+    G.fframe = (fo + 15) & ~15;
+    G.ttotal = to;
+    {   // computeKeyPoints' nfeaturesPerLevel (all 8 levels: the quotas do not depend on what a level can hold)
+        const float factor = (float)(1.0 / 1.2);
+        float ndesired = kNFeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)kMaxLevels));
+        int sum = 0;
+        for (int l = 0; l < kMaxLevels - 1; l++) {
+            G.per_level[l] = (int)std::lrint(ndesired);
+            sum += G.per_level[l];
+            ndesired *= factor;
+        }
+        G.per_level[kMaxLevels - 1] = std::max(kNFeatures - sum, 0);
+    }
+    return 0;
 }
 
 __device__ __forceinline__ int reflect101(int p, int n) {
@@ -77,6 +129,18 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 }
 __device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) {
     return (b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15;
+}
+
+// level l of unit u's cell pyramid (unit = frame * cells + cell, cells counted columns outer, rows inner: src/Frame.cpp:27-28)
+__device__ __forceinline__ const uint8_t *cell_level(const Geom &G, const uint8_t *gray, const uint8_t *cpyr, int u, int l,
+                                                     int &stride) {
+    stride = G.cstride[l];
+    if (l == 0) {
+        const int f = u / G.cells, c = u - f * G.cells;
+        const int ci = c / G.nrows, cj = c - ci * G.nrows;
+        return gray + (size_t)f * G.w * G.h + (size_t)(cj * G.ch) * G.w + ci * G.cw;
+    }
+    return cpyr + (size_t)u * G.cunit + G.coff[l];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -103,202 +167,372 @@ __global__ __launch_bounds__(256) void grid_outline_gray_kernel(uint8_t *__restr
     }
 }
 
-// level 0 of a pyramid (ROI + reflect frame) from a gray image region: unit u of a frame is the
-// cell (i = column, j = row) with origin (i*cw, j*ch); cells == 1 means "whole frame"
-__global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t *__restrict__ gray, int w, int h, int cw, int ch,
-                                                         int ncols, int nrows, PyrLayout L, uint8_t *__restrict__ pyr) {
-    const int u = blockIdx.y;
-    const int cells = ncols * nrows;
-    const int f = u / cells, c = u - f * cells;
-    const int ci = c / nrows, cj = c - ci * nrows;   // columns outer, rows inner (src/Frame.cpp:27-28)
-    const int sx = ci * cw, sy = cj * ch;
-    const int ew = L.lw[0] + 2 * L.border, eh = L.lh[0] + 2 * L.border;
+// the same for dword-aligned rows and widths that are a multiple of 4: a lane takes 4 pixels = three dwords of BGR
+__global__ __launch_bounds__(256) void grid_outline_gray4_kernel(uint8_t *__restrict__ bgr, int w, int h, int stride,
+                                                                 int cw, int ch, int ncols, int nrows,
+                                                                 uint8_t *__restrict__ gray) {
+    const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ew * eh) return;
-    const int by = i / ew, bx = i - by * ew;
-    const int x = reflect101(bx - L.border, L.lw[0]), y = reflect101(by - L.border, L.lh[0]);
-    pyr[(size_t)u * L.bufw * L.bufh + (size_t)(L.ly[0] - L.border + by) * L.bufw + (L.lx[0] - L.border + bx)] =
-        gray[((size_t)f * h + sy + y) * w + sx + x];
+    const int groups = w >> 2;
+    if (i >= groups * h) return;
+    const int y = i / groups, x = (i - y * groups) * 4;
+    uint8_t *row = bgr + ((size_t)f * h + y) * stride;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(row + 3 * x);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    uint32_t g[4];
+    g[0] = gray_of(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u);
+    g[1] = gray_of(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u);
+    g[2] = gray_of((d1 >> 16) & 255u, d1 >> 24, d2 & 255u);
+    g[3] = gray_of((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24);
+    if (y < ch * nrows) {
+        const int cy = y % ch;
+        const bool row_line = cy == 0 || cy == ch - 1;
+        int cx = x % cw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (x + k < cw * ncols && (row_line || cx == 0 || cx == cw - 1)) {
+                g[k] = 0;
+                uint8_t *q = row + 3 * (x + k);
+                q[0] = q[1] = q[2] = 0;
+            }
+            cx = cx + 1 == cw ? 0 : cx + 1;
+        }
+    }
+    *reinterpret_cast<uint32_t *>(gray + ((size_t)f * h + y) * w + x) = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
 }
 
-// INTER_LINEAR_EXACT coefficient for destination index d (Q8), resize.cpp interpolationLinear
-__device__ __forceinline__ void linear_coeff(int d, int dst_n, int src_n, int &ofs, int &c0, int &c1) {
+// ------------------------------------------------------------------------------------------
+// pyramids: INTER_LINEAR_EXACT (Q8 coefficients on both axes, Q16 accumulate, round half up)
+// ------------------------------------------------------------------------------------------
+// coefficient for destination index d (resize.cpp interpolationLinear): the table entry is ofs | c1 << 16, c0 = 256 - c1
+__device__ __forceinline__ uint32_t linear_coeff(int d, int dst_n, int src_n) {
     const double inv_scale = (double)dst_n / (double)src_n;
     const double scale = 1.0 / inv_scale;
     const double fval = scale * ((double)d + 0.5) - 0.5;
-    int ival = (int)floor(fval);
+    int ival = (int)floor(fval), c1;
     if (ival >= 0 && src_n > 1) {
         if (ival < src_n - 1) {
             c1 = (int)rint((fval - (double)ival) * 256.0);
-            c0 = 256 - c1;
         } else {
             ival = src_n - 2;
-            c0 = 0;
             c1 = 256;
         }
     } else {
         ival = 0;
-        c0 = 256;
         c1 = 0;
     }
-    ofs = ival;
+    return (uint32_t)ival | ((uint32_t)c1 << 16);
 }
 
-// level l (ROI + reflect frame) from the ROI of level l-1
-__global__ __launch_bounds__(256) void pyr_resize_kernel(PyrLayout L, int l, uint8_t *__restrict__ pyr) {
-    const int u = blockIdx.y;
-    uint8_t *base = pyr + (size_t)u * L.bufw * L.bufh;
-    const int dw = L.lw[l], dh = L.lh[l], sw = L.lw[l - 1], sh = L.lh[l - 1];
-    const int ew = dw + 2 * L.border, eh = dh + 2 * L.border;
+__global__ __launch_bounds__(256) void resize_tables_kernel(Geom G, uint32_t *__restrict__ tab) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ew * eh) return;
-    const int by = i / ew, bx = i - by * ew;
-    const int x = reflect101(bx - L.border, dw), y = reflect101(by - L.border, dh);
-    int xo, x0, x1, yo, y0, y1;
-    linear_coeff(x, dw, sw, xo, x0, x1);
-    linear_coeff(y, dh, sh, yo, y0, y1);
-    const uint8_t *src = base + (size_t)L.ly[l - 1] * L.bufw + L.lx[l - 1];
-    const uint8_t *r0 = src + (size_t)yo * L.bufw, *r1 = src + (size_t)min(yo + 1, sh - 1) * L.bufw;
-    const int xb = min(xo + 1, sw - 1);
-    const uint32_t h0 = (uint32_t)r0[xo] * x0 + (uint32_t)r0[xb] * x1;
-    const uint32_t h1 = (uint32_t)r1[xo] * x0 + (uint32_t)r1[xb] * x1;
-    const uint32_t v = h0 * y0 + h1 * y1;
-    base[(size_t)(L.ly[l] - L.border + by) * L.bufw + (L.lx[l] - L.border + bx)] = (uint8_t)((v + (1u << 15)) >> 16);
-}
-
-// ------------------------------------------------------------------------------------------
-// FAST-9/16 arc score map M (fast.cpp FAST_t<16> + cornerScore<16>)
-// ------------------------------------------------------------------------------------------
-constexpr int kFastMinThreshold = 5;   // lowest threshold any detector here uses
-
-__global__ __launch_bounds__(256) void fast_score_kernel(PyrLayout L, const uint8_t *__restrict__ pyr,
-                                                         uint8_t *__restrict__ M) {
-    const int u = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= L.roi_prefix[L.nlevels]) return;
-    int l = 0;
-    while (i >= L.roi_prefix[l + 1]) l++;
-    const int r = i - L.roi_prefix[l];
-    const int lw = L.lw[l], lh = L.lh[l];
-    const int y = r / lw, x = r - y * lw;
-    const size_t pos = (size_t)u * L.bufw * L.bufh + (size_t)(L.ly[l] + y) * L.bufw + L.lx[l] + x;
-    uint8_t out = 0;
-    if (x >= 3 && x < lw - 3 && y >= 3 && y < lh - 3) {
-        const uint8_t *p = pyr + pos;
-        const int s = L.bufw;
-        const int v = p[0];
-        int d[16];
-        d[0] = v - p[3 * s];      d[1] = v - p[3 * s + 1];  d[2] = v - p[2 * s + 2];  d[3] = v - p[s + 3];
-        d[4] = v - p[3];          d[5] = v - p[-s + 3];     d[6] = v - p[-2 * s + 2]; d[7] = v - p[-3 * s + 1];
-        d[8] = v - p[-3 * s];     d[9] = v - p[-3 * s - 1]; d[10] = v - p[-2 * s - 2]; d[11] = v - p[-s - 3];
-        d[12] = v - p[-3];        d[13] = v - p[s - 3];     d[14] = v - p[2 * s - 2]; d[15] = v - p[3 * s - 1];
-        // any 9-arc contains at least two of the four compass pixels: cheap necessary test
-        int dark = 0, bright = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-            dark += d[k] > kFastMinThreshold;
-            bright += d[k] < -kFastMinThreshold;
-        }
-        if (dark >= 2 || bright >= 2) {
-            int best = 0;
-#pragma unroll
-            for (int st = 0; st < 16; st++) {
-                int mn = d[st], mx = d[st];
-#pragma unroll
-                for (int j = 1; j < 9; j++) {
-                    const int e = d[(st + j) & 15];
-                    mn = min(mn, e);
-                    mx = max(mx, e);
-                }
-                best = max(best, max(mn, -mx));   // dark arcs: min d; bright arcs: min(-d) = -max d
-            }
-            out = (uint8_t)min(max(best, 0), 255);
-        }
+    if (i >= G.ttotal) return;
+    for (int l = 1; l < G.nlv; l++) {
+        if (i < G.tYF[l]) { tab[i] = linear_coeff(i - G.tXF[l], G.flw[l], G.flw[l - 1]); return; }
+        if (i < G.tXC[l]) { tab[i] = linear_coeff(i - G.tYF[l], G.flh[l], G.flh[l - 1]); return; }
+        if (i < G.tYC[l]) { tab[i] = linear_coeff(i - G.tXC[l], G.clw[l], G.clw[l - 1]); return; }
+        if (i < G.tYC[l] + G.clh[l]) { tab[i] = linear_coeff(i - G.tYC[l], G.clh[l], G.clh[l - 1]); return; }
     }
-    M[pos] = out;
+}
+
+__device__ __forceinline__ uint32_t resize_px(const uint8_t *r0, const uint8_t *r1, int sw, uint32_t xt, uint32_t y0c, uint32_t y1c) {
+    const int xo = (int)(xt & 0xffffu);
+    const uint32_t x1c = xt >> 16, x0c = 256u - x1c;
+    const int xb = min(xo + 1, sw - 1);
+    const uint32_t h0 = (uint32_t)r0[xo] * x0c + (uint32_t)r0[xb] * x1c;
+    const uint32_t h1 = (uint32_t)r1[xo] * x0c + (uint32_t)r1[xb] * x1c;
+    const uint32_t v = h0 * y0c + h1 * y1c;
+    return (v + (1u << 15)) >> 16;
+}
+
+// level l of every frame's pyramid (with its reflect margin) and of every cell's pyramid from level l - 1:
+// blocks [0, frames * nbF) take the frames, the rest the cells; a lane makes 4 pixels = one dword
+__global__ __launch_bounds__(256) void pyr_resize_kernel(Geom G, int l, int frames, int nbF, int nbC,
+                                                         const uint8_t *__restrict__ gray, uint8_t *__restrict__ fpyr,
+                                                         uint8_t *__restrict__ cpyr, const uint32_t *__restrict__ tab) {
+    int b = blockIdx.x;
+    if (b < frames * nbF) {
+        const int f = b / nbF, blk = b - f * nbF;
+        const int lw = G.flw[l], lh = G.flh[l], fs = G.fstride[l], groups = fs >> 2, rows = lh + 6;
+        const int t = blk * 256 + threadIdx.x;
+        if (t >= groups * rows) return;
+        const int by = t / groups, g = t - by * groups;
+        const int y = reflect101(by - 3, lh);
+        const uint32_t yt = tab[G.tYF[l] + y];
+        const int yo = (int)(yt & 0xffffu);
+        const uint32_t y1c = yt >> 16, y0c = 256u - y1c;
+        const int sw = G.flw[l - 1], sh = G.flh[l - 1], ss = G.fstride[l - 1];
+        const uint8_t *S = l == 1 ? gray + (size_t)f * G.w * G.h : fpyr + (size_t)f * G.fframe + G.foff[l - 1] + 3 * ss + 4;
+        const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)min(yo + 1, sh - 1) * ss;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = reflect101(4 * g + k - 4, lw);
+            out |= resize_px(r0, r1, sw, tab[G.tXF[l] + x], y0c, y1c) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(fpyr + (size_t)f * G.fframe + G.foff[l] + (size_t)by * fs + 4 * g) = out;
+    } else {
+        b -= frames * nbF;
+        const int u = b / nbC, blk = b - u * nbC;
+        const int lw = G.clw[l], lh = G.clh[l], cs = G.cstride[l], groups = cs >> 2;
+        const int t = blk * 256 + threadIdx.x;
+        if (t >= groups * lh) return;
+        const int y = t / groups, g = t - y * groups;
+        const uint32_t yt = tab[G.tYC[l] + y];
+        const int yo = (int)(yt & 0xffffu);
+        const uint32_t y1c = yt >> 16, y0c = 256u - y1c;
+        const int sw = G.clw[l - 1], sh = G.clh[l - 1];
+        int ss;
+        const uint8_t *S = cell_level(G, gray, cpyr, u, l - 1, ss);
+        const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)min(yo + 1, sh - 1) * ss;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = min(4 * g + k, lw - 1);
+            out |= resize_px(r0, r1, sw, tab[G.tXC[l] + x], y0c, y1c) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(cpyr + (size_t)u * G.cunit + G.coff[l] + (size_t)y * cs + 4 * g) = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// per (unit, level) keypoint slots
+// FAST-9/16 (fast.cpp FAST_t<16> + cornerScore<16>), 3x3 non-max suppression, both detectors' raster-ordered lists
 // ------------------------------------------------------------------------------------------
-struct SlotLayout {
-    int cap[kMaxLevels];      // capacity of each level's slot
-    int off[kMaxLevels + 1];  // prefix of caps
-    int per_level[kMaxLevels];   // nfeaturesPerLevel
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// M of the pixel at c (row stride s): max over the 16 arcs of 9 of min(v - p) (dark) and of min(p - v) (bright);
+// values <= kFastMin are reported as 0 (no detector here can tell them apart)
+__device__ __forceinline__ int fast_arc_score(const uint8_t *c, int s) {
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * s];      d[1] = v - c[3 * s + 1];  d[2] = v - c[2 * s + 2];   d[3] = v - c[s + 3];
+    d[4] = v - c[3];          d[5] = v - c[-s + 3];     d[6] = v - c[-2 * s + 2];  d[7] = v - c[-3 * s + 1];
+    d[8] = v - c[-3 * s];     d[9] = v - c[-3 * s - 1]; d[10] = v - c[-2 * s - 2]; d[11] = v - c[-s - 3];
+    d[12] = v - c[-3];        d[13] = v - c[s - 3];     d[14] = v - c[2 * s - 2];  d[15] = v - c[3 * s - 1];
+    // any arc of 9 holds at least two of the four compass pixels: cheap necessary test
+    const int dark = (d[0] > kFastMin) + (d[4] > kFastMin) + (d[8] > kFastMin) + (d[12] > kFastMin);
+    const int bright = (d[0] < -kFastMin) + (d[4] < -kFastMin) + (d[8] < -kFastMin) + (d[12] < -kFastMin);
+    int best = 0;
+    if (dark >= 2 || bright >= 2) {
+        int a3[16], b3[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            a3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+            b3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        }
+        int dk = -256, br = 256;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            dk = max(dk, min3i(a3[k], a3[(k + 3) & 15], a3[(k + 6) & 15]));
+            br = min(br, max3i(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]));
+        }
+        best = max(dk, -br);
+    }
+    return best > kFastMin ? min(best, 255) : 0;
+}
+
+// exact i / d for i * d < 2^32 with m = floor(2^32 / d) + 1 (which is 2^32 for d = 1 and arrives here as 0)
+__device__ __forceinline__ int div_magic(int i, uint32_t m) { return m ? (int)__umulhi((uint32_t)i, m) : i; }
+
+struct FastLds {
+    int R, SW, MW, CPR;   // strip rows, tile row strides, 64-pixel chunks per row
+    uint8_t *S, *M;
+    unsigned long long *mask5, *mask20;
+    int *cnt5, *cnt20, *hist, *tot;
 };
 
-// FAST keypoints of one (unit, level) at threshold t: 3x3 NMS on scores s = (M > t) ? M - 1 : 0,
-// runByImageBorder(edgeThreshold 31), raster order (ordered ballot compaction).
-__global__ __launch_bounds__(256) void fast_collect_kernel(PyrLayout L, SlotLayout SL, const uint8_t *__restrict__ M, int thr,
-                                                           short2 *__restrict__ kp_xy, float *__restrict__ kp_resp,
-                                                           int32_t *__restrict__ kp_cnt) {
-    const int u = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
-    const int lw = L.lw[l], lh = L.lh[l];
-    const int edge = 31;
-    const size_t slot = (size_t)u * SL.off[L.nlevels] + SL.off[l];
-    int32_t *cnt = kp_cnt + (size_t)u * kMaxLevels + l;
-    if (lh <= edge * 2 || lw <= edge * 2) {   // runByImageBorder clears everything
-        if (tid == 0) *cnt = 0;
-        return;
-    }
-    const int rw = lw - 2 * edge, rh = lh - 2 * edge;
-    const uint8_t *Mb = M + (size_t)u * L.bufw * L.bufh + (size_t)L.ly[l] * L.bufw + L.lx[l];
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < rw * rh; i0 += 256) {
-        const int i = i0 + tid;
-        bool keep = false;
-        int x = 0, y = 0, sc = 0;
-        if (i < rw * rh) {
-            y = edge + i / rw;
-            x = edge + (i - (i / rw) * rw);
-            const uint8_t *c = Mb + (size_t)y * L.bufw + x;
-            const int m = c[0];
-            if (m > thr) {
-                sc = m - 1;
-                keep = true;
-#pragma unroll
-                for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; dx++) {
-                        if (dx == 0 && dy == 0) continue;
-                        const int mn = c[dy * L.bufw + dx];
-                        const int sn = mn > thr ? mn - 1 : 0;
-                        keep = keep && (sc > sn);
-                    }
-            }
-        }
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) s_wave[wave] = (int)__popcll(bal);
-        __syncthreads();
-        int off = s_base;
-        for (int wv = 0; wv < wave; wv++) off += s_wave[wv];
-        off += (int)__popcll(bal & ((1ull << lane) - 1ull));
-        if (keep && off < SL.cap[l]) {
-            kp_xy[slot + off] = make_short2((short)x, (short)y);
-            kp_resp[slot + off] = (float)sc;
-        }
-        __syncthreads();
-        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        __syncthreads();
-    }
-    if (tid == 0) *cnt = min(s_base, SL.cap[l]);
+// rows a strip may have with `bytes` of LDS (host and device agree through this one function)
+__host__ __device__ inline int fast_strip_rows(int rw, int bytes) {
+    const int SW = (rw + 8 + 3) & ~3, MW = (rw + 2 + 3) & ~3, CPR = (rw + 63) >> 6;
+    const int fixed = 8 * SW + 2 * MW + 256 * 4 + 64, per_row = SW + MW + CPR * 24;
+    const int R = (bytes - fixed) / per_row;
+    return R > 32 ? 32 : R;
 }
 
-// KeyPointsFilter::retainBest(list, n_points) in place (keypoint.cpp): nth_element by response
-// descending, then std::partition of the tail on response >= boundary.  One lane replays it.
+// One workgroup per (unit, level); blocks are level-major so the large levels start first.
+// lists [unit][t][slot] hold (raster index in the inner region) << 8 | M; cnt0 [unit][t][8] their lengths;
+// c1_20 [unit][8] = length of the threshold-20 list after the first retainBest (from the score histogram).
+__global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, int lds_bytes, const uint8_t *__restrict__ gray,
+                                                           const uint8_t *__restrict__ cpyr, uint32_t *__restrict__ lists,
+                                                           int32_t *__restrict__ cnt0, int32_t *__restrict__ c1_20) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int l = blockIdx.x / units, u = blockIdx.x - l * units, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rw = G.rw[l], rh = G.rh[l], cap = G.cap[l];
+    int stride;
+    const uint8_t *src = cell_level(G, gray, cpyr, u, l, stride);
+    FastLds L;
+    L.R = fast_strip_rows(rw, lds_bytes);
+    L.SW = (rw + 8 + 3) & ~3;
+    L.MW = (rw + 2 + 3) & ~3;
+    L.CPR = (rw + 63) >> 6;
+    {
+        unsigned char *p = smem;
+        L.hist = reinterpret_cast<int *>(p);                       p += 256 * 4;
+        L.tot = reinterpret_cast<int *>(p);                        p += 64;
+        const int nc = L.R * L.CPR;
+        L.mask5 = reinterpret_cast<unsigned long long *>(p);       p += (size_t)nc * 8;
+        L.mask20 = reinterpret_cast<unsigned long long *>(p);      p += (size_t)nc * 8;
+        L.cnt5 = reinterpret_cast<int *>(p);                       p += (size_t)nc * 4;
+        L.cnt20 = reinterpret_cast<int *>(p);                      p += (size_t)nc * 4;
+        L.S = p;                                                   p += (size_t)(L.R + 8) * L.SW;
+        L.M = p;
+    }
+    L.hist[tid] = 0;
+    if (tid < 2) L.tot[tid] = 0;
+    const uint32_t mS = 0xffffffffu / (uint32_t)(rw + 8) + 1u, mM = 0xffffffffu / (uint32_t)(rw + 2) + 1u;
+    const uint32_t mC = 0xffffffffu / (uint32_t)L.CPR + 1u;
+    uint32_t *list20 = lists + ((size_t)(u * 2 + 0)) * G.loff[G.nlv] + G.loff[l];
+    uint32_t *list5 = lists + ((size_t)(u * 2 + 1)) * G.loff[G.nlv] + G.loff[l];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    for (int y0 = 0; y0 < rh; y0 += L.R) {   // strip = inner rows [y0, y0 + rows)
+        const int rows = min(L.R, rh - y0);
+        // 1. source tile: level rows 31 + y0 - 4 .. (rows + 8 of them), columns 27 .. lw - 28 (rw + 8)
+        {
+            const uint8_t *s0 = src + (size_t)(kEdge + y0 - 4) * stride + (kEdge - 4);
+            const int n = (rows + 8) * (rw + 8);
+            for (int i = tid; i < n; i += 256) {
+                const int r = div_magic(i, mS), c = i - r * (rw + 8);
+                L.S[r * L.SW + c] = s0[(size_t)r * stride + c];
+            }
+        }
+        __syncthreads();
+        // 2. M for inner rows y0 - 1 .. y0 + rows and inner columns -1 .. rw
+        {
+            const int n = (rows + 2) * (rw + 2);
+            for (int i = tid; i < n; i += 256) {
+                const int r = div_magic(i, mM), c = i - r * (rw + 2);
+                L.M[r * L.MW + c] = (uint8_t)fast_arc_score(L.S + (r + 3) * L.SW + c + 3, L.SW);
+            }
+        }
+        __syncthreads();
+        // 3. non-max suppression; a ballot mask per chunk of 64 pixels and detector, score histogram of the threshold-20 survivors
+        const int nc = rows * L.CPR;
+        for (int id = wave; id < nc; id += 4) {
+            const int r = div_magic(id, mC), c = id - r * L.CPR;
+            const int x = c * 64 + lane;
+            const uint8_t *m = L.M + (r + 1) * L.MW + x + 1;
+            const int v = x < rw ? (int)m[0] : 0;
+            bool keep = false;
+            if (v > kFastMin) {
+                const int nb = max(max(max3i(m[-L.MW - 1], m[-L.MW], m[-L.MW + 1]), max3i(m[L.MW - 1], m[L.MW], m[L.MW + 1])),
+                                   max((int)m[-1], (int)m[1]));
+                keep = v > nb;
+            }
+            const bool keep20 = keep && v > kThr[0];
+            const unsigned long long b5 = __ballot(keep), b20 = __ballot(keep20);
+            if (keep20) atomicAdd(&L.hist[v], 1);
+            if (lane == 0) {
+                L.mask5[id] = b5;
+                L.mask20[id] = b20;
+                L.cnt5[id] = (int)__popcll(b5);
+                L.cnt20[id] = (int)__popcll(b20);
+            }
+        }
+        __syncthreads();
+        // 4. exclusive scan of the chunk counts (wave 0: threshold 5, wave 1: threshold 20), running totals carried in LDS
+        if (wave < 2) {
+            int *cnt = wave == 0 ? L.cnt5 : L.cnt20;
+            int base = L.tot[wave];
+            for (int j0 = 0; j0 < nc; j0 += 64) {
+                const int j = j0 + lane;
+                const int v = j < nc ? cnt[j] : 0;
+                int inc = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += t;
+                }
+                if (j < nc) cnt[j] = base + inc - v;
+                base += __shfl(inc, 63, 64);
+            }
+            if (lane == 0) L.tot[wave] = base;
+        }
+        __syncthreads();
+        // 5. ordered writes
+        for (int id = wave; id < nc; id += 4) {
+            const int r = div_magic(id, mC), c = id - r * L.CPR;
+            const int x = c * 64 + lane;
+            const unsigned long long b5 = L.mask5[id], b20 = L.mask20[id];
+            if ((b5 >> lane) & 1ull) {
+                const uint32_t e = ((uint32_t)((y0 + r) * rw + x) << 8) | (uint32_t)L.M[(r + 1) * L.MW + x + 1];
+                const int p5 = L.cnt5[id] + (int)__popcll(b5 & lt);
+                if (p5 < cap) list5[p5] = e;
+                if ((b20 >> lane) & 1ull) {
+                    const int p20 = L.cnt20[id] + (int)__popcll(b20 & lt);
+                    if (p20 < cap) list20[p20] = e;
+                }
+            }
+        }
+        // (the next strip's first barrier stands between these reads of M / masks / counts and their next writes)
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int n5 = min(L.tot[0], cap), n20 = min(L.tot[1], cap);
+        // length after retainBest(list20, 2 * quota): all of it if it is no longer than that, otherwise the entries
+        // whose score is >= the (2 * quota)-th largest one
+        const int np = 2 * G.per_level[l];
+        const int4 hv = reinterpret_cast<const int4 *>(L.hist)[lane];   // scores 4 * lane .. 4 * lane + 3
+        const int s = hv.x + hv.y + hv.z + hv.w;
+        int suf = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += t;
+        }
+        int c1 = n20;
+        if (n20 > np && np > 0) {
+            const unsigned long long bal = __ballot(suf >= np);   // lane 0 always (suf = n20 > np)
+            const int Lm = 63 - (int)__builtin_clzll(bal);
+            int acc = suf - s;   // entries with scores above this lane's four
+            int got = 0;
+            if (lane == Lm) {
+                acc += hv.w; if (acc >= np) got = acc;
+                if (!got) { acc += hv.z; if (acc >= np) got = acc; }
+                if (!got) { acc += hv.y; if (acc >= np) got = acc; }
+                if (!got) { acc += hv.x; got = acc; }
+            }
+            c1 = __shfl(got, Lm, 64);
+        } else if (np == 0) {
+            c1 = 0;
+        }
+        if (lane == 0) {
+            cnt0[(size_t)(u * 2 + 0) * kMaxLevels + l] = n20;
+            cnt0[(size_t)(u * 2 + 1) * kMaxLevels + l] = n5;
+            c1_20[(size_t)u * kMaxLevels + l] = c1;
+        }
+    }
+}
+
+// which detectors a cell has to run: bit 0 = threshold 20, bit 1 = threshold 5 (see the head of this file)
+__global__ __launch_bounds__(256) void grid_decide_kernel(Geom G, int units, const int32_t *__restrict__ c1_20,
+                                                          uint8_t *__restrict__ flags) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    int lb = 0, ub = 0;
+    for (int l = 0; l < G.nlv; l++) {
+        const int c = c1_20[(size_t)u * kMaxLevels + l];
+        lb += min(c, G.per_level[l]);
+        ub += c;
+    }
+    flags[u] = (uint8_t)((ub >= kNFeatures ? 1 : 0) | (lb < kNFeatures ? 2 : 0));
+}
+
+// ------------------------------------------------------------------------------------------
+// KeyPointsFilter::retainBest(list, n_points) (keypoint.cpp): nth_element by response descending, then
+// std::partition of the tail on response >= boundary.  One wave per list.
+// ------------------------------------------------------------------------------------------
 struct RespStore {
-    using value_type = int2;   // (response bits, payload index)
+    using value_type = int2;   // (response bits, payload)
     using key_type = float;
     float *key_;
-    int *pay_;
-    __device__ int2 get(int i) const { return make_int2(__float_as_int(key_[i]), pay_[i]); }
+    uint32_t *pay_;
+    __device__ int2 get(int i) const { return make_int2(__float_as_int(key_[i]), (int)pay_[i]); }
     __device__ void set(int i, const int2 &v) {
         key_[i] = __int_as_float(v.x);
-        pay_[i] = v.y;
+        pay_[i] = (uint32_t)v.y;
     }
     __device__ void swap(int i, int j) {
         const int2 a = get(i), b = get(j);
@@ -310,108 +544,141 @@ struct RespStore {
     __device__ bool less(float a, float b) const { return a > b; }   // KeypointResponseGreater
 };
 
-// xy_in -> xy_out (permuted when a selection happens, copied otherwise); responses permuted in place.
-// Work arrays live in LDS when the list fits (the usual case) and in a per-slot global scratch otherwise.
-__global__ __launch_bounds__(64) void retain_best_kernel(PyrLayout L, SlotLayout SL, int mult, const short2 *__restrict__ xy_in,
-                                                         short2 *__restrict__ xy_out, float *__restrict__ kp_resp,
-                                                         int32_t *__restrict__ kp_cnt, int lds_entries,
-                                                         float *__restrict__ g_key, int *__restrict__ g_pay,
-                                                         int *__restrict__ g_sl, int *__restrict__ g_sr) {
+// std::partition(first = a, last = b, key >= amb), bidirectional form: with L_k the k-th position from the left that fails
+// the predicate and R_k the k-th from the right that meets it, it swaps (L_k, R_k) while L_k < R_k and returns
+// a + (number that meet it).  Same stopper-list scheme as vs_sel::wave_partition.
+template <class I>
+__device__ int wave_std_partition(RespStore &s, int a, int b, float amb, I *sl, I *sr) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nL = 0, nR = 0;
+    for (int p0 = a; p0 < b; p0 += 64) {
+        const int p = p0 + lane;
+        const bool st = p < b && !(s.key(p) >= amb);
+        const unsigned long long bal = __ballot(st);
+        if (st) sl[a + nL + (int)__popcll(bal & lt)] = (I)p;
+        nL += (int)__popcll(bal);
+    }
+    for (int p0 = b - 1; p0 >= a; p0 -= 64) {
+        const int p = p0 - lane;
+        const bool st = p >= a && s.key(p) >= amb;
+        const unsigned long long bal = __ballot(st);
+        if (st) sr[a + nR + (int)__popcll(bal & lt)] = (I)p;
+        nR += (int)__popcll(bal);
+    }
+    vs_sel::wave_sync_lds();
+    const int m = nL < nR ? nL : nR;
+    for (int k0 = 0; k0 < m; k0 += 64) {
+        const int k = k0 + lane;
+        const bool sw = k < m && (int)sl[a + k] < (int)sr[a + k];
+        if (sw) s.swap((int)sl[a + k], (int)sr[a + k]);
+        if (__ballot(sw) != ~0ull) break;
+    }
+    vs_sel::wave_sync_lds();
+    return a + nR;
+}
+
+// mode 1: keys = FAST score, n_points = 2 * quota, cnt_in = cnt0, cnt_out = cnt1;  mode 2: keys = Harris response,
+// n_points = quota, cnt_in = cnt1, cnt_out = cnt2.  Survivors are written back to the front of the list in libstdc++'s order.
+// Tiers by list length n: kLo < n + 1 <= kEntries entries of LDS per wave (kGlobal: per-list global scratch, any length);
+// lists that retainBest leaves alone (n <= n_points) are settled by the tier with kLo == 0.
+template <int kEntries, int kLo, int kWaves, bool kGlobal>
+__global__ __launch_bounds__(64 * kWaves) void retain_best_kernel(Geom G, int mode, int n_lists, uint32_t *__restrict__ ent,
+                                                                  const float *__restrict__ resp,
+                                                                  const int32_t *__restrict__ cnt_in, int32_t *__restrict__ cnt_out,
+                                                                  const uint8_t *__restrict__ flags, float *__restrict__ g_key,
+                                                                  uint32_t *__restrict__ g_pay, int *__restrict__ g_sl,
+                                                                  int *__restrict__ g_sr) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int u = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
-    int32_t *cnt = kp_cnt + (size_t)u * kMaxLevels + l;
-    const int n = *cnt;
-    const int n_points = mult * SL.per_level[l];
-    const size_t slot = (size_t)u * SL.off[L.nlevels] + SL.off[l];
-    if (!(n_points >= 0 && n > n_points)) {
-        for (int i = tid; i < n; i += 64) xy_out[slot + i] = xy_in[slot + i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = blockIdx.x * kWaves + wave;
+    if (li >= n_lists) return;
+    const int l = li % G.nlv, ut = li / G.nlv, u = ut >> 1, t = ut & 1;
+    if (!(flags[u] & (1 << t))) return;
+    const size_t ci = (size_t)ut * kMaxLevels + l;
+    const int n = cnt_in[ci];
+    const int n_points = (mode == 1 ? 2 : 1) * G.per_level[l];
+    if (n <= n_points) {
+        if (kLo == 0 && lane == 0) cnt_out[ci] = n;
         return;
     }
     if (n_points == 0) {
-        if (tid == 0) *cnt = 0;
+        if (kLo == 0 && lane == 0) cnt_out[ci] = 0;
         return;
     }
-    float *key;
-    int *pay, *sl, *sr;
-    if (n + 1 <= lds_entries) {
-        key = reinterpret_cast<float *>(smem);
-        pay = reinterpret_cast<int *>(key + lds_entries);
-        sl = pay + lds_entries;
-        sr = sl + lds_entries;
-    } else {
-        key = g_key + slot;
-        pay = g_pay + slot;
-        sl = g_sl + slot;
-        sr = g_sr + slot + ((size_t)u * kMaxLevels + l);   // one spare element per slot
-    }
-    for (int i = tid; i < n; i += 64) {
-        key[i] = kp_resp[slot + i];
-        pay[i] = i;
-    }
-    __syncthreads();
-    __shared__ int s_new_n;
-    RespStore s{key, pay};
-    vs_sel::wave_nth_element(s, 0, n_points - 1, n, sl, sr);   // the block is one wave
-    __syncthreads();
-    if (tid == 0) {
-        const float ambiguous = key[n_points - 1];
-        // std::partition (bidirectional), pred: response >= ambiguous
-        int first = n_points, last = n;
-        while (true) {
-            while (true) {
-                if (first == last) goto done;
-                if (key[first] >= ambiguous) ++first;
-                else break;
-            }
-            --last;
-            while (true) {
-                if (first == last) goto done;
-                if (!(key[last] >= ambiguous)) --last;
-                else break;
-            }
-            s.swap(first, last);
-            ++first;
+    if (n + 1 <= kLo || (!kGlobal && n + 1 > kEntries)) return;
+    const size_t slot = (size_t)ut * G.loff[G.nlv] + G.loff[l];
+    RespStore s;
+    int m;
+    if constexpr (kGlobal) {
+        s.key_ = g_key + slot;
+        s.pay_ = g_pay + slot;
+        int *sl = g_sl + slot, *sr = g_sr + slot + ci;   // one spare element per list
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t e = ent[slot + i];
+            s.key_[i] = mode == 1 ? (float)(e & 255u) : resp[slot + i];
+            s.pay_[i] = e;
         }
-    done:
-        s_new_n = first;
+        __threadfence_block();
+        vs_sel::wave_sync_lds();
+        vs_sel::wave_nth_element(s, 0, n_points - 1, n, sl, sr);
+        __threadfence_block();
+        m = wave_std_partition(s, n_points, n, s.key(n_points - 1), sl, sr);
+        __threadfence_block();
+    } else {
+        unsigned char *base = smem + (size_t)wave * kEntries * 12;
+        s.key_ = reinterpret_cast<float *>(base);
+        s.pay_ = reinterpret_cast<uint32_t *>(base + (size_t)kEntries * 4);
+        uint16_t *sl = reinterpret_cast<uint16_t *>(base + (size_t)kEntries * 8);
+        uint16_t *sr = sl + kEntries;
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t e = ent[slot + i];
+            s.key_[i] = mode == 1 ? (float)(e & 255u) : resp[slot + i];
+            s.pay_[i] = e;
+        }
+        vs_sel::wave_sync_lds();
+        vs_sel::wave_nth_element(s, 0, n_points - 1, n, sl, sr);
+        m = wave_std_partition(s, n_points, n, s.key(n_points - 1), sl, sr);
     }
-    __syncthreads();
-    const int m = s_new_n;
-    for (int i = tid; i < m; i += 64) {
-        kp_resp[slot + i] = key[i];
-        xy_out[slot + i] = xy_in[slot + pay[i]];
-    }
-    if (tid == 0) *cnt = m;
+    for (int i = lane; i < m; i += 64) ent[slot + i] = s.pay_[i];
+    if (lane == 0) cnt_out[ci] = m;
 }
 
-// HarrisResponses(pyramid, keypoints, 7, 0.04) for every keypoint of every slot
-__global__ __launch_bounds__(256) void harris_kernel(PyrLayout L, SlotLayout SL, const uint8_t *__restrict__ pyr,
-                                                     const short2 *__restrict__ kp_xy, float *__restrict__ kp_resp,
-                                                     const int32_t *__restrict__ kp_cnt) {
-    const int u = blockIdx.z, l = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kp_cnt[(size_t)u * kMaxLevels + l]) return;
-    const size_t slot = (size_t)u * SL.off[L.nlevels] + SL.off[l];
-    const short2 p = kp_xy[slot + i];
-    const int step = L.bufw, blockSize = 7, r = blockSize / 2;
-    const uint8_t *ptr0 = pyr + (size_t)u * L.bufw * L.bufh + (size_t)(p.y - r + L.ly[l]) * step + p.x - r + L.lx[l];
-    int a = 0, b = 0, c = 0;
-    for (int yy = 0; yy < blockSize; yy++)
-        for (int xx = 0; xx < blockSize; xx++) {
-            const uint8_t *ptr = ptr0 + yy * step + xx;
-            const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-step + 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[step - 1]);
-            const int Iy = (ptr[step] - ptr[-step]) * 2 + (ptr[step - 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[-step + 1]);
-            a += Ix * Ix;
-            b += Iy * Iy;
-            c += Ix * Iy;
-        }
-    const float scale = 1.f / ((1 << 2) * blockSize * 255.f);
-    const float scale_sq_sq = scale * scale * scale * scale;
-    const float fa = (float)a, fb = (float)b, fc = (float)c;
-    const float t1 = fa * fb, t2 = fc * fc, sum = fa + fb;
-    const float t3 = 0.04f * sum;
-    const float t4 = t3 * sum;
-    kp_resp[slot + i] = ((t1 - t2) - t4) * scale_sq_sq;
+// HarrisResponses(pyramid, keypoints, 7, 0.04) for the lists the second retainBest will cut (n > quota)
+__global__ __launch_bounds__(256) void harris_kernel(Geom G, const uint8_t *__restrict__ gray, const uint8_t *__restrict__ cpyr,
+                                                     const uint32_t *__restrict__ ent, float *__restrict__ resp,
+                                                     const int32_t *__restrict__ cnt1, const uint8_t *__restrict__ flags) {
+    const int li = blockIdx.x;
+    const int l = li % G.nlv, ut = li / G.nlv, u = ut >> 1, t = ut & 1;
+    if (!(flags[u] & (1 << t))) return;
+    const int n = cnt1[(size_t)ut * kMaxLevels + l];
+    if (n <= G.per_level[l]) return;
+    const size_t slot = (size_t)ut * G.loff[G.nlv] + G.loff[l];
+    int step;
+    const uint8_t *img = cell_level(G, gray, cpyr, u, l, step);
+    const int rw = G.rw[l], blockSize = 7, r = blockSize / 2;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int idx = (int)(ent[slot + i] >> 8);
+        const int py = idx / rw, px = idx - py * rw;
+        const uint8_t *ptr0 = img + (size_t)(py + kEdge - r) * step + px + kEdge - r;
+        int a = 0, b = 0, c = 0;
+        for (int yy = 0; yy < blockSize; yy++)
+            for (int xx = 0; xx < blockSize; xx++) {
+                const uint8_t *ptr = ptr0 + yy * step + xx;
+                const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-step + 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[step - 1]);
+                const int Iy = (ptr[step] - ptr[-step]) * 2 + (ptr[step - 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[-step + 1]);
+                a += Ix * Ix;
+                b += Iy * Iy;
+                c += Ix * Iy;
+            }
+        const float scale = 1.f / ((1 << 2) * blockSize * 255.f);
+        const float scale_sq_sq = scale * scale * scale * scale;
+        const float fa = (float)a, fb = (float)b, fc = (float)c;
+        const float t1 = fa * fb, t2 = fc * fc, sum = fa + fb;
+        const float t3 = 0.04f * sum;
+        const float t4 = t3 * sum;
+        resp[slot + i] = ((t1 - t2) - t4) * scale_sq_sq;
+    }
 }
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fastAtan2
@@ -439,109 +706,180 @@ struct UmaxTable {
     int v[17];
 };
 
-// ICAngles + "pt *= scale": final per-slot keypoints (level coordinates -> cell coordinates)
-__global__ __launch_bounds__(256) void ic_angle_kernel(PyrLayout L, SlotLayout SL, UmaxTable U, const uint8_t *__restrict__ pyr,
-                                                       const short2 *__restrict__ kp_xy, const int32_t *__restrict__ kp_cnt,
-                                                       float4 *__restrict__ kp_final) {
-    const int u = blockIdx.z, l = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kp_cnt[(size_t)u * kMaxLevels + l]) return;
-    const size_t slot = (size_t)u * SL.off[L.nlevels] + SL.off[l];
-    const short2 p = kp_xy[slot + i];
-    const int step = L.bufw, half_k = 15;
-    const uint8_t *center = pyr + (size_t)u * L.bufw * L.bufh + (size_t)(p.y + L.ly[l]) * step + p.x + L.lx[l];
-    int m_01 = 0, m_10 = 0;
-    for (int uu = -half_k; uu <= half_k; ++uu) m_10 += uu * center[uu];
-    for (int v = 1; v <= half_k; ++v) {
-        int v_sum = 0;
-        const int d = U.v[v];
-        for (int uu = -d; uu <= d; ++uu) {
-            const int val_plus = center[uu + v * step], val_minus = center[uu - v * step];
-            v_sum += (val_plus - val_minus);
-            m_10 += uu * (val_plus + val_minus);
+// ICAngles: the angle of every final keypoint (into resp, whose Harris values are spent).  Half a wave per keypoint: lane j of
+// a half holds patch column j - 15, walks the 31 rows (contiguous bytes across the lanes) and the two integer moments are
+// summed over the half by shuffles.
+__global__ __launch_bounds__(256) void ic_angle_kernel(Geom G, UmaxTable U, const uint8_t *__restrict__ gray,
+                                                       const uint8_t *__restrict__ cpyr, const uint32_t *__restrict__ ent,
+                                                       float *__restrict__ resp, const int32_t *__restrict__ cnt2,
+                                                       const uint8_t *__restrict__ flags) {
+    const int li = blockIdx.x;
+    const int l = li % G.nlv, ut = li / G.nlv, u = ut >> 1, t = ut & 1;
+    if (!(flags[u] & (1 << t))) return;
+    const int n = cnt2[(size_t)ut * kMaxLevels + l];
+    if (n == 0) return;
+    const size_t slot = (size_t)ut * G.loff[G.nlv] + G.loff[l];
+    int step;
+    const uint8_t *img = cell_level(G, gray, cpyr, u, l, step);
+    const int rw = G.rw[l];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+    const int uo = j - 15;
+    const int auo = uo < 0 ? -uo : uo;
+    for (int i0 = wave * 2; i0 < n; i0 += 8) {
+        const int i = i0 + half;
+        const bool valid = i < n && j <= 30;
+        const int idx = (int)(ent[slot + (i < n ? i : 0)] >> 8);
+        const int py = idx / rw, px = idx - py * rw;
+        const uint8_t *center = img + (size_t)(py + kEdge) * step + px + kEdge;
+        int m_10 = 0, m_01 = 0;
+#pragma unroll
+        for (int v = -15; v <= 15; v++) {
+            const int d = U.v[v < 0 ? -v : v];
+            if (valid && auo <= d) {
+                const int val = center[v * step + uo];
+                m_10 += uo * val;
+                m_01 += v * val;
+            }
         }
-        m_01 += v * v_sum;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            m_10 += __shfl_xor(m_10, o, 64);
+            m_01 += __shfl_xor(m_01, o, 64);
+        }
+        if (i < n && j == 0) resp[slot + i] = fast_atan2_deg((float)m_01, (float)m_10);
     }
-    const float angle = fast_atan2_deg((float)m_01, (float)m_10);
-    const float sc = L.scale[l];
-    kp_final[slot + i] = make_float4((float)p.x * sc, (float)p.y * sc, angle, (float)l);
 }
 
 // ------------------------------------------------------------------------------------------
-// frame assembly: choose detector per cell (:34-36), shift (:37-40), runByImageBorder(31) on the
-// frame and ORB::compute's regrouping by level (stable).  One workgroup per frame.
+// frame assembly: choose the detector per cell (:34-36), "pt *= scale", shift (:37-40), runByImageBorder(31) on the
+// frame and ORB::compute's regrouping by level (stable: cell order inside a level).  One workgroup per frame; the
+// lists of a frame in output order = (level, cell).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grid_assemble_kernel(PyrLayout L, SlotLayout SL, int cells, int nrows, int cw, int ch,
-                                                            int w, int h, int nfeatures, const float4 *__restrict__ fin20,
-                                                            const int32_t *__restrict__ cnt20, const float4 *__restrict__ fin5,
-                                                            const int32_t *__restrict__ cnt5, int kp_cap,
-                                                            float4 *__restrict__ out_kp, int32_t *__restrict__ out_n) {
-    const int f = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    float4 *O = out_kp + (size_t)f * kp_cap;
-    for (int lvl = 0; lvl < L.nlevels; lvl++) {   // output is grouped by level, cell order inside
-        for (int c = 0; c < cells; c++) {
-            const int u = f * cells + c;
+__global__ __launch_bounds__(256) void grid_assemble_kernel(Geom G, const uint32_t *__restrict__ ent, const float *__restrict__ ang,
+                                                            const int32_t *__restrict__ cnt2, const uint8_t *__restrict__ flags,
+                                                            int kp_cap, float4 *__restrict__ out_kp, int32_t *__restrict__ out_n) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *kept = reinterpret_cast<int *>(smem);              // [nlv * cells] kept keypoints, then their exclusive prefix
+    uint8_t *sel = reinterpret_cast<uint8_t *>(kept + G.nlv * G.cells);   // [cells] detector chosen
+    __shared__ int s_total;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = G.nlv * G.cells;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int c = tid; c < G.cells; c += 256) {
+        const int u = f * G.cells + c;
+        const int fl = flags[u];
+        int t = 1;
+        if (!(fl & 2)) {
+            t = 0;                                  // the threshold-20 detector is certain to reach 500
+        } else if (fl & 1) {
             int tot20 = 0;
-            for (int k = 0; k < L.nlevels; k++) tot20 += cnt20[(size_t)u * kMaxLevels + k];
-            const bool use20 = tot20 >= nfeatures;   // `if (temp.size() < nfeatures)` -> fallback replaces
-            const float4 *src = (use20 ? fin20 : fin5) + (size_t)u * SL.off[L.nlevels] + SL.off[lvl];
-            const int n = (use20 ? cnt20 : cnt5)[(size_t)u * kMaxLevels + lvl];
-            const int ci = c / nrows, cj = c - ci * nrows;
-            const float sx = (float)(ci * cw), sy = (float)(cj * ch);
-            for (int i0 = 0; i0 < n; i0 += 256) {
-                const int i = i0 + tid;
+            for (int l = 0; l < G.nlv; l++) tot20 += cnt2[(size_t)(u * 2) * kMaxLevels + l];
+            t = tot20 >= kNFeatures ? 0 : 1;        // `if (temp.size() < nfeatures)` -> the fallback's result replaces it
+        }
+        sel[c] = (uint8_t)t;
+    }
+    __syncthreads();
+    const float wlim = (float)(G.w - kEdge), hlim = (float)(G.h - kEdge);
+    const bool none = G.h <= 2 * kEdge || G.w <= 2 * kEdge;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int q = wave; q < nl; q += 4) {
+            const int lvl = q / G.cells, c = q - lvl * G.cells;
+            const int ut = (f * G.cells + c) * 2 + sel[c];
+            const int n = cnt2[(size_t)ut * kMaxLevels + lvl];
+            const size_t slot = (size_t)ut * G.loff[G.nlv] + G.loff[lvl];
+            const int ci = c / G.nrows, cj = c - ci * G.nrows;
+            const float sx = (float)(ci * G.cw), sy = (float)(cj * G.ch), sc = G.scale[lvl];
+            const int rw = G.rw[lvl];
+            int base = pass ? kept[q] : 0, total = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
                 bool keep = false;
                 float4 k4 = make_float4(0, 0, 0, 0);
                 if (i < n) {
-                    k4 = src[i];
-                    k4.x = sx + k4.x;
-                    k4.y = sy + k4.y;
-                    keep = k4.x >= 31.f && k4.x < (float)(w - 31) && k4.y >= 31.f && k4.y < (float)(h - 31) &&
-                           !(h <= 62 || w <= 62);
+                    const int idx = (int)(ent[slot + i] >> 8);
+                    const int py = idx / rw, px = idx - py * rw;
+                    const float lx = (float)(px + kEdge) * sc, ly = (float)(py + kEdge) * sc;
+                    k4 = make_float4(sx + lx, sy + ly, pass ? ang[slot + i] : 0.f, (float)lvl);
+                    keep = !none && k4.x >= (float)kEdge && k4.x < wlim && k4.y >= (float)kEdge && k4.y < hlim;
                 }
                 const unsigned long long bal = __ballot(keep);
-                if (lane == 0) s_wave[wave] = (int)__popcll(bal);
-                __syncthreads();
-                int off = s_base;
-                for (int wv = 0; wv < wave; wv++) off += s_wave[wv];
-                off += (int)__popcll(bal & ((1ull << lane) - 1ull));
-                if (keep && off < kp_cap) O[off] = k4;
-                __syncthreads();
-                if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-                __syncthreads();
+                if (pass && keep) {
+                    const int o = base + total + (int)__popcll(bal & lt);
+                    if (o < kp_cap) out_kp[(size_t)f * kp_cap + o] = k4;
+                }
+                total += (int)__popcll(bal);
+            }
+            if (!pass && lane == 0) kept[q] = total;
+        }
+        __syncthreads();
+        if (!pass) {
+            if (wave == 0) {
+                int base = 0;
+                for (int j0 = 0; j0 < nl; j0 += 64) {
+                    const int jj = j0 + lane;
+                    const int v = jj < nl ? kept[jj] : 0;
+                    int inc = v;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int tt = __shfl_up(inc, o, 64);
+                        if (lane >= o) inc += tt;
+                    }
+                    if (jj < nl) kept[jj] = base + inc - v;
+                    base += __shfl(inc, 63, 64);
+                }
+                if (lane == 0) s_total = base;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) out_n[f] = min(s_total, kp_cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// ORB::compute: GaussianBlur 7x7 sigma 2 of levels >= 1 (level 0 goes through vs_launch_gaussian7), steered BRIEF
+// ------------------------------------------------------------------------------------------
+// One workgroup per 64 x 32 tile of a level; the margin carries the reflect values, so the tile is read as aligned dwords.
+__global__ __launch_bounds__(256) void pyr_blur_kernel(Geom G, int l, int tiles_x, int tiles_y, const uint8_t *__restrict__ fpyr,
+                                                       uint8_t *__restrict__ fblur) {
+    constexpr int TW = 64, TH = 32;
+    __shared__ uint32_t T[(TH + 6) * (TW / 4 + 2)];          // source columns x0 - 4 .. x0 + TW + 3
+    __shared__ uint16_t RP[(TH + 6) * TW];                   // horizontally filtered rows (Q8)
+    const int tid = threadIdx.x;
+    const int per = tiles_x * tiles_y;
+    const int f = blockIdx.x / per, tt = blockIdx.x - f * per;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int lw = G.flw[l], lh = G.flh[l], fs = G.fstride[l];
+    const uint8_t *src = fpyr + (size_t)f * G.fframe + G.foff[l];   // margin row 0, margin column 0; image (0, 0) at [3][4]
+    constexpr int TD = TW / 4 + 2;
+    const int rows = min(TH, lh - y0) + 6;
+    const int dwords = min(TD, (fs - x0) >> 2);                     // stay inside the row (fs is a multiple of 4)
+    for (int i = tid; i < rows * TD; i += 256) {
+        const int r = i / TD, c = i - r * TD;
+        T[i] = c < dwords ? *reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + r) * fs + x0 + 4 * c) : 0u;
+    }
+    __syncthreads();
+    const uint8_t *Tb = reinterpret_cast<const uint8_t *>(T);
+    for (int i = tid; i < rows * TW; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t *p = Tb + r * (TD * 4) + c + 1;                // image column x0 + c - 3 is byte (c + 1) of the row
+        RP[i] = (uint16_t)(18u * p[0] + 34u * p[1] + 48u * p[2] + 56u * p[3] + 48u * p[4] + 34u * p[5] + 18u * p[6]);
+    }
+    __syncthreads();
+    const int cx = tid & 63, ry = tid >> 6;
+    uint8_t *dst = fblur + (size_t)f * G.fframe + G.foff[l];
+    if (x0 + cx < lw) {
+#pragma unroll
+        for (int k = 0; k < TH / 4; k++) {
+            const int ly = ry * (TH / 4) + k, y = y0 + ly;
+            if (y < lh) {
+                const uint16_t *q = RP + ly * TW + cx;
+                const uint32_t s = 18u * q[0] + 34u * q[TW] + 48u * q[2 * TW] + 56u * q[3 * TW] + 48u * q[4 * TW] +
+                                   34u * q[5 * TW] + 18u * q[6 * TW];
+                dst[(size_t)(y + 3) * fs + x0 + cx + 4] = (uint8_t)((s + (1u << 15)) >> 16);
             }
         }
     }
-    if (tid == 0) out_n[f] = min(s_base, kp_cap);
-}
-
-// GaussianBlur 7x7 sigma 2 of every level's ROI, reading the (reflect-framed) source pyramid
-__global__ __launch_bounds__(256) void pyr_blur_kernel(PyrLayout L, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst) {
-    const int u = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= L.roi_prefix[L.nlevels]) return;
-    int l = 0;
-    while (i >= L.roi_prefix[l + 1]) l++;
-    const int r = i - L.roi_prefix[l];
-    const int y = r / L.lw[l], x = r - y * L.lw[l];
-    const size_t pos = (size_t)u * L.bufw * L.bufh + (size_t)(L.ly[l] + y) * L.bufw + L.lx[l] + x;
-    const uint8_t *c = src + pos;
-    const int s = L.bufw;
-    const int kq[7] = {18, 34, 48, 56, 48, 34, 18};
-    uint32_t acc = 0;
-#pragma unroll
-    for (int dy = -3; dy <= 3; dy++) {
-        uint32_t row = 0;
-#pragma unroll
-        for (int dx = -3; dx <= 3; dx++) row += (uint32_t)kq[dx + 3] * c[dy * s + dx];
-        acc += (uint32_t)kq[dy + 3] * row;
-    }
-    dst[pos] = (uint8_t)((acc + (1u << 15)) >> 16);
 }
 
 // pinned sin/cos of an angle in degrees (mirrors vso::sincos_deg_pinned operation for operation)
@@ -567,33 +905,59 @@ __device__ __forceinline__ void sincos_deg_pinned(float angle_deg, float &s_out,
     c_out = (float)c;
 }
 
-// computeOrbDescriptors: lane per (keypoint, byte) on the blurred frame pyramid
-__global__ __launch_bounds__(256) void orb_desc_kernel(PyrLayout L, const uint8_t *__restrict__ blurred,
+// computeOrbDescriptors: half a wave per keypoint, a lane per descriptor byte.  A sample inside the level's image reads the
+// blurred level; outside it the unblurred reflect value (what OpenCV's in-place blur leaves in the level's border).
+__global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, const uint8_t *__restrict__ gray, const uint8_t *__restrict__ blur0,
+                                                       const uint8_t *__restrict__ fpyr, const uint8_t *__restrict__ fblur,
                                                        const float4 *__restrict__ kps, const int32_t *__restrict__ n_arr,
                                                        int kp_cap, const int8_t *__restrict__ pattern,
                                                        uint8_t *__restrict__ desc, float *__restrict__ out_xy,
                                                        float *__restrict__ out_angle_octave) {
+    __shared__ int s_pat[256];
     const int f = blockIdx.y, tid = threadIdx.x;
+    s_pat[tid] = reinterpret_cast<const int *>(pattern)[tid];   // (x1, y1, x2, y2) as int8 x 4 per bit
+    __syncthreads();
     const int kp = blockIdx.x * 8 + (tid >> 5), byte = tid & 31;
     if (kp >= n_arr[f]) return;
     const float4 k4 = kps[(size_t)f * kp_cap + kp];
     const int l = (int)k4.w;
-    const float scale = 1.f / L.scale[l];
+    // per-level constants, selected without indexing the argument struct by a per-lane value
+    float lscale = G.scale[0];
+    int lw = G.flw[0], lh = G.flh[0], fs = G.fstride[0], fo = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxLevels; q++)
+        if (l == q) {
+            lscale = G.scale[q];
+            lw = G.flw[q];
+            lh = G.flh[q];
+            fs = G.fstride[q];
+            fo = G.foff[q];
+        }
+    const float scale = 1.f / lscale;
     float a, b;
     sincos_deg_pinned(k4.z, b, a);
     const int cx = (int)rintf(k4.x * scale), cy = (int)rintf(k4.y * scale);
-    const uint8_t *center = blurred + (size_t)f * L.bufw * L.bufh + (size_t)(cy + L.ly[l]) * L.bufw + cx + L.lx[l];
+    const uint8_t *img, *blr;   // pixel (0, 0) of the unblurred and the blurred level
+    if (l == 0) {
+        img = gray + (size_t)f * G.w * G.h;
+        blr = blur0 + (size_t)f * G.w * G.h;
+    } else {
+        img = fpyr + (size_t)f * G.fframe + fo + 3 * fs + 4;
+        blr = fblur + (size_t)f * G.fframe + fo + 3 * fs + 4;
+    }
     uint32_t val = 0;
 #pragma unroll
     for (int bit = 0; bit < 8; bit++) {
-        const int8_t *pp = pattern + (size_t)(byte * 8 + bit) * 4;
+        const int pp = s_pat[byte * 8 + bit];
         int t[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            const float fx = (float)pp[2 * e], fy = (float)pp[2 * e + 1];
+            const float fx = (float)(int8_t)(pp >> (16 * e)), fy = (float)(int8_t)(pp >> (16 * e + 8));
             const float a1 = fx * a, a2 = fy * b, b1 = fx * b, b2 = fy * a;
             const float rx = a1 - a2, ry = b1 + b2;
-            t[e] = center[(int)rintf(ry) * L.bufw + (int)rintf(rx)];
+            const int x = cx + (int)rintf(rx), y = cy + (int)rintf(ry);
+            if ((unsigned)x < (unsigned)lw && (unsigned)y < (unsigned)lh) t[e] = blr[(size_t)y * fs + x];
+            else t[e] = img[(size_t)reflect101(y, lh) * fs + reflect101(x, lw)];
         }
         val |= (uint32_t)(t[0] < t[1]) << bit;
     }
@@ -606,6 +970,11 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(PyrLayout L, const uint8_
             out_angle_octave[((size_t)f * kp_cap + kp) * 2 + 1] = k4.w;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void grid_zero_counts_kernel(int32_t *__restrict__ n_out, int frames) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < frames) n_out[i] = 0;
 }
 
 void umax_table(UmaxTable &U) {   // orb.cpp computeKeyPoints, halfPatchSize = 15
@@ -621,6 +990,36 @@ void umax_table(UmaxTable &U) {   // orb.cpp computeKeyPoints, halfPatchSize = 1
     }
 }
 
+// the retainBest tiers: lists of up to 1023 keypoints four to a workgroup, up to 8191 one to a workgroup, longer ones (one
+// cell of several megapixels) out of global scratch
+constexpr int kTierA = 1024, kTierB = 8192;
+
+int launch_retain(vslam_ctx *ctx, const Geom &G, int mode, int n_lists, int max_len, uint32_t *ent, const float *resp,
+                  const int32_t *cnt_in, int32_t *cnt_out, const uint8_t *flags, float *g_key, uint32_t *g_pay, int *g_sl,
+                  int *g_sr) {
+    hipStream_t st = ctx->stream;
+    {
+        auto k = retain_best_kernel<kTierA, 0, 4, false>;
+        retain_best_kernel<kTierA, 0, 4, false><<<vs_div_up(n_lists, 4), 256, (size_t)kTierA * 12 * 4, st>>>(
+            G, mode, n_lists, ent, resp, cnt_in, cnt_out, flags, nullptr, nullptr, nullptr, nullptr);
+        (void)k;
+    }
+    if (max_len + 1 > kTierA) {
+        auto k = retain_best_kernel<kTierB, kTierA, 1, false>;
+        if (!ctx->attr_done["orb_grid.retainB"]) {
+            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            kTierB * 12));
+            ctx->attr_done["orb_grid.retainB"] = true;
+        }
+        k<<<n_lists, 64, (size_t)kTierB * 12, st>>>(G, mode, n_lists, ent, resp, cnt_in, cnt_out, flags, nullptr, nullptr, nullptr,
+                                                    nullptr);
+    }
+    if (max_len + 1 > kTierB)
+        retain_best_kernel<0, kTierB, 1, true><<<n_lists, 64, 0, st>>>(G, mode, n_lists, ent, resp, cnt_in, cnt_out, flags, g_key,
+                                                                       g_pay, g_sl, g_sr);
+    return VSLAM_OK;
+}
+
 }  // namespace
 
 // extract_features(Frame&, nrows, ncols) for a batch of frames
@@ -629,116 +1028,121 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
                            int32_t *n_out) {
     VS_REQUIRE(ctx, bgr && pattern && xy && desc && n_out, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, frames > 0 && w > 0 && h > 0 && stride >= 3 * w && nrows > 0 && ncols > 0 && kp_cap > 0, VSLAM_ERR_INVALID);
-    const int nfeatures = 500, nlevels = 8;
-    const double scaleFactor = 1.2;
-    const int cw = w / ncols, ch = h / nrows;   // src/Frame.cpp:20
-    VS_REQUIRE(ctx, cw >= 7 && ch >= 7, VSLAM_ERR_INVALID);
-    VS_REQUIRE(ctx, cw < 32000 && ch < 32000, VSLAM_ERR_CAPACITY);
-    const int cells = nrows * ncols, units = frames * cells;
-    const PyrLayout LC = make_layout(cw, ch, nlevels, scaleFactor);
-    const PyrLayout LF = make_layout(w, h, nlevels, scaleFactor);
+    VS_REQUIRE(ctx, w / ncols >= 7 && h / nrows >= 7, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, w <= 32768 && h <= 32768 && nrows * ncols <= 2048, VSLAM_ERR_CAPACITY);
+    VS_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(pattern) & 3) == 0, VSLAM_ERR_INVALID);
+    Geom G;
+    make_geom(w, h, nrows, ncols, G);
+    const int cells = G.cells, units = frames * cells;
+    hipStream_t st = ctx->stream;
 
-    SlotLayout SL{};
-    {   // computeKeyPoints' nfeaturesPerLevel
-        const float factor = (float)(1.0 / scaleFactor);
-        float ndesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
-        int sum = 0;
-        for (int l = 0; l < nlevels - 1; l++) {
-            SL.per_level[l] = (int)std::lrint(ndesired);
-            sum += SL.per_level[l];
-            ndesired *= factor;
-        }
-        SL.per_level[nlevels - 1] = std::max(nfeatures - sum, 0);
-        SL.off[0] = 0;
-        for (int l = 0; l < nlevels; l++) {
-            const int rw = LC.lw[l] - 62, rh = LC.lh[l] - 62;   // NMS survivors are isolated: <= ceil(rw/2)*ceil(rh/2)
-            SL.cap[l] = (rw > 0 && rh > 0) ? ((rw + 1) / 2) * ((rh + 1) / 2) : 1;
-            SL.off[l + 1] = SL.off[l] + SL.cap[l];
-        }
+    uint8_t *gray = nullptr;
+    int rc;
+    if ((rc = vs_arena_get(ctx, "grid.gray", (size_t)frames * w * h, (void **)&gray))) return rc;
+    {   // :32 outlines into the caller's image + gray of the result (ORB converts BGR ROIs to gray)
+        VsProfScope ps(ctx, "grid_outline_gray_kernel");
+        if (w % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0)
+            grid_outline_gray4_kernel<<<dim3(vs_div_up((w / 4) * h, 256), frames), 256, 0, st>>>(bgr, w, h, stride, G.cw, G.ch, ncols,
+                                                                                                 nrows, gray);
+        else
+            grid_outline_gray_kernel<<<dim3(vs_div_up(w * h, 256), frames), 256, 0, st>>>(bgr, w, h, stride, G.cw, G.ch, ncols, nrows,
+                                                                                          gray);
+    }
+    if (G.nlv == 0) {   // no level of a cell's pyramid is larger than the 31-px border on every side: no keypoints at all
+        grid_zero_counts_kernel<<<vs_div_up(frames, 256), 256, 0, st>>>(n_out, frames);
+        VS_HIP(ctx, hipGetLastError());
+        return VSLAM_OK;
+    }
+    // one (cell, level) inner region is indexed in 24 bits and its strip tiles have to fit LDS
+    for (int l = 0; l < G.nlv; l++) VS_REQUIRE(ctx, (long long)G.rw[l] * G.rh[l] < (1ll << 24), VSLAM_ERR_CAPACITY);
+    int fast_lds = 0;
+    {
+        const int rw0 = G.rw[0];
+        const int SW = (rw0 + 8 + 3) & ~3, MW = (rw0 + 2 + 3) & ~3, CPR = (rw0 + 63) >> 6;
+        const int fixed = 8 * SW + 2 * MW + 256 * 4 + 64, per_row = SW + MW + CPR * 24;
+        int R = std::min(24, G.rh[0]);
+        while (R > 4 && fixed + per_row * R > 40 * 1024) R--;
+        fast_lds = fixed + per_row * R;
+        VS_REQUIRE(ctx, fast_lds <= 150 * 1024, VSLAM_ERR_CAPACITY);
+        VS_REQUIRE(ctx, fast_strip_rows(rw0, fast_lds) >= std::min(4, G.rh[0]), VSLAM_ERR_CAPACITY);
+    }
+
+    const size_t LT = (size_t)G.loff[G.nlv], slots = (size_t)units * 2 * LT;
+    uint8_t *cpyr = nullptr, *fpyr = nullptr, *fblur = nullptr, *blur0 = nullptr, *flags = nullptr;
+    uint32_t *tab = nullptr, *ent = nullptr;
+    float *resp = nullptr;
+    float4 *fkp = nullptr;
+    int32_t *cnt = nullptr;
+    if ((rc = vs_arena_get(ctx, "grid.cpyr", (size_t)G.cunit * units + 16, (void **)&cpyr))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.fpyr", (size_t)G.fframe * frames + 16, (void **)&fpyr))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.fblur", (size_t)G.fframe * frames + 16, (void **)&fblur))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.blur0", (size_t)frames * w * h, (void **)&blur0))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.tab", sizeof(uint32_t) * (size_t)(G.ttotal + 1), (void **)&tab))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.ent", sizeof(uint32_t) * slots, (void **)&ent))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.resp", sizeof(float) * slots, (void **)&resp))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.fkp", sizeof(float4) * (size_t)frames * kp_cap, (void **)&fkp))) return rc;
+    // counters: cnt0 / cnt1 / cnt2 [units][2][8], c1_20 [units][8]; flags [units]
+    const size_t cwords = (size_t)units * 2 * kMaxLevels;
+    if ((rc = vs_arena_get(ctx, "grid.cnt", sizeof(int32_t) * (3 * cwords + (size_t)units * kMaxLevels), (void **)&cnt))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.flags", (size_t)units, (void **)&flags))) return rc;
+    int32_t *cnt0 = cnt, *cnt1 = cnt + cwords, *cnt2 = cnt + 2 * cwords, *c1_20 = cnt + 3 * cwords;
+    float *g_key = nullptr;
+    uint32_t *g_pay = nullptr;
+    int *g_sl = nullptr, *g_sr = nullptr;
+    if (G.cap[0] + 1 > kTierB) {   // per-list global scratch for lists no LDS tier holds
+        if ((rc = vs_arena_get(ctx, "grid.sel_key", sizeof(float) * slots, (void **)&g_key))) return rc;
+        if ((rc = vs_arena_get(ctx, "grid.sel_pay", sizeof(uint32_t) * slots, (void **)&g_pay))) return rc;
+        if ((rc = vs_arena_get(ctx, "grid.sel_sl", sizeof(int) * slots, (void **)&g_sl))) return rc;
+        if ((rc = vs_arena_get(ctx, "grid.sel_sr", sizeof(int) * (slots + cwords + 1), (void **)&g_sr))) return rc;
     }
     UmaxTable U;
     umax_table(U);
 
-    const size_t cell_pyr = (size_t)LC.bufw * LC.bufh, frame_pyr = (size_t)LF.bufw * LF.bufh;
-    const size_t slots = (size_t)units * SL.off[nlevels];
-    uint8_t *gray = nullptr, *pyrc = nullptr, *mmap = nullptr, *pyrf = nullptr, *pyrb = nullptr;
-    short2 *kxy[2] = {nullptr, nullptr};
-    float *kresp[2] = {nullptr, nullptr};
-    float4 *kfin[2] = {nullptr, nullptr}, *fkp = nullptr;
-    int32_t *kcnt[2] = {nullptr, nullptr};
-    int rc;
-    if ((rc = vs_arena_get(ctx, "grid.gray", (size_t)frames * w * h, (void **)&gray))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.pyrc", cell_pyr * units, (void **)&pyrc))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.mmap", cell_pyr * units, (void **)&mmap))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.pyrf", frame_pyr * frames, (void **)&pyrf))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.pyrb", frame_pyr * frames, (void **)&pyrb))) return rc;
-    for (int t = 0; t < 2; t++) {
-        const std::string s = t ? "5" : "20";
-        if ((rc = vs_arena_get(ctx, ("grid.kxy" + s).c_str(), sizeof(short2) * slots, (void **)&kxy[t]))) return rc;
-        if ((rc = vs_arena_get(ctx, ("grid.kresp" + s).c_str(), sizeof(float) * slots, (void **)&kresp[t]))) return rc;
-        if ((rc = vs_arena_get(ctx, ("grid.kfin" + s).c_str(), sizeof(float4) * slots, (void **)&kfin[t]))) return rc;
-        if ((rc = vs_arena_get(ctx, ("grid.kcnt" + s).c_str(), sizeof(int32_t) * (size_t)units * kMaxLevels, (void **)&kcnt[t]))) return rc;
-    }
-    if ((rc = vs_arena_get(ctx, "grid.fkp", sizeof(float4) * (size_t)frames * kp_cap, (void **)&fkp))) return rc;
-    hipStream_t st = ctx->stream;
-
-    {   // :32 outlines into the caller's image + gray of the result (ORB converts BGR ROIs to gray)
-        VsProfScope ps(ctx, "grid_outline_gray_kernel");
-        grid_outline_gray_kernel<<<dim3(vs_div_up(w * h, 256), frames), 256, 0, st>>>(bgr, w, h, stride, cw, ch, ncols, nrows, gray);
-    }
-    {   // cell pyramids
+    if (G.nlv > 1) {   // both pyramids, level by level (each level is a resize of the one before)
         VsProfScope ps(ctx, "grid_pyramid_kernels");
-        const int e0 = (LC.lw[0] + 2 * LC.border) * (LC.lh[0] + 2 * LC.border);
-        pyr_level0_kernel<<<dim3(vs_div_up(e0, 256), units), 256, 0, st>>>(gray, w, h, cw, ch, ncols, nrows, LC, pyrc);
-        for (int l = 1; l < nlevels; l++) {
-            const int e = (LC.lw[l] + 2 * LC.border) * (LC.lh[l] + 2 * LC.border);
-            pyr_resize_kernel<<<dim3(vs_div_up(e, 256), units), 256, 0, st>>>(LC, l, pyrc);
+        resize_tables_kernel<<<vs_div_up(G.ttotal, 256), 256, 0, st>>>(G, tab);
+        for (int l = 1; l < G.nlv; l++) {
+            const int nbF = vs_div_up((G.fstride[l] / 4) * (G.flh[l] + 6), 256), nbC = vs_div_up((G.cstride[l] / 4) * G.clh[l], 256);
+            pyr_resize_kernel<<<frames * nbF + units * nbC, 256, 0, st>>>(G, l, frames, nbF, nbC, gray, fpyr, cpyr, tab);
         }
     }
     {
-        VsProfScope ps(ctx, "fast_score_kernel");
-        fast_score_kernel<<<dim3(vs_div_up(LC.roi_prefix[nlevels], 256), units), 256, 0, st>>>(LC, pyrc, mmap);
+        VsProfScope ps(ctx, "fast_collect_kernel");
+        if (fast_lds > 64 * 1024 && !ctx->attr_done["orb_grid.fast"]) {
+            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_collect_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            ctx->attr_done["orb_grid.fast"] = true;
+        }
+        fast_collect_kernel<<<units * G.nlv, 256, fast_lds, st>>>(G, units, fast_lds, gray, cpyr, ent, cnt0, c1_20);
+        grid_decide_kernel<<<vs_div_up(units, 256), 256, 0, st>>>(G, units, c1_20, flags);
     }
-    // selection work arrays: LDS for lists of up to 4095 keypoints, a per-slot global scratch beyond that
-    const int lds_entries = std::min(SL.cap[0] + 1, 4096);
-    const size_t sel_lds = (size_t)lds_entries * 16;
-    short2 *kxy_tmp = nullptr;
-    float *g_key = nullptr;
-    int *g_pay = nullptr, *g_sl = nullptr, *g_sr = nullptr;
-    if ((rc = vs_arena_get(ctx, "grid.kxy_tmp", sizeof(short2) * slots, (void **)&kxy_tmp))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.sel_key", sizeof(float) * slots, (void **)&g_key))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.sel_pay", sizeof(int) * slots, (void **)&g_pay))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.sel_sl", sizeof(int) * slots, (void **)&g_sl))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.sel_sr", sizeof(int) * (slots + (size_t)units * kMaxLevels + 1), (void **)&g_sr))) return rc;
-    const int thr[2] = {20, 5};   // src/Frame.cpp:22-23
-    for (int t = 0; t < 2; t++) {
-        VsProfScope ps(ctx, t ? "orb_detect_t5_kernels" : "orb_detect_t20_kernels");
-        fast_collect_kernel<<<dim3(nlevels, units), 256, 0, st>>>(LC, SL, mmap, thr[t], kxy[t], kresp[t], kcnt[t]);
-        retain_best_kernel<<<dim3(nlevels, units), 64, sel_lds, st>>>(LC, SL, 2, kxy[t], kxy_tmp, kresp[t], kcnt[t], lds_entries,
-                                                                      g_key, g_pay, g_sl, g_sr);
-        const int maxk = vs_div_up(SL.cap[0], 256);
-        harris_kernel<<<dim3(maxk, nlevels, units), 256, 0, st>>>(LC, SL, pyrc, kxy_tmp, kresp[t], kcnt[t]);
-        retain_best_kernel<<<dim3(nlevels, units), 64, sel_lds, st>>>(LC, SL, 1, kxy_tmp, kxy[t], kresp[t], kcnt[t], lds_entries,
-                                                                      g_key, g_pay, g_sl, g_sr);
-        ic_angle_kernel<<<dim3(maxk, nlevels, units), 256, 0, st>>>(LC, SL, U, pyrc, kxy[t], kcnt[t], kfin[t]);
+    const int n_lists = units * 2 * G.nlv;
+    {
+        VsProfScope ps(ctx, "orb_select_kernels");
+        if ((rc = launch_retain(ctx, G, 1, n_lists, G.cap[0], ent, resp, cnt0, cnt1, flags, g_key, g_pay, g_sl, g_sr))) return rc;
+        harris_kernel<<<n_lists, 256, 0, st>>>(G, gray, cpyr, ent, resp, cnt1, flags);
+        if ((rc = launch_retain(ctx, G, 2, n_lists, G.cap[0], ent, resp, cnt1, cnt2, flags, g_key, g_pay, g_sl, g_sr))) return rc;
+    }
+    {
+        VsProfScope ps(ctx, "ic_angle_kernel");
+        ic_angle_kernel<<<n_lists, 256, 0, st>>>(G, U, gray, cpyr, ent, resp, cnt2, flags);
     }
     {
         VsProfScope ps(ctx, "grid_assemble_kernel");
-        grid_assemble_kernel<<<frames, 256, 0, st>>>(LC, SL, cells, nrows, cw, ch, w, h, nfeatures, kfin[0], kcnt[0], kfin[1],
-                                                     kcnt[1], kp_cap, fkp, n_out);
+        const size_t lds = sizeof(int) * (size_t)G.nlv * cells + (size_t)cells + 16;
+        grid_assemble_kernel<<<frames, 256, lds, st>>>(G, ent, resp, cnt2, flags, kp_cap, fkp, n_out);
     }
-    {   // ORB::compute (:43): frame pyramid of the outlined image, per-level blur, steered BRIEF
+    {   // ORB::compute (:43): per-level blur of the outlined frame's pyramid, steered BRIEF
         VsProfScope ps(ctx, "orb_compute_kernels");
-        const int e0 = (LF.lw[0] + 2 * LF.border) * (LF.lh[0] + 2 * LF.border);
-        pyr_level0_kernel<<<dim3(vs_div_up(e0, 256), frames), 256, 0, st>>>(gray, w, h, w, h, 1, 1, LF, pyrf);
-        for (int l = 1; l < nlevels; l++) {
-            const int e = (LF.lw[l] + 2 * LF.border) * (LF.lh[l] + 2 * LF.border);
-            pyr_resize_kernel<<<dim3(vs_div_up(e, 256), frames), 256, 0, st>>>(LF, l, pyrf);
+        if (w >= 4 && h >= 4) {
+            if ((rc = vs_launch_gaussian7(ctx, gray, frames, w, h, blur0))) return rc;
         }
-        VS_HIP(ctx, hipMemcpyAsync(pyrb, pyrf, frame_pyr * frames, hipMemcpyDeviceToDevice, st));
-        pyr_blur_kernel<<<dim3(vs_div_up(LF.roi_prefix[nlevels], 256), frames), 256, 0, st>>>(LF, pyrf, pyrb);
-        orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(LF, pyrb, fkp, n_out, kp_cap, pattern, desc, xy,
-                                                                            angle_octave);
+        for (int l = 1; l < G.nlv; l++) {
+            const int tx = vs_div_up(G.flw[l], 64), ty = vs_div_up(G.flh[l], 32);
+            pyr_blur_kernel<<<frames * tx * ty, 256, 0, st>>>(G, l, tx, ty, fpyr, fblur);
+        }
+        orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(G, gray, blur0, fpyr, fblur, fkp, n_out, kp_cap, pattern, desc,
+                                                                            xy, angle_octave);
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
