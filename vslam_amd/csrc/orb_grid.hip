@@ -524,11 +524,21 @@ __global__ __launch_bounds__(256) void grid_decide_kernel(Geom G, int units, con
 // KeyPointsFilter::retainBest(list, n_points) (keypoint.cpp): nth_element by response descending, then
 // std::partition of the tail on response >= boundary.  One wave per list.
 // ------------------------------------------------------------------------------------------
-struct RespStore {
+struct RespStore {   // second retainBest: Harris response + the list entry it belongs to
     using value_type = int2;   // (response bits, payload)
     using key_type = float;
+    static constexpr int kBytes = 8;
     float *key_;
     uint32_t *pay_;
+    __device__ void bind(unsigned char *base, int entries) {
+        key_ = reinterpret_cast<float *>(base);
+        pay_ = reinterpret_cast<uint32_t *>(base + (size_t)entries * 4);
+    }
+    __device__ void load(int i, uint32_t e, float r) {
+        key_[i] = r;
+        pay_[i] = e;
+    }
+    __device__ uint32_t entry(int i) const { return pay_[i]; }
     __device__ int2 get(int i) const { return make_int2(__float_as_int(key_[i]), (int)pay_[i]); }
     __device__ void set(int i, const int2 &v) {
         key_[i] = __int_as_float(v.x);
@@ -544,11 +554,31 @@ struct RespStore {
     __device__ bool less(float a, float b) const { return a > b; }   // KeypointResponseGreater
 };
 
+struct ScoreStore {   // first retainBest: the FAST score is the low byte of the entry itself
+    using value_type = uint32_t;
+    using key_type = int;
+    static constexpr int kBytes = 4;
+    uint32_t *e_;
+    __device__ void bind(unsigned char *base, int) { e_ = reinterpret_cast<uint32_t *>(base); }
+    __device__ void load(int i, uint32_t e, float) { e_[i] = e; }
+    __device__ uint32_t entry(int i) const { return e_[i]; }
+    __device__ uint32_t get(int i) const { return e_[i]; }
+    __device__ void set(int i, const uint32_t &v) { e_[i] = v; }
+    __device__ void swap(int i, int j) {
+        const uint32_t a = e_[i], b = e_[j];
+        e_[i] = b;
+        e_[j] = a;
+    }
+    __device__ int key(int i) const { return (int)(e_[i] & 255u); }
+    __device__ int key_of(const uint32_t &v) const { return (int)(v & 255u); }
+    __device__ bool less(int a, int b) const { return a > b; }
+};
+
 // std::partition(first = a, last = b, key >= amb), bidirectional form: with L_k the k-th position from the left that fails
 // the predicate and R_k the k-th from the right that meets it, it swaps (L_k, R_k) while L_k < R_k and returns
 // a + (number that meet it).  Same stopper-list scheme as vs_sel::wave_partition.
-template <class I>
-__device__ int wave_std_partition(RespStore &s, int a, int b, float amb, I *sl, I *sr) {
+template <class S, class I>
+__device__ int wave_std_partition(S &s, int a, int b, typename S::key_type amb, I *sl, I *sr) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nL = 0, nR = 0;
@@ -578,18 +608,18 @@ __device__ int wave_std_partition(RespStore &s, int a, int b, float amb, I *sl, 
     return a + nR;
 }
 
-// mode 1: keys = FAST score, n_points = 2 * quota, cnt_in = cnt0, cnt_out = cnt1;  mode 2: keys = Harris response,
-// n_points = quota, cnt_in = cnt1, cnt_out = cnt2.  Survivors are written back to the front of the list in libstdc++'s order.
-// Tiers by list length n: kLo < n + 1 <= kEntries entries of LDS per wave (kGlobal: per-list global scratch, any length);
-// lists that retainBest leaves alone (n <= n_points) are settled by the tier with kLo == 0.
-template <int kEntries, int kLo, int kWaves, bool kGlobal>
-__global__ __launch_bounds__(64 * kWaves) void retain_best_kernel(Geom G, int mode, int n_lists, uint32_t *__restrict__ ent,
+// S = ScoreStore: keys = FAST score, n_points = 2 * quota, cnt_in = cnt0, cnt_out = cnt1;  S = RespStore: keys = Harris
+// response, n_points = quota, cnt_in = cnt1, cnt_out = cnt2.  Survivors are written back to the front of the list in libstdc++'s
+// order.  Tiers by list length n: kLo < n + 1 <= kEntries entries of LDS per wave (kGlobal: per-list global scratch, any
+// length); lists that retainBest leaves alone (n <= n_points) are settled by the tier with kLo == 0.
+template <class S, int kEntries, int kLo, int kWaves, bool kGlobal>
+__global__ __launch_bounds__(64 * kWaves) void retain_best_kernel(Geom G, int n_lists, uint32_t *__restrict__ ent,
                                                                   const float *__restrict__ resp,
                                                                   const int32_t *__restrict__ cnt_in, int32_t *__restrict__ cnt_out,
-                                                                  const uint8_t *__restrict__ flags, float *__restrict__ g_key,
-                                                                  uint32_t *__restrict__ g_pay, int *__restrict__ g_sl,
-                                                                  int *__restrict__ g_sr) {
+                                                                  const uint8_t *__restrict__ flags, unsigned char *__restrict__ g_store,
+                                                                  int *__restrict__ g_sl, int *__restrict__ g_sr) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool kScore = S::kBytes == 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = blockIdx.x * kWaves + wave;
     if (li >= n_lists) return;
@@ -597,7 +627,7 @@ __global__ __launch_bounds__(64 * kWaves) void retain_best_kernel(Geom G, int mo
     if (!(flags[u] & (1 << t))) return;
     const size_t ci = (size_t)ut * kMaxLevels + l;
     const int n = cnt_in[ci];
-    const int n_points = (mode == 1 ? 2 : 1) * G.per_level[l];
+    const int n_points = (kScore ? 2 : 1) * G.per_level[l];
     if (n <= n_points) {
         if (kLo == 0 && lane == 0) cnt_out[ci] = n;
         return;
@@ -608,17 +638,12 @@ __global__ __launch_bounds__(64 * kWaves) void retain_best_kernel(Geom G, int mo
     }
     if (n + 1 <= kLo || (!kGlobal && n + 1 > kEntries)) return;
     const size_t slot = (size_t)ut * G.loff[G.nlv] + G.loff[l];
-    RespStore s;
+    S s;
     int m;
     if constexpr (kGlobal) {
-        s.key_ = g_key + slot;
-        s.pay_ = g_pay + slot;
+        s.bind(g_store + slot * 8, G.cap[l]);   // 8 bytes per slot entry hold either store (cap[l] entries of this list's slot)
         int *sl = g_sl + slot, *sr = g_sr + slot + ci;   // one spare element per list
-        for (int i = lane; i < n; i += 64) {
-            const uint32_t e = ent[slot + i];
-            s.key_[i] = mode == 1 ? (float)(e & 255u) : resp[slot + i];
-            s.pay_[i] = e;
-        }
+        for (int i = lane; i < n; i += 64) s.load(i, ent[slot + i], kScore ? 0.f : resp[slot + i]);
         __threadfence_block();
         vs_sel::wave_sync_lds();
         vs_sel::wave_nth_element(s, 0, n_points - 1, n, sl, sr);
@@ -626,28 +651,24 @@ __global__ __launch_bounds__(64 * kWaves) void retain_best_kernel(Geom G, int mo
         m = wave_std_partition(s, n_points, n, s.key(n_points - 1), sl, sr);
         __threadfence_block();
     } else {
-        unsigned char *base = smem + (size_t)wave * kEntries * 12;
-        s.key_ = reinterpret_cast<float *>(base);
-        s.pay_ = reinterpret_cast<uint32_t *>(base + (size_t)kEntries * 4);
-        uint16_t *sl = reinterpret_cast<uint16_t *>(base + (size_t)kEntries * 8);
+        unsigned char *base = smem + (size_t)wave * kEntries * (S::kBytes + 4);
+        s.bind(base, kEntries);
+        uint16_t *sl = reinterpret_cast<uint16_t *>(base + (size_t)kEntries * S::kBytes);
         uint16_t *sr = sl + kEntries;
-        for (int i = lane; i < n; i += 64) {
-            const uint32_t e = ent[slot + i];
-            s.key_[i] = mode == 1 ? (float)(e & 255u) : resp[slot + i];
-            s.pay_[i] = e;
-        }
+        for (int i = lane; i < n; i += 64) s.load(i, ent[slot + i], kScore ? 0.f : resp[slot + i]);
         vs_sel::wave_sync_lds();
         vs_sel::wave_nth_element(s, 0, n_points - 1, n, sl, sr);
         m = wave_std_partition(s, n_points, n, s.key(n_points - 1), sl, sr);
     }
-    for (int i = lane; i < m; i += 64) ent[slot + i] = s.pay_[i];
+    for (int i = lane; i < m; i += 64) ent[slot + i] = s.entry(i);
     if (lane == 0) cnt_out[ci] = m;
 }
 
-// HarrisResponses(pyramid, keypoints, 7, 0.04) for the lists the second retainBest will cut (n > quota)
-__global__ __launch_bounds__(256) void harris_kernel(Geom G, const uint8_t *__restrict__ gray, const uint8_t *__restrict__ cpyr,
-                                                     const uint32_t *__restrict__ ent, float *__restrict__ resp,
-                                                     const int32_t *__restrict__ cnt1, const uint8_t *__restrict__ flags) {
+// HarrisResponses(pyramid, keypoints, 7, 0.04) for the lists the second retainBest will cut (n > quota).  A lane per
+// keypoint; its 9x9 window is fetched as 27 (unaligned) dwords before any arithmetic so that the loads are in flight together.
+__global__ __launch_bounds__(64) void harris_kernel(Geom G, const uint8_t *__restrict__ gray, const uint8_t *__restrict__ cpyr,
+                                                    const uint32_t *__restrict__ ent, float *__restrict__ resp,
+                                                    const int32_t *__restrict__ cnt1, const uint8_t *__restrict__ flags) {
     const int li = blockIdx.x;
     const int l = li % G.nlv, ut = li / G.nlv, u = ut >> 1, t = ut & 1;
     if (!(flags[u] & (1 << t))) return;
@@ -656,22 +677,30 @@ __global__ __launch_bounds__(256) void harris_kernel(Geom G, const uint8_t *__re
     const size_t slot = (size_t)ut * G.loff[G.nlv] + G.loff[l];
     int step;
     const uint8_t *img = cell_level(G, gray, cpyr, u, l, step);
-    const int rw = G.rw[l], blockSize = 7, r = blockSize / 2;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    const int rw = G.rw[l];
+    for (int i = threadIdx.x; i < n; i += 64) {
         const int idx = (int)(ent[slot + i] >> 8);
         const int py = idx / rw, px = idx - py * rw;
-        const uint8_t *ptr0 = img + (size_t)(py + kEdge - r) * step + px + kEdge - r;
+        const uint8_t *p0 = img + (size_t)(py + kEdge - 4) * step + px + kEdge - 4;   // window rows / columns -4 .. 4
+        uint32_t wv[9][3];
+#pragma unroll
+        for (int r = 0; r < 9; r++) __builtin_memcpy(wv[r], p0 + (size_t)r * step, 12);
         int a = 0, b = 0, c = 0;
-        for (int yy = 0; yy < blockSize; yy++)
-            for (int xx = 0; xx < blockSize; xx++) {
-                const uint8_t *ptr = ptr0 + yy * step + xx;
-                const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-step + 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[step - 1]);
-                const int Iy = (ptr[step] - ptr[-step]) * 2 + (ptr[step - 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[-step + 1]);
+#pragma unroll
+        for (int yy = 1; yy <= 7; yy++)
+#pragma unroll
+            for (int xx = 1; xx <= 7; xx++) {
+#define VS_W(R, C) ((int)((wv[R][(C) >> 2] >> (8 * ((C) & 3))) & 255u))
+                const int Ix = (VS_W(yy, xx + 1) - VS_W(yy, xx - 1)) * 2 + (VS_W(yy - 1, xx + 1) - VS_W(yy - 1, xx - 1)) +
+                               (VS_W(yy + 1, xx + 1) - VS_W(yy + 1, xx - 1));
+                const int Iy = (VS_W(yy + 1, xx) - VS_W(yy - 1, xx)) * 2 + (VS_W(yy + 1, xx - 1) - VS_W(yy - 1, xx - 1)) +
+                               (VS_W(yy + 1, xx + 1) - VS_W(yy - 1, xx + 1));
+#undef VS_W
                 a += Ix * Ix;
                 b += Iy * Iy;
                 c += Ix * Iy;
             }
-        const float scale = 1.f / ((1 << 2) * blockSize * 255.f);
+        const float scale = 1.f / ((1 << 2) * 7 * 255.f);
         const float scale_sq_sq = scale * scale * scale * scale;
         const float fa = (float)a, fb = (float)b, fc = (float)c;
         const float t1 = fa * fb, t2 = fc * fc, sum = fa + fb;
@@ -706,56 +735,13 @@ struct UmaxTable {
     int v[17];
 };
 
-// ICAngles: the angle of every final keypoint (into resp, whose Harris values are spent).  Half a wave per keypoint: lane j of
-// a half holds patch column j - 15, walks the 31 rows (contiguous bytes across the lanes) and the two integer moments are
-// summed over the half by shuffles.
-__global__ __launch_bounds__(256) void ic_angle_kernel(Geom G, UmaxTable U, const uint8_t *__restrict__ gray,
-                                                       const uint8_t *__restrict__ cpyr, const uint32_t *__restrict__ ent,
-                                                       float *__restrict__ resp, const int32_t *__restrict__ cnt2,
-                                                       const uint8_t *__restrict__ flags) {
-    const int li = blockIdx.x;
-    const int l = li % G.nlv, ut = li / G.nlv, u = ut >> 1, t = ut & 1;
-    if (!(flags[u] & (1 << t))) return;
-    const int n = cnt2[(size_t)ut * kMaxLevels + l];
-    if (n == 0) return;
-    const size_t slot = (size_t)ut * G.loff[G.nlv] + G.loff[l];
-    int step;
-    const uint8_t *img = cell_level(G, gray, cpyr, u, l, step);
-    const int rw = G.rw[l];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
-    const int uo = j - 15;
-    const int auo = uo < 0 ? -uo : uo;
-    for (int i0 = wave * 2; i0 < n; i0 += 8) {
-        const int i = i0 + half;
-        const bool valid = i < n && j <= 30;
-        const int idx = (int)(ent[slot + (i < n ? i : 0)] >> 8);
-        const int py = idx / rw, px = idx - py * rw;
-        const uint8_t *center = img + (size_t)(py + kEdge) * step + px + kEdge;
-        int m_10 = 0, m_01 = 0;
-#pragma unroll
-        for (int v = -15; v <= 15; v++) {
-            const int d = U.v[v < 0 ? -v : v];
-            if (valid && auo <= d) {
-                const int val = center[v * step + uo];
-                m_10 += uo * val;
-                m_01 += v * val;
-            }
-        }
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) {
-            m_10 += __shfl_xor(m_10, o, 64);
-            m_01 += __shfl_xor(m_01, o, 64);
-        }
-        if (i < n && j == 0) resp[slot + i] = fast_atan2_deg((float)m_01, (float)m_10);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // frame assembly: choose the detector per cell (:34-36), "pt *= scale", shift (:37-40), runByImageBorder(31) on the
 // frame and ORB::compute's regrouping by level (stable: cell order inside a level).  One workgroup per frame; the
-// lists of a frame in output order = (level, cell).
+// lists of a frame in output order = (level, cell).  Per keypoint: (x, y, raster index in the cell level's inner region,
+// cell << 4 | level); the angle is the descriptor kernel's job.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grid_assemble_kernel(Geom G, const uint32_t *__restrict__ ent, const float *__restrict__ ang,
+__global__ __launch_bounds__(256) void grid_assemble_kernel(Geom G, const uint32_t *__restrict__ ent,
                                                             const int32_t *__restrict__ cnt2, const uint8_t *__restrict__ flags,
                                                             int kp_cap, float4 *__restrict__ out_kp, int32_t *__restrict__ out_n) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -799,7 +785,9 @@ __global__ __launch_bounds__(256) void grid_assemble_kernel(Geom G, const uint32
                     const int idx = (int)(ent[slot + i] >> 8);
                     const int py = idx / rw, px = idx - py * rw;
                     const float lx = (float)(px + kEdge) * sc, ly = (float)(py + kEdge) * sc;
-                    k4 = make_float4(sx + lx, sy + ly, pass ? ang[slot + i] : 0.f, (float)lvl);
+                    // (x, y) in the frame, where the keypoint sits in its cell's level (the descriptor kernel finds the
+                    // intensity centroid there), the level
+                    k4 = make_float4(sx + lx, sy + ly, __int_as_float(idx), __int_as_float((c << 4) | lvl));
                     keep = !none && k4.x >= (float)kEdge && k4.x < wlim && k4.y >= (float)kEdge && k4.y < hlim;
                 }
                 const unsigned long long bal = __ballot(keep);
@@ -905,9 +893,13 @@ __device__ __forceinline__ void sincos_deg_pinned(float angle_deg, float &s_out,
     c_out = (float)c;
 }
 
-// computeOrbDescriptors: half a wave per keypoint, a lane per descriptor byte.  A sample inside the level's image reads the
-// blurred level; outside it the unblurred reflect value (what OpenCV's in-place blur leaves in the level's border).
-__global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, const uint8_t *__restrict__ gray, const uint8_t *__restrict__ blur0,
+// ICAngles + computeOrbDescriptors: half a wave per keypoint.
+// Angle: lane j of the half holds column j - 15 of the 31 x 31 patch around the keypoint in its CELL's pyramid level (rows are
+// contiguous bytes across the lanes); the two integer moments are summed over the half by shuffles.
+// Descriptor: a lane per byte on the FRAME's pyramid level.  A sample inside the level's image reads the blurred level;
+// outside it the unblurred reflect value (what OpenCV's in-place blur leaves in the level's border).
+__global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, const uint8_t *__restrict__ gray,
+                                                       const uint8_t *__restrict__ cpyr, const uint8_t *__restrict__ blur0,
                                                        const uint8_t *__restrict__ fpyr, const uint8_t *__restrict__ fblur,
                                                        const float4 *__restrict__ kps, const int32_t *__restrict__ n_arr,
                                                        int kp_cap, const int8_t *__restrict__ pattern,
@@ -918,12 +910,13 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, const uint8_t *__
     s_pat[tid] = reinterpret_cast<const int *>(pattern)[tid];   // (x1, y1, x2, y2) as int8 x 4 per bit
     __syncthreads();
     const int kp = blockIdx.x * 8 + (tid >> 5), byte = tid & 31;
-    if (kp >= n_arr[f]) return;
+    if (kp >= n_arr[f]) return;   // whole halves leave; the shuffles below stay inside a half
     const float4 k4 = kps[(size_t)f * kp_cap + kp];
-    const int l = (int)k4.w;
+    const int idx = __float_as_int(k4.z), cl = __float_as_int(k4.w);
+    const int l = cl & 15, c = cl >> 4;
     // per-level constants, selected without indexing the argument struct by a per-lane value
     float lscale = G.scale[0];
-    int lw = G.flw[0], lh = G.flh[0], fs = G.fstride[0], fo = 0;
+    int lw = G.flw[0], lh = G.flh[0], fs = G.fstride[0], fo = 0, rw = G.rw[0], cs = G.cstride[0], co = 0;
 #pragma unroll
     for (int q = 1; q < kMaxLevels; q++)
         if (l == q) {
@@ -932,10 +925,42 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, const uint8_t *__
             lh = G.flh[q];
             fs = G.fstride[q];
             fo = G.foff[q];
+            rw = G.rw[q];
+            cs = G.cstride[q];
+            co = G.coff[q];
         }
+    float angle;
+    {
+        const uint8_t *cimg;
+        if (l == 0) {
+            const int ci = c / G.nrows, cj = c - ci * G.nrows;
+            cimg = gray + (size_t)f * G.w * G.h + (size_t)(cj * G.ch) * G.w + ci * G.cw;
+        } else {
+            cimg = cpyr + (size_t)(f * G.cells + c) * G.cunit + co;
+        }
+        const int py = idx / rw, px = idx - py * rw;
+        const uint8_t *center = cimg + (size_t)(py + kEdge) * cs + px + kEdge;
+        const int uo = byte - 15, auo = uo < 0 ? -uo : uo;
+        int m_10 = 0, m_01 = 0;
+#pragma unroll
+        for (int v = -15; v <= 15; v++) {
+            const int d = U.v[v < 0 ? -v : v];
+            if (auo <= d) {   // lane 31 (uo = 16) never
+                const int val = center[v * cs + uo];
+                m_10 += uo * val;
+                m_01 += v * val;
+            }
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            m_10 += __shfl_xor(m_10, o, 64);
+            m_01 += __shfl_xor(m_01, o, 64);
+        }
+        angle = fast_atan2_deg((float)m_01, (float)m_10);
+    }
     const float scale = 1.f / lscale;
     float a, b;
-    sincos_deg_pinned(k4.z, b, a);
+    sincos_deg_pinned(angle, b, a);
     const int cx = (int)rintf(k4.x * scale), cy = (int)rintf(k4.y * scale);
     const uint8_t *img, *blr;   // pixel (0, 0) of the unblurred and the blurred level
     if (l == 0) {
@@ -966,8 +991,8 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, const uint8_t *__
         out_xy[((size_t)f * kp_cap + kp) * 2] = k4.x;
         out_xy[((size_t)f * kp_cap + kp) * 2 + 1] = k4.y;
         if (out_angle_octave) {
-            out_angle_octave[((size_t)f * kp_cap + kp) * 2] = k4.z;
-            out_angle_octave[((size_t)f * kp_cap + kp) * 2 + 1] = k4.w;
+            out_angle_octave[((size_t)f * kp_cap + kp) * 2] = angle;
+            out_angle_octave[((size_t)f * kp_cap + kp) * 2 + 1] = (float)l;
         }
     }
 }
@@ -990,33 +1015,31 @@ void umax_table(UmaxTable &U) {   // orb.cpp computeKeyPoints, halfPatchSize = 1
     }
 }
 
-// the retainBest tiers: lists of up to 1023 keypoints four to a workgroup, up to 8191 one to a workgroup, longer ones (one
-// cell of several megapixels) out of global scratch
-constexpr int kTierA = 1024, kTierB = 8192;
+// the retainBest tiers: lists of up to 511 keypoints four to a workgroup, up to 2047 and up to 8191 one to a workgroup (a
+// one-wave workgroup; LDS decides how many a CU holds), longer ones (one cell of several megapixels) out of global scratch
+constexpr int kTier1 = 512, kTier2 = 2048, kTier3 = 8192;
 
-int launch_retain(vslam_ctx *ctx, const Geom &G, int mode, int n_lists, int max_len, uint32_t *ent, const float *resp,
-                  const int32_t *cnt_in, int32_t *cnt_out, const uint8_t *flags, float *g_key, uint32_t *g_pay, int *g_sl,
-                  int *g_sr) {
+template <class S>
+int launch_retain(vslam_ctx *ctx, const Geom &G, int n_lists, int max_len, uint32_t *ent, const float *resp, const int32_t *cnt_in,
+                  int32_t *cnt_out, const uint8_t *flags, unsigned char *g_store, int *g_sl, int *g_sr) {
     hipStream_t st = ctx->stream;
-    {
-        auto k = retain_best_kernel<kTierA, 0, 4, false>;
-        retain_best_kernel<kTierA, 0, 4, false><<<vs_div_up(n_lists, 4), 256, (size_t)kTierA * 12 * 4, st>>>(
-            G, mode, n_lists, ent, resp, cnt_in, cnt_out, flags, nullptr, nullptr, nullptr, nullptr);
-        (void)k;
-    }
-    if (max_len + 1 > kTierA) {
-        auto k = retain_best_kernel<kTierB, kTierA, 1, false>;
-        if (!ctx->attr_done["orb_grid.retainB"]) {
-            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            kTierB * 12));
-            ctx->attr_done["orb_grid.retainB"] = true;
+    constexpr int per = S::kBytes + 4;
+    retain_best_kernel<S, kTier1, 0, 4, false><<<vs_div_up(n_lists, 4), 256, (size_t)kTier1 * per * 4, st>>>(
+        G, n_lists, ent, resp, cnt_in, cnt_out, flags, nullptr, nullptr, nullptr);
+    if (max_len + 1 > kTier1)
+        retain_best_kernel<S, kTier2, kTier1, 1, false><<<n_lists, 64, (size_t)kTier2 * per, st>>>(G, n_lists, ent, resp, cnt_in, cnt_out,
+                                                                                               flags, nullptr, nullptr, nullptr);
+    if (max_len + 1 > kTier2) {
+        auto k = retain_best_kernel<S, kTier3, kTier2, 1, false>;
+        const char *key = S::kBytes == 4 ? "orb_grid.retain3s" : "orb_grid.retain3r";
+        if (kTier3 * per > 64 * 1024 && !ctx->attr_done[key]) {
+            VS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kTier3 * per));
+            ctx->attr_done[key] = true;
         }
-        k<<<n_lists, 64, (size_t)kTierB * 12, st>>>(G, mode, n_lists, ent, resp, cnt_in, cnt_out, flags, nullptr, nullptr, nullptr,
-                                                    nullptr);
+        k<<<n_lists, 64, (size_t)kTier3 * per, st>>>(G, n_lists, ent, resp, cnt_in, cnt_out, flags, nullptr, nullptr, nullptr);
     }
-    if (max_len + 1 > kTierB)
-        retain_best_kernel<0, kTierB, 1, true><<<n_lists, 64, 0, st>>>(G, mode, n_lists, ent, resp, cnt_in, cnt_out, flags, g_key,
-                                                                       g_pay, g_sl, g_sr);
+    if (max_len + 1 > kTier3)
+        retain_best_kernel<S, 0, kTier3, 1, true><<<n_lists, 64, 0, st>>>(G, n_lists, ent, resp, cnt_in, cnt_out, flags, g_store, g_sl, g_sr);
     return VSLAM_OK;
 }
 
@@ -1086,12 +1109,10 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
     if ((rc = vs_arena_get(ctx, "grid.cnt", sizeof(int32_t) * (3 * cwords + (size_t)units * kMaxLevels), (void **)&cnt))) return rc;
     if ((rc = vs_arena_get(ctx, "grid.flags", (size_t)units, (void **)&flags))) return rc;
     int32_t *cnt0 = cnt, *cnt1 = cnt + cwords, *cnt2 = cnt + 2 * cwords, *c1_20 = cnt + 3 * cwords;
-    float *g_key = nullptr;
-    uint32_t *g_pay = nullptr;
+    unsigned char *g_store = nullptr;
     int *g_sl = nullptr, *g_sr = nullptr;
-    if (G.cap[0] + 1 > kTierB) {   // per-list global scratch for lists no LDS tier holds
-        if ((rc = vs_arena_get(ctx, "grid.sel_key", sizeof(float) * slots, (void **)&g_key))) return rc;
-        if ((rc = vs_arena_get(ctx, "grid.sel_pay", sizeof(uint32_t) * slots, (void **)&g_pay))) return rc;
+    if (G.cap[0] + 1 > kTier3) {   // per-list global scratch for lists no LDS tier holds
+        if ((rc = vs_arena_get(ctx, "grid.sel_store", 8 * slots, (void **)&g_store))) return rc;
         if ((rc = vs_arena_get(ctx, "grid.sel_sl", sizeof(int) * slots, (void **)&g_sl))) return rc;
         if ((rc = vs_arena_get(ctx, "grid.sel_sr", sizeof(int) * (slots + cwords + 1), (void **)&g_sr))) return rc;
     }
@@ -1119,18 +1140,14 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
     const int n_lists = units * 2 * G.nlv;
     {
         VsProfScope ps(ctx, "orb_select_kernels");
-        if ((rc = launch_retain(ctx, G, 1, n_lists, G.cap[0], ent, resp, cnt0, cnt1, flags, g_key, g_pay, g_sl, g_sr))) return rc;
-        harris_kernel<<<n_lists, 256, 0, st>>>(G, gray, cpyr, ent, resp, cnt1, flags);
-        if ((rc = launch_retain(ctx, G, 2, n_lists, G.cap[0], ent, resp, cnt1, cnt2, flags, g_key, g_pay, g_sl, g_sr))) return rc;
-    }
-    {
-        VsProfScope ps(ctx, "ic_angle_kernel");
-        ic_angle_kernel<<<n_lists, 256, 0, st>>>(G, U, gray, cpyr, ent, resp, cnt2, flags);
+        if ((rc = launch_retain<ScoreStore>(ctx, G, n_lists, G.cap[0], ent, resp, cnt0, cnt1, flags, g_store, g_sl, g_sr))) return rc;
+        harris_kernel<<<n_lists, 64, 0, st>>>(G, gray, cpyr, ent, resp, cnt1, flags);
+        if ((rc = launch_retain<RespStore>(ctx, G, n_lists, G.cap[0], ent, resp, cnt1, cnt2, flags, g_store, g_sl, g_sr))) return rc;
     }
     {
         VsProfScope ps(ctx, "grid_assemble_kernel");
         const size_t lds = sizeof(int) * (size_t)G.nlv * cells + (size_t)cells + 16;
-        grid_assemble_kernel<<<frames, 256, lds, st>>>(G, ent, resp, cnt2, flags, kp_cap, fkp, n_out);
+        grid_assemble_kernel<<<frames, 256, lds, st>>>(G, ent, cnt2, flags, kp_cap, fkp, n_out);
     }
     {   // ORB::compute (:43): per-level blur of the outlined frame's pyramid, steered BRIEF
         VsProfScope ps(ctx, "orb_compute_kernels");
@@ -1141,8 +1158,8 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
             const int tx = vs_div_up(G.flw[l], 64), ty = vs_div_up(G.flh[l], 32);
             pyr_blur_kernel<<<frames * tx * ty, 256, 0, st>>>(G, l, tx, ty, fpyr, fblur);
         }
-        orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(G, gray, blur0, fpyr, fblur, fkp, n_out, kp_cap, pattern, desc,
-                                                                            xy, angle_octave);
+        orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(G, U, gray, cpyr, blur0, fpyr, fblur, fkp, n_out, kp_cap,
+                                                                            pattern, desc, xy, angle_octave);
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
