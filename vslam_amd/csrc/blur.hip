@@ -133,9 +133,13 @@ __device__ __forceinline__ void blur_step(BlurState &st, const BlurArgs &a, int 
     }
 }
 
+// Rows [y_begin, y_end) of every image are produced (the whole image for the plain blur; the grid ORB extractor blurs pyramid
+// levels that carry their own reflect margin and asks for the rows between the margins only); frame_pitch = bytes from one
+// image to the next.
 __global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__restrict__ gray, int w, int h,
                                                                uint8_t *__restrict__ out, int seg_rows, int frames,
-                                                               int strips, int per_frame) {
+                                                               int strips, int per_frame, size_t frame_pitch, int y_begin,
+                                                               int y_end) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     int f, blk;   // a frame's strips and segments share an XCD (see min_eigen_stream_kernel)
@@ -143,14 +147,14 @@ __global__ __launch_bounds__(256) void gaussian7_stream_kernel(const uint8_t *__
     if (f >= frames) return;
     const int strip = blk % strips, segblk = blk / strips;
     BlurArgs a;
-    a.ys = (segblk * 4 + wave) * seg_rows;
-    if (a.ys >= h) return;   // whole wave; no barriers in this kernel
-    const int ye = a.ys + seg_rows < h ? a.ys + seg_rows : h;
+    a.ys = y_begin + (segblk * 4 + wave) * seg_rows;
+    if (a.ys >= y_end) return;   // whole wave; no barriers in this kernel
+    const int ye = a.ys + seg_rows < y_end ? a.ys + seg_rows : y_end;
     a.steps = ye - a.ys + 6;
     a.w = w;
     a.h = h;
-    a.src = gray + (size_t)f * w * h;
-    a.dst = out + (size_t)f * w * h;
+    a.src = gray + (size_t)f * frame_pitch;
+    a.dst = out + (size_t)f * frame_pitch;
     const int x0 = strip * 256;
     a.x = x0 + 4 * lane;
     a.own_lane = a.x < w;
@@ -190,7 +194,7 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
         const int seg_rows = vs_div_up(h, segs);
         const int per_frame = strips * vs_div_up(segs, 4);
         gaussian7_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(gray, w, h, out, seg_rows, frames,
-                                                                                          strips, per_frame);
+                                                                                          strips, per_frame, (size_t)w * h, 0, h);
     } else {
         dim3 grid(vs_div_up(w, kBTW), vs_div_up(h, kBTH), frames);
         gaussian7_kernel<<<grid, kBT, 0, ctx->stream>>>(gray, w, h, out);
@@ -199,3 +203,21 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     return VSLAM_OK;
 }
 
+
+// The same filter on rows [y_begin, y_end) of images of w x h bytes that lie frame_pitch bytes apart (w % 4 == 0, dword-aligned
+// rows): the caller's images carry the border values in their own margins, so no row or column this touches is reflected.
+int vs_launch_gaussian7_rows(vslam_ctx *ctx, const uint8_t *src, uint8_t *dst, int frames, size_t frame_pitch, int w, int h,
+                             int y_begin, int y_end) {
+    VS_REQUIRE(ctx, src && dst && frames > 0 && w >= 8 && w % 4 == 0 && frame_pitch % 4 == 0, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, y_begin >= 3 && y_end <= h - 3 && y_begin < y_end, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0, VSLAM_ERR_INVALID);
+    const int rows = y_end - y_begin;
+    const int strips = vs_div_up(w, 256);
+    const int segs = vs_stream_segments(rows, frames, strips);
+    const int seg_rows = vs_div_up(rows, segs);
+    const int per_frame = strips * vs_div_up(segs, 4);
+    gaussian7_stream_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(src, w, h, dst, seg_rows, frames, strips,
+                                                                                      per_frame, frame_pitch, y_begin, y_end);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}

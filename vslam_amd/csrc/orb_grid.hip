@@ -235,64 +235,118 @@ __global__ __launch_bounds__(256) void resize_tables_kernel(Geom G, uint32_t *__
     }
 }
 
-__device__ __forceinline__ uint32_t resize_px(const uint8_t *r0, const uint8_t *r1, int sw, uint32_t xt, uint32_t y0c, uint32_t y1c) {
+// One output pixel from rows r0 / r1 of the source; x0 = the source column that r0[0] / r1[0] hold
+__device__ __forceinline__ uint32_t resize_px(const uint8_t *r0, const uint8_t *r1, int x0, int sw, uint32_t xt, uint32_t y0c,
+                                              uint32_t y1c) {
     const int xo = (int)(xt & 0xffffu);
     const uint32_t x1c = xt >> 16, x0c = 256u - x1c;
     const int xb = min(xo + 1, sw - 1);
-    const uint32_t h0 = (uint32_t)r0[xo] * x0c + (uint32_t)r0[xb] * x1c;
-    const uint32_t h1 = (uint32_t)r1[xo] * x0c + (uint32_t)r1[xb] * x1c;
+    const uint32_t h0 = (uint32_t)r0[xo - x0] * x0c + (uint32_t)r0[xb - x0] * x1c;
+    const uint32_t h1 = (uint32_t)r1[xo - x0] * x0c + (uint32_t)r1[xb - x0] * x1c;
     const uint32_t v = h0 * y0c + h1 * y1c;
     return (v + (1u << 15)) >> 16;
 }
 
-// level l of every frame's pyramid (with its reflect margin) and of every cell's pyramid from level l - 1:
-// blocks [0, frames * nbF) take the frames, the rest the cells; a lane makes 4 pixels = one dword
-__global__ __launch_bounds__(256) void pyr_resize_kernel(Geom G, int l, int frames, int nbF, int nbC,
+// the index set {reflect101(t, n) : a <= t <= b} is the interval [lo, hi]
+__device__ __forceinline__ void reflect_range(int a, int b, int n, int &lo, int &hi) {
+    const int ra = reflect101(a, n), rb = reflect101(b, n);
+    lo = (a <= 0 && b >= 0) ? 0 : min(ra, rb);
+    hi = (a <= n - 1 && b >= n - 1) ? n - 1 : max(ra, rb);
+}
+
+// Level l of every frame's pyramid (with its reflect margin) and of every cell's pyramid from level l - 1.  Blocks
+// [0, frames * nbF) take the frames, the rest the cells; a workgroup makes a 64 x 16 tile, a lane 4 pixels = one dword.
+// The source pixels a tile touches form a box of about 78 x 21; it is fetched as (unaligned) dwords into LDS and the four
+// taps per pixel are LDS byte reads: per-lane byte gathers from global memory cost a wave 16 address cycles each.
+constexpr int kRTW = 64, kRTH = 16, kRBW = 112, kRBH = 40;   // tile; box capacity (row pitch kRBW bytes)
+
+__global__ __launch_bounds__(256) void pyr_resize_kernel(Geom G, int l, int frames, int nbF, int nbC, int txF, int txC,
                                                          const uint8_t *__restrict__ gray, uint8_t *__restrict__ fpyr,
                                                          uint8_t *__restrict__ cpyr, const uint32_t *__restrict__ tab) {
+    __shared__ uint32_t box[kRBH * kRBW / 4];
+    const int tid = threadIdx.x, row = tid >> 4, g = tid & 15;
     int b = blockIdx.x;
-    if (b < frames * nbF) {
-        const int f = b / nbF, blk = b - f * nbF;
-        const int lw = G.flw[l], lh = G.flh[l], fs = G.fstride[l], groups = fs >> 2, rows = lh + 6;
-        const int t = blk * 256 + threadIdx.x;
-        if (t >= groups * rows) return;
-        const int by = t / groups, g = t - by * groups;
-        const int y = reflect101(by - 3, lh);
-        const uint32_t yt = tab[G.tYF[l] + y];
-        const int yo = (int)(yt & 0xffffu);
-        const uint32_t y1c = yt >> 16, y0c = 256u - y1c;
-        const int sw = G.flw[l - 1], sh = G.flh[l - 1], ss = G.fstride[l - 1];
-        const uint8_t *S = l == 1 ? gray + (size_t)f * G.w * G.h : fpyr + (size_t)f * G.fframe + G.foff[l - 1] + 3 * ss + 4;
-        const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)min(yo + 1, sh - 1) * ss;
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = reflect101(4 * g + k - 4, lw);
-            out |= resize_px(r0, r1, sw, tab[G.tXF[l] + x], y0c, y1c) << (8 * k);
-        }
-        *reinterpret_cast<uint32_t *>(fpyr + (size_t)f * G.fframe + G.foff[l] + (size_t)by * fs + 4 * g) = out;
+    const bool is_frame = b < frames * nbF;
+    int img, tile, tiles_x, lw, lh, os, sw, sh, ss, tX, tY, out_w4, out_h;
+    const uint8_t *S;
+    uint8_t *D;
+    if (is_frame) {
+        img = b / nbF;
+        tile = b - img * nbF;
+        tiles_x = txF;
+        lw = G.flw[l]; lh = G.flh[l]; os = G.fstride[l];
+        sw = G.flw[l - 1]; sh = G.flh[l - 1]; ss = G.fstride[l - 1];
+        tX = G.tXF[l]; tY = G.tYF[l];
+        out_w4 = os >> 2; out_h = lh + 6;
+        S = l == 1 ? gray + (size_t)img * G.w * G.h : fpyr + (size_t)img * G.fframe + G.foff[l - 1] + 3 * ss + 4;
+        D = fpyr + (size_t)img * G.fframe + G.foff[l];
     } else {
         b -= frames * nbF;
-        const int u = b / nbC, blk = b - u * nbC;
-        const int lw = G.clw[l], lh = G.clh[l], cs = G.cstride[l], groups = cs >> 2;
-        const int t = blk * 256 + threadIdx.x;
-        if (t >= groups * lh) return;
-        const int y = t / groups, g = t - y * groups;
-        const uint32_t yt = tab[G.tYC[l] + y];
-        const int yo = (int)(yt & 0xffffu);
-        const uint32_t y1c = yt >> 16, y0c = 256u - y1c;
-        const int sw = G.clw[l - 1], sh = G.clh[l - 1];
-        int ss;
-        const uint8_t *S = cell_level(G, gray, cpyr, u, l - 1, ss);
-        const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)min(yo + 1, sh - 1) * ss;
-        uint32_t out = 0;
+        img = b / nbC;
+        tile = b - img * nbC;
+        tiles_x = txC;
+        lw = G.clw[l]; lh = G.clh[l]; os = G.cstride[l];
+        sw = G.clw[l - 1]; sh = G.clh[l - 1];
+        tX = G.tXC[l]; tY = G.tYC[l];
+        out_w4 = os >> 2; out_h = lh;
+        S = cell_level(G, gray, cpyr, img, l - 1, ss);
+        D = cpyr + (size_t)img * G.cunit + G.coff[l];
+    }
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    // output coordinates of this lane: dword column gx of the stored row, row gy; image coordinates differ by the margin
+    const int gx = tx * (kRTW / 4) + g, gy = ty * kRTH + row;
+    const int mx = is_frame ? 4 : 0, my = is_frame ? 3 : 0;
+    // source box of the whole tile (uniform): image x range of the tile's columns, y range of its rows
+    int xlo, xhi, ylo, yhi;
+    {
+        const int xa = tx * kRTW - mx, xb = min(tx * kRTW + kRTW - 1, os - 1) - mx;
+        const int ya = ty * kRTH - my, yb = min(ty * kRTH + kRTH - 1, out_h - 1) - my;
+        if (is_frame) {
+            reflect_range(xa, xb, lw, xlo, xhi);
+            reflect_range(ya, yb, lh, ylo, yhi);
+        } else {
+            xlo = xa; xhi = min(xb, lw - 1);
+            ylo = ya; yhi = yb;
+        }
+    }
+    const int bx0 = (int)(tab[tX + xlo] & 0xffffu), bx1 = min((int)(tab[tX + xhi] & 0xffffu) + 1, sw - 1);
+    const int by0 = (int)(tab[tY + ylo] & 0xffffu), by1 = min((int)(tab[tY + yhi] & 0xffffu) + 1, sh - 1);
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    const bool staged = bw <= kRBW - 4 && bh <= kRBH;   // (uniform) otherwise the taps come straight from global memory
+    if (staged) {
+        const int nd = (bw + 3) >> 2;   // <= 27 dwords per row
+        const int c = tid & 31;
+        if (c < nd)
+            for (int r = tid >> 5; r < bh; r += 8) {
+                uint32_t v;
+                __builtin_memcpy(&v, S + (size_t)(by0 + r) * ss + bx0 + 4 * c, 4);
+                box[r * (kRBW / 4) + c] = v;
+            }
+    }
+    __syncthreads();
+    if (gx >= out_w4 || gy >= out_h) return;
+    const int y = is_frame ? reflect101(gy - my, lh) : gy;
+    const uint32_t yt = tab[tY + y];
+    const int yo = (int)(yt & 0xffffu), yb = min(yo + 1, sh - 1);
+    const uint32_t y1c = yt >> 16, y0c = 256u - y1c;
+    uint32_t out = 0;
+    if (staged) {   // two code paths, not one pointer: LDS reads stay LDS reads (and no LDS offset ever goes negative)
+        const uint8_t *bb = reinterpret_cast<const uint8_t *>(box);
+        const uint8_t *r0 = bb + (yo - by0) * kRBW, *r1 = bb + (yb - by0) * kRBW;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int x = min(4 * g + k, lw - 1);
-            out |= resize_px(r0, r1, sw, tab[G.tXC[l] + x], y0c, y1c) << (8 * k);
+            const int x = is_frame ? reflect101(4 * gx + k - mx, lw) : min(4 * gx + k, lw - 1);
+            out |= resize_px(r0, r1, bx0, sw, tab[tX + x], y0c, y1c) << (8 * k);
         }
-        *reinterpret_cast<uint32_t *>(cpyr + (size_t)u * G.cunit + G.coff[l] + (size_t)y * cs + 4 * g) = out;
+    } else {
+        const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)yb * ss;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = is_frame ? reflect101(4 * gx + k - mx, lw) : min(4 * gx + k, lw - 1);
+            out |= resize_px(r0, r1, 0, sw, tab[tX + x], y0c, y1c) << (8 * k);
+        }
     }
+    *reinterpret_cast<uint32_t *>(D + (size_t)gy * os + 4 * gx) = out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -381,7 +435,7 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
     }
     L.hist[tid] = 0;
     if (tid < 2) L.tot[tid] = 0;
-    const uint32_t mS = 0xffffffffu / (uint32_t)(rw + 8) + 1u, mM = 0xffffffffu / (uint32_t)(rw + 2) + 1u;
+    const uint32_t mS = 0xffffffffu / (uint32_t)(L.SW >> 2) + 1u, mM = 0xffffffffu / (uint32_t)(rw + 2) + 1u;
     const uint32_t mC = 0xffffffffu / (uint32_t)L.CPR + 1u;
     uint32_t *list20 = lists + ((size_t)(u * 2 + 0)) * G.loff[G.nlv] + G.loff[l];
     uint32_t *list5 = lists + ((size_t)(u * 2 + 1)) * G.loff[G.nlv] + G.loff[l];
@@ -389,13 +443,27 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
 
     for (int y0 = 0; y0 < rh; y0 += L.R) {   // strip = inner rows [y0, y0 + rows)
         const int rows = min(L.R, rh - y0);
-        // 1. source tile: level rows 31 + y0 - 4 .. (rows + 8 of them), columns 27 .. lw - 28 (rw + 8)
+        // 1. source tile: level rows 31 + y0 - 4 .. (rows + 8 of them), columns 27 .. lw - 28 (rw + 8), as (unaligned) dwords,
+        //    eight loads in flight per lane (a dword may reach up to 3 bytes past the tile's last column: still inside the level's row)
         {
             const uint8_t *s0 = src + (size_t)(kEdge + y0 - 4) * stride + (kEdge - 4);
-            const int n = (rows + 8) * (rw + 8);
-            for (int i = tid; i < n; i += 256) {
-                const int r = div_magic(i, mS), c = i - r * (rw + 8);
-                L.S[r * L.SW + c] = s0[(size_t)r * stride + c];
+            const int dpr = L.SW >> 2, n = (rows + 8) * dpr;
+            uint32_t *S4 = reinterpret_cast<uint32_t *>(L.S);
+            for (int i0 = tid; i0 < n; i0 += 256 * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = i0 + 256 * k;
+                    if (i < n) {
+                        const int r = div_magic(i, mS), c = i - r * dpr;
+                        __builtin_memcpy(&v[k], s0 + (size_t)r * stride + 4 * c, 4);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = i0 + 256 * k;
+                    if (i < n) S4[i] = v[k];
+                }
             }
         }
         __syncthreads();
@@ -824,52 +892,8 @@ __global__ __launch_bounds__(256) void grid_assemble_kernel(Geom G, const uint32
 }
 
 // ------------------------------------------------------------------------------------------
-// ORB::compute: GaussianBlur 7x7 sigma 2 of levels >= 1 (level 0 goes through vs_launch_gaussian7), steered BRIEF
+// ORB::compute: GaussianBlur 7x7 sigma 2 per level (blur.hip's streaming kernel), intensity centroid, steered BRIEF
 // ------------------------------------------------------------------------------------------
-// One workgroup per 64 x 32 tile of a level; the margin carries the reflect values, so the tile is read as aligned dwords.
-__global__ __launch_bounds__(256) void pyr_blur_kernel(Geom G, int l, int tiles_x, int tiles_y, const uint8_t *__restrict__ fpyr,
-                                                       uint8_t *__restrict__ fblur) {
-    constexpr int TW = 64, TH = 32;
-    __shared__ uint32_t T[(TH + 6) * (TW / 4 + 2)];          // source columns x0 - 4 .. x0 + TW + 3
-    __shared__ uint16_t RP[(TH + 6) * TW];                   // horizontally filtered rows (Q8)
-    const int tid = threadIdx.x;
-    const int per = tiles_x * tiles_y;
-    const int f = blockIdx.x / per, tt = blockIdx.x - f * per;
-    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int lw = G.flw[l], lh = G.flh[l], fs = G.fstride[l];
-    const uint8_t *src = fpyr + (size_t)f * G.fframe + G.foff[l];   // margin row 0, margin column 0; image (0, 0) at [3][4]
-    constexpr int TD = TW / 4 + 2;
-    const int rows = min(TH, lh - y0) + 6;
-    const int dwords = min(TD, (fs - x0) >> 2);                     // stay inside the row (fs is a multiple of 4)
-    for (int i = tid; i < rows * TD; i += 256) {
-        const int r = i / TD, c = i - r * TD;
-        T[i] = c < dwords ? *reinterpret_cast<const uint32_t *>(src + (size_t)(y0 + r) * fs + x0 + 4 * c) : 0u;
-    }
-    __syncthreads();
-    const uint8_t *Tb = reinterpret_cast<const uint8_t *>(T);
-    for (int i = tid; i < rows * TW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t *p = Tb + r * (TD * 4) + c + 1;                // image column x0 + c - 3 is byte (c + 1) of the row
-        RP[i] = (uint16_t)(18u * p[0] + 34u * p[1] + 48u * p[2] + 56u * p[3] + 48u * p[4] + 34u * p[5] + 18u * p[6]);
-    }
-    __syncthreads();
-    const int cx = tid & 63, ry = tid >> 6;
-    uint8_t *dst = fblur + (size_t)f * G.fframe + G.foff[l];
-    if (x0 + cx < lw) {
-#pragma unroll
-        for (int k = 0; k < TH / 4; k++) {
-            const int ly = ry * (TH / 4) + k, y = y0 + ly;
-            if (y < lh) {
-                const uint16_t *q = RP + ly * TW + cx;
-                const uint32_t s = 18u * q[0] + 34u * q[TW] + 48u * q[2 * TW] + 56u * q[3 * TW] + 48u * q[4 * TW] +
-                                   34u * q[5 * TW] + 18u * q[6 * TW];
-                dst[(size_t)(y + 3) * fs + x0 + cx + 4] = (uint8_t)((s + (1u << 15)) >> 16);
-            }
-        }
-    }
-}
-
 // pinned sin/cos of an angle in degrees (mirrors vso::sincos_deg_pinned operation for operation)
 __device__ __forceinline__ void sincos_deg_pinned(float angle_deg, float &s_out, float &c_out) {
     const float ar = angle_deg * (float)(3.14159265358979323846 / 180.f);
@@ -1061,7 +1085,7 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
 
     uint8_t *gray = nullptr;
     int rc;
-    if ((rc = vs_arena_get(ctx, "grid.gray", (size_t)frames * w * h, (void **)&gray))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.gray", (size_t)frames * w * h + 16, (void **)&gray))) return rc;   // + slack: rows are read as dwords
     {   // :32 outlines into the caller's image + gray of the result (ORB converts BGR ROIs to gray)
         VsProfScope ps(ctx, "grid_outline_gray_kernel");
         if (w % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0)
@@ -1123,8 +1147,9 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
         VsProfScope ps(ctx, "grid_pyramid_kernels");
         resize_tables_kernel<<<vs_div_up(G.ttotal, 256), 256, 0, st>>>(G, tab);
         for (int l = 1; l < G.nlv; l++) {
-            const int nbF = vs_div_up((G.fstride[l] / 4) * (G.flh[l] + 6), 256), nbC = vs_div_up((G.cstride[l] / 4) * G.clh[l], 256);
-            pyr_resize_kernel<<<frames * nbF + units * nbC, 256, 0, st>>>(G, l, frames, nbF, nbC, gray, fpyr, cpyr, tab);
+            const int txF = vs_div_up(G.fstride[l], kRTW), txC = vs_div_up(G.cstride[l], kRTW);
+            const int nbF = txF * vs_div_up(G.flh[l] + 6, kRTH), nbC = txC * vs_div_up(G.clh[l], kRTH);
+            pyr_resize_kernel<<<frames * nbF + units * nbC, 256, 0, st>>>(G, l, frames, nbF, nbC, txF, txC, gray, fpyr, cpyr, tab);
         }
     }
     {
@@ -1154,10 +1179,12 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
         if (w >= 4 && h >= 4) {
             if ((rc = vs_launch_gaussian7(ctx, gray, frames, w, h, blur0))) return rc;
         }
-        for (int l = 1; l < G.nlv; l++) {
-            const int tx = vs_div_up(G.flw[l], 64), ty = vs_div_up(G.flh[l], 32);
-            pyr_blur_kernel<<<frames * tx * ty, 256, 0, st>>>(G, l, tx, ty, fpyr, fblur);
-        }
+        // levels >= 1 as images of fstride x (lh + 6) bytes whose margins hold the reflect values: rows 3 .. lh + 2 through the
+        // streaming blur (what it writes into the margin columns of fblur is never read)
+        for (int l = 1; l < G.nlv; l++)
+            if ((rc = vs_launch_gaussian7_rows(ctx, fpyr + G.foff[l], fblur + G.foff[l], frames, (size_t)G.fframe, G.fstride[l],
+                                               G.flh[l] + 6, 3, G.flh[l] + 3)))
+                return rc;
         orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(G, U, gray, cpyr, blur0, fpyr, fblur, fkp, n_out, kp_cap,
                                                                             pattern, desc, xy, angle_octave);
     }
