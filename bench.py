@@ -33,7 +33,13 @@ WORKLOADS = {
     "C2": (640, 480, 1000, 1024, 64),
     "C3": (1280, 720, 2000, 4096, 256),
     "C5": (1920, 1080, 4000, 8192, 512),
+    # the same step with the reference's OTHER extractor, extract_features(Frame&, nrows, ncols) (src/Frame.cpp:16-51: grid
+    # ORB/FAST, the one north_star names; its only call is commented out at src/vslam.cpp:63): 4 x 4 cells, every keypoint it
+    # finds (about 6800 per frame; "keypoints" = the slots per frame), then match + RANSAC as the live path.  Not the headline.
+    "C3g": (1280, 720, 8192, 4096, 32),
 }
+SEED_INDEX = {"C2": 0, "C3": 1, "C5": 2, "C3g": 3}   # seeds of the BASELINE configs stay what they were before C3g existed
+GRID = (4, 4)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -321,6 +327,186 @@ def oracle_on_frames(frames_a, frames_b, seeds, K, H, thr, gpu_out, pair0, what)
     return base, parity
 
 
+def grid_algorithmic_bytes(scope, w, h, kp):
+    """Compulsory HBM bytes PER FRAME of the grid extractor's stages (4 x 4 cells, levels 0-5 of an 8-level 1.2 pyramid hold
+    keypoints at 1280x720): inputs read once, outputs written once."""
+    px = w * h
+    lv = [1.0 / (1.2 ** (2 * l)) for l in range(6)]
+    pyr = px * sum(lv[1:])                      # one pyramid's levels 1..5
+    inner = sum(max(0.0, (w / 4 / 1.2 ** l - 62)) * max(0.0, (h / 4 / 1.2 ** l - 62)) for l in range(6)) * 16
+    return {"grid_outline_gray_kernel": 3 * px + px,
+            "grid_pyramid_kernels": 2 * (px * sum(lv[:5]) + pyr),          # frame + cell pyramids: level l - 1 in, level l out
+            "fast_collect_kernel": inner * (1 + 0.06 * 4),                    # inner regions in, list entries out
+            "orb_select_kernels": kp * 3 * (4 + 4 + 81),                      # entries + responses + 9x9 windows
+            "grid_assemble_kernel": kp * (4 + 16),
+            "orb_compute_kernels": 2 * (px + pyr) + kp * (961 + 512 + 16 + 48)}.get(scope, 0.0)
+
+
+def grid_workload(args):
+    """--workload C3g: the bench step with the grid ORB/FAST extractor in front (both frames of every pair), then the live
+    path's match + RANSAC on its keypoints.  Same contract as the main line; one GPU only (a secondary workload)."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import numpy as np
+    import torch
+    from vslam_amd import capi, shard, synth
+    from vslam_amd.capi import Pipeline
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    w, h, K, H, P = WORKLOADS["C3g"]
+    if args.pairs:
+        P = args.pairs
+    thr = 10.0
+    seed = 0x5EED0000 + SEED_INDEX["C3g"]
+    n_slots = max(1, min(16, args.in_flight))
+    pipe = Pipeline(0, n_slots)
+    ctx = pipe.contexts[0]
+    make_frames = synth.frames_torch if args.data == "easy" else synth.frames_torch_hard
+    pat = torch.from_numpy(synth.brief_pattern()).to(dev)
+
+    class Slot:
+        pass
+    slots = []
+    for s_ in range(n_slots):
+        sl = Slot()
+        sl.bgr = make_frames(seed + 7919 * s_, P, w, h, dev)
+        sl.seeds_np = shard.pair_seeds(seed, s_ * P, (s_ + 1) * P)
+        sl.seeds = torch.from_numpy(sl.seeds_np.view(np.int32)).to(dev)
+        sl.g = dict(xy=torch.zeros((2 * P, K, 2), dtype=torch.float32, device=dev),
+                    desc=torch.zeros((2 * P, K, 32), dtype=torch.uint8, device=dev),
+                    angle_octave=torch.zeros((2 * P, K, 2), dtype=torch.float32, device=dev),
+                    n=torch.zeros((2 * P,), dtype=torch.int32, device=dev))
+        sl.m = dict(matches=torch.zeros((P, K, 2), dtype=torch.int32, device=dev), best=torch.zeros((P, 4), dtype=torch.int32, device=dev),
+                    F=torch.zeros((P, 9), dtype=torch.float32, device=dev), prelim_m=torch.zeros((P,), dtype=torch.int32, device=dev))
+        sl.used = 0
+        slots.append(sl)
+    torch.cuda.synchronize(dev)
+
+    def run(c, sl):
+        g = c.extract_features_grid(sl.bgr, GRID[0], GRID[1], pat, K, out=sl.g)   # draws the cell outlines into sl.bgr (:32), every step
+        c.match_features(g["xy"][:P], g["desc"][:P], g["n"][:P], g["xy"][P:], g["desc"][P:], g["n"][P:], sl.seeds, H, thr, out=sl.m)
+
+    def step(k):
+        sl = slots[k % n_slots]
+        t, c = pipe.acquire()
+        run(c, sl)
+        pipe.commit(t)
+        sl.used += 1
+
+    for k in range(n_slots):
+        step(k)
+    pipe.drain()
+    for k in range(args.warmup):
+        step(k)
+    pipe.drain()
+    for sl in slots:
+        sl.used = 0
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    pipe.drain()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    ms_step = dt / args.steps * 1e3
+    used = [sl for sl in slots if sl.used > 0]
+    for sl in used:
+        sl.host = {k: v.cpu().numpy() for k, v in list(sl.g.items()) + list(sl.m.items())}
+        assert (sl.host["n"] > 1000).all() and (sl.host["best"][:, 0] >= 0).all() and (sl.host["best"][:, 3] >= 8).all(), "bench output degenerate"
+    n_kp = np.concatenate([sl.host["n"] for sl in used])
+    best = np.concatenate([sl.host["best"] for sl in used])
+    data_label = {"easy": "easy data: translated texture + one moving block",
+                  "hard": "SURVEY 8(d) data: rotation + parallax, sub-pixel resampling"}[args.data]
+    result = {
+        "metric": "frame-pairs/sec (grid ORB/FAST extract+match+RANSAC) @1280x720, 4x4 cells, 4096 hyp; secondary workload, not BASELINE.json's headline",
+        "value": P * args.steps / dt, "unit": "frame-pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
+        "data": "synthetic (" + data_label + ")",
+        "config": {"workload": f"C3g: {w}x{h}, grid ORB/FAST extractor (src/Frame.cpp:16-51) {GRID[0]}x{GRID[1]} cells on both frames of a pair, "
+                               f"all its keypoints ({K} slots per frame), {H} hypotheses, batch {P} pairs per GPU, {data_label}",
+                   "pairs_per_gpu": P, "batches_in_flight": n_slots, "parallelism": f"one GPU; {n_slots} batch(es) in flight (vslam_pipeline_*)"},
+        "setup_steps": n_slots, "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
+        "workspace_bytes": pipe.workspace_bytes(), "workspace_bytes_per_context": ctx.workspace_bytes(),
+    }
+    exit_code = 0
+    if not args.no_profile_pass:   # per-stage times, HIP events on the stream, one context, one batch after the other
+        s0 = slots[0]
+        psteps = 3
+        # the extractor alone (what tools/grid_bench.py times)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ctx.extract_features_grid(s0.bgr, GRID[0], GRID[1], pat, K, out=s0.g)
+        ctx.synchronize()
+        ext_ms = (time.perf_counter() - t1) / 10 * 1e3
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        for _ in range(psteps):
+            run(ctx, s0)
+        rep = ctx.prof_report()
+        ctx.prof_enable(False)
+        mean_kp = float(n_kp.mean())
+        ks = []
+        for name, (ms, cnt) in rep.items():
+            per = ms / max(cnt, 1)
+            alg = grid_algorithmic_bytes(name, w, h, mean_kp) * 2 * P
+            k = {"kernel": name, "ms_per_launch": per, "launches_per_step": cnt / psteps}
+            if alg:
+                k["alg_bytes_per_launch"] = alg
+                k["alg_GBps"] = alg / (per * 1e-3) / 1e9 if per > 0 else 0.0
+            ks.append(k)
+        ks.sort(key=lambda k: -k["ms_per_launch"] * k["launches_per_step"])
+        result["kernels"] = ks
+        result["grid_extractor"] = {"ms_per_call": ext_ms, "frames": 2 * P, "us_per_frame": ext_ms / (2 * P) * 1e3,
+                                    "what": "vslam_extract_features_grid alone on the batch's 2 x pairs frames, one context, 10 calls; "
+                                            "the stages inside it are the grid_* / fast_* / orb_* rows of `kernels` (HIP events around each stage)"}
+        gk = [k for k in ks if "alg_bytes_per_launch" in k]
+        if gk:
+            top = gk[0]
+            result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": top["alg_GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": top["ms_per_launch"],
+                                  "note": "stage of the grid extractor with the largest share of the step; algorithmic bytes as "
+                                          "grid_algorithmic_bytes() states them; the FAST stage is bound by its vector arithmetic, not by bandwidth"}
+    # parity of what was timed + CPU baseline: the oracle on the very frames the device processed
+    n_chk = min(P, args.cpu_pairs if args.cpu_pairs > 0 else 2, 8)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    o = Oracle()
+    patn = synth.brief_pattern()
+    sl = used[0]
+    fa, fb = sl.bgr[:n_chk].cpu().numpy(), sl.bgr[P:P + n_chk].cpu().numpy()
+    bad = []
+    t1 = time.perf_counter()
+    for p_ in range(n_chk):
+        ra = o.extract_features_grid(fa[p_], GRID[0], GRID[1], patn)
+        rb = o.extract_features_grid(fb[p_], GRID[0], GRID[1], patn)
+        ref = o.match_features(ra[1], ra[2], rb[1], rb[2], int(sl.seeds_np[p_]) & 0xFFFFFFFF, H, thr)
+        na, nb, k = len(ra[1]), len(rb[1]), len(ref["matches"])
+        ho = sl.host
+        ok = (int(ho["n"][p_]) == na and int(ho["n"][P + p_]) == nb and np.array_equal(ho["xy"][p_, :na].view(np.uint32), ra[1].view(np.uint32))
+              and np.array_equal(ho["desc"][p_, :na], ra[2]) and np.array_equal(ho["desc"][P + p_, :nb], rb[2])
+              and int(ho["best"][p_, 3]) == k and np.array_equal(ho["matches"][p_, :k], ref["matches"])
+              and np.array_equal(ho["F"][p_].view(np.uint32), np.asarray(ref["F"], np.float32).reshape(-1).view(np.uint32)))
+        if not ok:
+            bad.append(p_)
+    secs = time.perf_counter() - t1
+    result["parity_in_bench"] = {"pairs": n_chk, "bit_exact": not bad,
+                                 "checked": "keypoint counts, coordinates and descriptors of both frames (grid extractor), inlier-match lists and F (as "
+                                            "uint32) of the timed steps' output vs the oracle on the same bytes"}
+    if bad:
+        result["parity_in_bench"]["mismatching_pairs"] = bad
+        exit_code = 3
+    if args.cpu_pairs > 0:
+        result["cpu_baseline"] = {"value": n_chk / secs, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                                  "sample": f"{n_chk} pairs of the timed batch copied back from the device, oracle single thread, {secs:.1f} s"}
+    pipe.close()
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    os.close(real_stdout)
+    return exit_code
+
+
 def self_launch(n_gpus, argv):
     """--gpus N > 1 without a launcher: start the ranks as a CHILD process tree (never exec: this parent has
     not imported torch or touched the GPU, and it stays alive to relay the result).  Rank 0's JSON line is the
@@ -428,6 +614,10 @@ def main():
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if os.environ.get("VSLAM_BENCH_DRY"):
         sys.exit(dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))))
+    if args.workload == "C3g":
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            sys.exit("bench.py: C3g (grid extractor workload) is a one-GPU secondary measurement")
+        sys.exit(grid_workload(args))
 
     # The contract is ONE line on stdout.  RCCL prints a version banner there when its communicator comes up and gloo its
     # connection notes, from C code: hand every such write to stderr by pointing fd 1 at it for the whole run, and write
@@ -469,7 +659,7 @@ def main():
     if args.pairs:
         P = args.pairs
     thr = 10.0                                    # RansacFilter rf(8, 100, 10), src/vslam.cpp:19
-    seed = 0x5EED0000 + sorted(WORKLOADS).index(args.workload)
+    seed = 0x5EED0000 + SEED_INDEX[args.workload]
     n_slots = max(1, min(16, args.in_flight))
     pipe = Pipeline(local_rank, n_slots)
     if args.solver == "gram":
@@ -793,91 +983,128 @@ def main():
     # ---- secondary measurements (rank 0, one GPU): one context, the in-flight sweep, the other data regime, the
     # full-evaluation worst case, the other workloads with their own per-kernel pass
     if rank == 0 and world == 1 and not args.no_extras:
-        s0 = slots[0]
+        try:
+            s0 = slots[0]
 
-        def child(extra, timeout=600):
-            """Another configuration of this bench in a FRESH PROCESS (child, never exec): which hardware queue a stream lands on
-            depends on what a process created before it, and that mapping moves a step by several per cent -- a second pipeline made
-            in this process would not be comparable with the first (HISTORY.md, round 5).  Returns the child's line."""
-            import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras", "--cpu-pairs", "0", "--cpu-all-cores-pairs", "0",
-                   "--data", args.data, "--solver", args.solver] + extra
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VSLAM_BENCH_FORCE_DIST")}
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout, env=env)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode != 0 or not lines:
-                return None
-            return json.loads(lines[-1])
+            def child(extra, timeout=600):
+                """Another configuration of this bench in a FRESH PROCESS (child, never exec): which hardware queue a stream lands on
+                depends on what a process created before it, and that mapping moves a step by several per cent -- a second pipeline made
+                in this process would not be comparable with the first (HISTORY.md, round 5).  Returns the child's line; a child that
+                times out, exits non-zero or prints no line comes back as {"failed": True, ...} with the tail of its stderr (a parity
+                mismatch -- exit code 3 -- still carries its line under "line")."""
+                import subprocess
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras", "--cpu-pairs", "0", "--cpu-all-cores-pairs", "0",
+                       "--data", args.data, "--solver", args.solver] + extra
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VSLAM_BENCH_FORCE_DIST")}
+                try:
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=env)
+                except subprocess.TimeoutExpired as e:
+                    err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+                    return {"failed": True, "reason": f"no result within {timeout} s", "args": extra, "stderr_tail": err[-600:]}
+                except OSError as e:
+                    return {"failed": True, "reason": repr(e), "args": extra}
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                line = None
+                if lines:
+                    try:
+                        line = json.loads(lines[-1])
+                    except ValueError:
+                        line = None
+                if r.returncode != 0 or line is None:
+                    return {"failed": True, "returncode": r.returncode, "args": extra, "stderr_tail": r.stderr[-600:], "line": line}
+                return line
 
-        sweep = {}
-        for d in (1, 2, 3, 4, 6):
-            if d == n_slots and args.steps >= 20:
-                sweep[str(d)] = {"contexts": d, "ms_per_batch": ms_step, "frame_pairs_per_s": P / ms_step * 1e3, "from": "the timed loop above"}
-                continue
-            c = child(["--workload", args.workload, "--pairs", str(P), "--in-flight", str(d), "--steps", "40", "--warmup", "8", "--no-profile-pass"])
-            if c:
-                sweep[str(d)] = {"contexts": d, "ms_per_batch": c["ms_per_step"], "frame_pairs_per_s": c["value"],
-                                 "parity_in_bench": c["parity_in_bench"]["bit_exact"], "from": "a fresh process, 40 steps"}
-        result["in_flight_sweep"] = sweep
-        if "1" in sweep:
-            result["single_context"] = {"ms_per_step": sweep["1"]["ms_per_batch"], "frame_pairs_per_s": sweep["1"]["frame_pairs_per_s"],
-                                        "what": "one batch after the other on one context (the headline arrangement of rounds 1-4), same data regime, fresh process"}
+            def child_parity_ok(c):
+                """False when a child's own in-bench parity check found a difference (its line is kept; the exit code says so)."""
+                line = c.get("line") if c.get("failed") else c
+                return not (line and line.get("parity_in_bench") and line["parity_in_bench"].get("bit_exact") is False)
 
-        def kernel_ms(c, frames, pairs, kk, hh, sd, names):
-            rep = profile_pass(c, frames, pairs, kk, hh, sd, 1)
-            return {nm: rep[nm][0] / max(rep[nm][1], 1) for nm in names if nm in rep}
-
-        scoring = ("ransac_rank_kernel", "ransac_screen_kernel", "ransac_cand_kernel", "ransac_count_kernel",
-                   "ransac_ties_kernel", "ransac_tiesum_kernel", "ransac_select_kernel", "ransac_score_kernel")
-        regimes = {}
-        other = "hard" if args.data == "easy" else "easy"
-        for kind in (args.data, other):
-            frames = s0.bgr if kind == args.data else (synth.frames_torch if kind == "easy" else synth.frames_torch_hard)(seed, P, w, h, dev)
-            ms, o = timed_single(ctx, frames, P, K, H, s0.seeds)
-            ho = {k: o[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
-            entry = {"ms_per_step": ms, "frame_pairs_per_s": P / ms * 1e3, "contexts": 1, "mean_keypoints": float(ho["n"].mean()),
-                     "mean_inlier_matches": float(ho["best"][:, 3].mean()),
-                     "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring)}
-            # worst case of the data-dependent scoring kernels: every (hypothesis, match) pair evaluated, every sum formed
-            ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, True)
-            ms_all, _ = timed_single(ctx, frames, P, K, H, s0.seeds, steps=5)
-            entry["full_evaluation"] = {"ms_per_step": ms_all, "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring),
-                                        "what": "VSLAM_OPT_RANSAC_ALL_SUMS: no bail-out, no screen: the count and residual sum of every hypothesis"}
-            ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
-            if kind != args.data:   # the timed batches were checked above; check this regime's output too
-                nchk = min(P, 24)
-                _, par = oracle_on_frames(frames[:nchk].cpu().numpy(), frames[P:P + nchk].cpu().numpy(), s0.seeds_np[:nchk], K, H, thr, ho, 0,
-                                          args.workload + ", " + kind + " data")
-                entry["parity_in_bench"] = par
-                if not par["bit_exact"]:
+            sweep = {}
+            for d in (1, 2, 3, 4, 6):
+                if d == n_slots and args.steps >= 20:
+                    sweep[str(d)] = {"contexts": d, "ms_per_batch": ms_step, "frame_pairs_per_s": P / ms_step * 1e3, "from": "the timed loop above"}
+                    continue
+                c = child(["--workload", args.workload, "--pairs", str(P), "--in-flight", str(d), "--steps", "40", "--warmup", "8", "--no-profile-pass"])
+                if not child_parity_ok(c):
                     exit_code = 3
-                del frames
-            regimes[kind] = entry
-        result["data_regimes"] = regimes
-        others = {}
-        for wl in sorted(WORKLOADS):   # each in a process of its own (see child): headline arrangement, own per-kernel pass
-            if wl == args.workload:
-                continue
-            w2, h2, K2, H2, P2 = WORKLOADS[wl]
-            c = child(["--workload", wl, "--in-flight", str(n_slots), "--steps", "24" if wl != "C5" else "12", "--warmup", "4"])
-            c1 = child(["--workload", wl, "--in-flight", "1", "--steps", "12" if wl != "C5" else "6", "--warmup", "2", "--no-profile-pass"])
-            if not c:
-                others[wl] = {"failed": True}
-                continue
-            kt = c.get("kernels", [])
-            entry = {"workload": c["config"]["workload"], "ms_per_step": c["ms_per_step"], "frame_pairs_per_s": c["value"],
-                     "batches_in_flight": n_slots, "steps": c["steps"], "parity_in_bench": c["parity_in_bench"],
-                     "single_context": {"ms_per_step": c1["ms_per_step"], "frame_pairs_per_s": c1["value"]} if c1 else None,
-                     "workspace_bytes_per_context": c["workspace_bytes_per_context"], "mean_inlier_matches": c["mean_inlier_matches"],
-                     "kernels_ms_per_launch": {k["kernel"]: round(k["ms_per_launch"], 5) for k in kt}}
-            if "roofline" in c:
-                rf = c["roofline"]
-                entry["dominant_kernel"] = {"kernel": rf["kernel"], "ms_per_launch": rf["avg_launch_ms"], "frac_algorithmic": rf.get("frac_algorithmic"),
-                                            "hbm_frac_algorithmic": (rf.get("hbm") or {}).get("frac", rf["frac"] if rf["bound"] == "hbm" else None)}
-            if "roofline_match" in c:
-                entry["roofline_match"] = c["roofline_match"]
-            others[wl] = entry
-        result["other_workloads"] = others
+                if c.get("failed"):
+                    sweep[str(d)] = {"contexts": d, **{k: v for k, v in c.items() if k != "line"}}
+                else:
+                    sweep[str(d)] = {"contexts": d, "ms_per_batch": c["ms_per_step"], "frame_pairs_per_s": c["value"],
+                                     "parity_in_bench": c["parity_in_bench"]["bit_exact"], "from": "a fresh process, 40 steps"}
+            result["in_flight_sweep"] = sweep
+            if "1" in sweep and not sweep["1"].get("failed"):
+                result["single_context"] = {"ms_per_step": sweep["1"]["ms_per_batch"], "frame_pairs_per_s": sweep["1"]["frame_pairs_per_s"],
+                                            "what": "one batch after the other on one context (the headline arrangement of rounds 1-4), same data regime, fresh process"}
+
+            def kernel_ms(c, frames, pairs, kk, hh, sd, names):
+                rep = profile_pass(c, frames, pairs, kk, hh, sd, 1)
+                return {nm: rep[nm][0] / max(rep[nm][1], 1) for nm in names if nm in rep}
+
+            scoring = ("ransac_rank_kernel", "ransac_screen_kernel", "ransac_cand_kernel", "ransac_count_kernel",
+                       "ransac_ties_kernel", "ransac_tiesum_kernel", "ransac_select_kernel", "ransac_score_kernel")
+            regimes = {}
+            other = "hard" if args.data == "easy" else "easy"
+            for kind in (args.data, other):
+                frames = s0.bgr if kind == args.data else (synth.frames_torch if kind == "easy" else synth.frames_torch_hard)(seed, P, w, h, dev)
+                ms, o = timed_single(ctx, frames, P, K, H, s0.seeds)
+                ho = {k: o[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
+                entry = {"ms_per_step": ms, "frame_pairs_per_s": P / ms * 1e3, "contexts": 1, "mean_keypoints": float(ho["n"].mean()),
+                         "mean_inlier_matches": float(ho["best"][:, 3].mean()),
+                         "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring)}
+                # worst case of the data-dependent scoring kernels: every (hypothesis, match) pair evaluated, every sum formed
+                ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, True)
+                ms_all, _ = timed_single(ctx, frames, P, K, H, s0.seeds, steps=5)
+                entry["full_evaluation"] = {"ms_per_step": ms_all, "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring),
+                                            "what": "VSLAM_OPT_RANSAC_ALL_SUMS: no bail-out, no screen: the count and residual sum of every hypothesis"}
+                ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, False)
+                if kind != args.data:   # the timed batches were checked above; check this regime's output too
+                    nchk = min(P, 24)
+                    _, par = oracle_on_frames(frames[:nchk].cpu().numpy(), frames[P:P + nchk].cpu().numpy(), s0.seeds_np[:nchk], K, H, thr, ho, 0,
+                                              args.workload + ", " + kind + " data")
+                    entry["parity_in_bench"] = par
+                    if not par["bit_exact"]:
+                        exit_code = 3
+                    del frames
+                regimes[kind] = entry
+            result["data_regimes"] = regimes
+            others = {}
+            for wl in sorted(WORKLOADS):   # each in a process of its own (see child): headline arrangement, own per-kernel pass
+                if wl == args.workload:
+                    continue
+                w2, h2, K2, H2, P2 = WORKLOADS[wl]
+                extra_cpu = ["--cpu-pairs", "4"] if wl == "C3g" else []   # (C3g checks its output against the oracle inside the child)
+                c = child(["--workload", wl, "--in-flight", str(n_slots), "--steps", "24" if wl != "C5" else "12", "--warmup", "4"] + extra_cpu)
+                c1 = child(["--workload", wl, "--in-flight", "1", "--steps", "12" if wl != "C5" else "6", "--warmup", "2", "--no-profile-pass"])
+                if not (child_parity_ok(c) and child_parity_ok(c1)):
+                    exit_code = 3
+                if c1.get("failed"):
+                    c1 = None
+                if c.get("failed"):
+                    others[wl] = {k: v for k, v in c.items() if k != "line"}
+                    continue
+                kt = c.get("kernels", [])
+                entry = {"workload": c["config"]["workload"], "ms_per_step": c["ms_per_step"], "frame_pairs_per_s": c["value"],
+                         "batches_in_flight": n_slots, "steps": c["steps"], "parity_in_bench": c["parity_in_bench"],
+                         "single_context": {"ms_per_step": c1["ms_per_step"], "frame_pairs_per_s": c1["value"]} if c1 else None,
+                         "workspace_bytes_per_context": c["workspace_bytes_per_context"], "mean_inlier_matches": c["mean_inlier_matches"],
+                         "kernels_ms_per_launch": {k["kernel"]: round(k["ms_per_launch"], 5) for k in kt}}
+                if "roofline" in c:
+                    rf = c["roofline"]
+                    entry["dominant_kernel"] = {"kernel": rf["kernel"], "ms_per_launch": rf["avg_launch_ms"], "frac_algorithmic": rf.get("frac_algorithmic"),
+                                                "hbm_frac_algorithmic": (rf.get("hbm") or {}).get("frac", rf["frac"] if rf["bound"] == "hbm" else None)}
+                if "roofline_match" in c:
+                    entry["roofline_match"] = c["roofline_match"]
+                if "grid_extractor" in c:
+                    entry["grid_extractor"] = c["grid_extractor"]
+                    entry["cpu_baseline"] = c.get("cpu_baseline")
+                others[wl] = entry
+            result["other_workloads"] = others
+        except Exception as e:   # a secondary measurement must not cost the headline its line
+            import traceback
+            result["extras_error"] = {"error": repr(e), "traceback_tail": traceback.format_exc()[-800:]}
+            exit_code = exit_code or 5
+
     if multi:
         dist.barrier()
         for sl in slots:

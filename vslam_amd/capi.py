@@ -342,16 +342,18 @@ class Context:
                                                     _ptr(out["n_detected"])))
         return out
 
-    def extract_features_grid(self, bgr, nrows, ncols, pattern, kp_stride):
+    def extract_features_grid(self, bgr, nrows, ncols, pattern, kp_stride, out=None):
         """extract_features(frame, nrows, ncols): bgr is modified in place (cell outlines)."""
         torch = self.torch
         F, H, W, _ = bgr.shape
         self._dev(bgr, torch.uint8, "bgr"); self._dev(pattern, torch.int8, "pattern")
         dev = bgr.device
-        out = dict(xy=torch.zeros((F, kp_stride, 2), dtype=torch.float32, device=dev),
-                   desc=torch.zeros((F, kp_stride, 32), dtype=torch.uint8, device=dev),
-                   angle_octave=torch.zeros((F, kp_stride, 2), dtype=torch.float32, device=dev),
-                   n=torch.zeros((F,), dtype=torch.int32, device=dev))
+        if out is None:
+            out = dict(xy=torch.zeros((F, kp_stride, 2), dtype=torch.float32, device=dev),
+                       desc=torch.zeros((F, kp_stride, 32), dtype=torch.uint8, device=dev),
+                       angle_octave=torch.zeros((F, kp_stride, 2), dtype=torch.float32, device=dev),
+                       n=torch.zeros((F,), dtype=torch.int32, device=dev))
+            self._ready()
         self._check(self.lib.vslam_extract_features_grid(self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H),
                                                          C.c_int(3 * W), C.c_int(nrows), C.c_int(ncols), _ptr(pattern),
                                                          C.c_int(kp_stride), _ptr(out["xy"]), _ptr(out["desc"]),

@@ -254,54 +254,59 @@ __device__ __forceinline__ void reflect_range(int a, int b, int n, int &lo, int 
     hi = (a <= n - 1 && b >= n - 1) ? n - 1 : max(ra, rb);
 }
 
-// Level l of every frame's pyramid (with its reflect margin) and of every cell's pyramid from level l - 1.  Blocks
-// [0, frames * nbF) take the frames, the rest the cells; a workgroup makes a 64 x 16 tile, a lane 4 pixels = one dword.
-// The source pixels a tile touches form a box of about 78 x 21; it is fetched as (unaligned) dwords into LDS and the four
-// taps per pixel are LDS byte reads: per-lane byte gathers from global memory cost a wave 16 address cycles each.
-constexpr int kRTW = 64, kRTH = 16, kRBW = 112, kRBH = 40;   // tile; box capacity (row pitch kRBW bytes)
+// Level l of every frame's pyramid (kFrame: with its reflect margin) or of every cell's pyramid from level l - 1.  A workgroup
+// makes a 64 x 32 tile, a lane 4 pixels x 2 rows.  The source pixels a tile touches form a box of about 83 x 45; it is
+// fetched as (unaligned) dwords into LDS and the four taps per pixel are LDS byte reads: per-lane byte gathers from global
+// memory cost a wave 16 address cycles each, and the per-lane coefficient look-ups are shared by the lane's rows.
+constexpr int kRTW = 64, kRTH = 32, kRBW = 112, kRBH = 48;   // tile; box capacity (row pitch kRBW bytes)
 
-__global__ __launch_bounds__(256) void pyr_resize_kernel(Geom G, int l, int frames, int nbF, int nbC, int txF, int txC,
-                                                         const uint8_t *__restrict__ gray, uint8_t *__restrict__ fpyr,
-                                                         uint8_t *__restrict__ cpyr, const uint32_t *__restrict__ tab) {
-    __shared__ uint32_t box[kRBH * kRBW / 4];
-    const int tid = threadIdx.x, row = tid >> 4, g = tid & 15;
-    int b = blockIdx.x;
-    const bool is_frame = b < frames * nbF;
-    int img, tile, tiles_x, lw, lh, os, sw, sh, ss, tX, tY, out_w4, out_h;
+template <bool kFrame>
+__device__ __forceinline__ void pyr_resize_tile(const Geom &G, int l, int block, int tiles_x, int tiles_per_img, uint32_t *box,
+                                                const uint8_t *__restrict__ gray, uint8_t *__restrict__ fpyr,
+                                                uint8_t *__restrict__ cpyr, const uint32_t *__restrict__ tab) {
+    const int tid = threadIdx.x, rg = tid >> 4, g = tid & 15;
+    const int img = block / tiles_per_img, tile = block - img * tiles_per_img;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    constexpr int mx = kFrame ? 4 : 0, my = kFrame ? 3 : 0;
+    int lw, lh, os, sw, sh, ss, tX, tY, out_h;
     const uint8_t *S;
     uint8_t *D;
-    if (is_frame) {
-        img = b / nbF;
-        tile = b - img * nbF;
-        tiles_x = txF;
+    if (kFrame) {
         lw = G.flw[l]; lh = G.flh[l]; os = G.fstride[l];
         sw = G.flw[l - 1]; sh = G.flh[l - 1]; ss = G.fstride[l - 1];
         tX = G.tXF[l]; tY = G.tYF[l];
-        out_w4 = os >> 2; out_h = lh + 6;
+        out_h = lh + 6;
         S = l == 1 ? gray + (size_t)img * G.w * G.h : fpyr + (size_t)img * G.fframe + G.foff[l - 1] + 3 * ss + 4;
         D = fpyr + (size_t)img * G.fframe + G.foff[l];
     } else {
-        b -= frames * nbF;
-        img = b / nbC;
-        tile = b - img * nbC;
-        tiles_x = txC;
         lw = G.clw[l]; lh = G.clh[l]; os = G.cstride[l];
         sw = G.clw[l - 1]; sh = G.clh[l - 1];
         tX = G.tXC[l]; tY = G.tYC[l];
-        out_w4 = os >> 2; out_h = lh;
+        out_h = lh;
         S = cell_level(G, gray, cpyr, img, l - 1, ss);
         D = cpyr + (size_t)img * G.cunit + G.coff[l];
     }
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    // output coordinates of this lane: dword column gx of the stored row, row gy; image coordinates differ by the margin
-    const int gx = tx * (kRTW / 4) + g, gy = ty * kRTH + row;
-    const int mx = is_frame ? 4 : 0, my = is_frame ? 3 : 0;
+    const int out_w4 = os >> 2;
+    // this lane: dword column gx of the stored rows gy0, gy0 + 1; image coordinates differ by the margin
+    const int gx = tx * (kRTW / 4) + g, gy0 = ty * kRTH + 2 * rg;
+    const bool mine = gx < out_w4 && gy0 < out_h, two = gy0 + 1 < out_h;
+    // per-lane coefficients first: these loads and the box loads below are then in flight together
+    uint32_t yt[2] = {0, 0}, xt[4] = {0, 0, 0, 0};
+    if (mine) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int gy = two ? gy0 + j : gy0;
+            yt[j] = tab[tY + (kFrame ? reflect101(gy - my, lh) : gy)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) xt[k] = tab[tX + (kFrame ? reflect101(4 * gx + k - mx, lw) : min(4 * gx + k, lw - 1))];
+    }
     // source box of the whole tile (uniform): image x range of the tile's columns, y range of its rows
     int xlo, xhi, ylo, yhi;
     {
         const int xa = tx * kRTW - mx, xb = min(tx * kRTW + kRTW - 1, os - 1) - mx;
         const int ya = ty * kRTH - my, yb = min(ty * kRTH + kRTH - 1, out_h - 1) - my;
-        if (is_frame) {
+        if (kFrame) {
             reflect_range(xa, xb, lw, xlo, xhi);
             reflect_range(ya, yb, lh, ylo, yhi);
         } else {
@@ -309,8 +314,13 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(Geom G, int l, int fram
             ylo = ya; yhi = yb;
         }
     }
-    const int bx0 = (int)(tab[tX + xlo] & 0xffffu), bx1 = min((int)(tab[tX + xhi] & 0xffffu) + 1, sw - 1);
-    const int by0 = (int)(tab[tY + ylo] & 0xffffu), by1 = min((int)(tab[tY + yhi] & 0xffffu) + 1, sh - 1);
+    // The box without a table read in front of its loads: the tap offset of destination index d is
+    // floor((d + 0.5) * src / dst - 0.5), which lies in [floor(d * src / dst), floor(d * src / dst) + 1] for src >= dst
+    // (levels shrink); the margins absorb the second tap and the rounding of the float arithmetic (its error, below 0.01
+    // at these sizes, moves a floor by at most one).
+    const float fxs = (float)sw / (float)lw, fys = (float)sh / (float)lh;
+    const int bx0 = max((int)((float)xlo * fxs) - 2, 0), bx1 = min((int)((float)xhi * fxs) + 4, sw - 1);
+    const int by0 = max((int)((float)ylo * fys) - 2, 0), by1 = min((int)((float)yhi * fys) + 4, sh - 1);
     const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
     const bool staged = bw <= kRBW - 4 && bh <= kRBH;   // (uniform) otherwise the taps come straight from global memory
     if (staged) {
@@ -324,29 +334,34 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(Geom G, int l, int fram
             }
     }
     __syncthreads();
-    if (gx >= out_w4 || gy >= out_h) return;
-    const int y = is_frame ? reflect101(gy - my, lh) : gy;
-    const uint32_t yt = tab[tY + y];
-    const int yo = (int)(yt & 0xffffu), yb = min(yo + 1, sh - 1);
-    const uint32_t y1c = yt >> 16, y0c = 256u - y1c;
-    uint32_t out = 0;
-    if (staged) {   // two code paths, not one pointer: LDS reads stay LDS reads (and no LDS offset ever goes negative)
-        const uint8_t *bb = reinterpret_cast<const uint8_t *>(box);
-        const uint8_t *r0 = bb + (yo - by0) * kRBW, *r1 = bb + (yb - by0) * kRBW;
+    if (!mine) return;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = is_frame ? reflect101(4 * gx + k - mx, lw) : min(4 * gx + k, lw - 1);
-            out |= resize_px(r0, r1, bx0, sw, tab[tX + x], y0c, y1c) << (8 * k);
-        }
-    } else {
-        const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)yb * ss;
+    for (int j = 0; j < 2; j++) {
+        if (j == 1 && !two) break;
+        const int yo = (int)(yt[j] & 0xffffu), yb = min(yo + 1, sh - 1);
+        const uint32_t y1c = yt[j] >> 16, y0c = 256u - y1c;
+        uint32_t out = 0;
+        if (staged) {   // two code paths, not one pointer: LDS reads stay LDS reads (and no LDS offset ever goes negative)
+            const uint8_t *bb = reinterpret_cast<const uint8_t *>(box);
+            const uint8_t *r0 = bb + (yo - by0) * kRBW, *r1 = bb + (yb - by0) * kRBW;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = is_frame ? reflect101(4 * gx + k - mx, lw) : min(4 * gx + k, lw - 1);
-            out |= resize_px(r0, r1, 0, sw, tab[tX + x], y0c, y1c) << (8 * k);
+            for (int k = 0; k < 4; k++) out |= resize_px(r0, r1, bx0, sw, xt[k], y0c, y1c) << (8 * k);
+        } else {
+            const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)yb * ss;
+#pragma unroll
+            for (int k = 0; k < 4; k++) out |= resize_px(r0, r1, 0, sw, xt[k], y0c, y1c) << (8 * k);
         }
+        *reinterpret_cast<uint32_t *>(D + (size_t)(gy0 + j) * os + 4 * gx) = out;
     }
-    *reinterpret_cast<uint32_t *>(D + (size_t)gy * os + 4 * gx) = out;
+}
+
+// one launch per level: blocks [0, frame_blocks) make the frames' level, the rest the cells' (the two are independent)
+__global__ __launch_bounds__(256) void pyr_resize_kernel(Geom G, int l, int frame_blocks, int txF, int nbF, int txC, int nbC,
+                                                         const uint8_t *__restrict__ gray, uint8_t *__restrict__ fpyr,
+                                                         uint8_t *__restrict__ cpyr, const uint32_t *__restrict__ tab) {
+    __shared__ uint32_t box[kRBH * kRBW / 4];
+    if ((int)blockIdx.x < frame_blocks) pyr_resize_tile<true>(G, l, blockIdx.x, txF, nbF, box, gray, fpyr, cpyr, tab);
+    else pyr_resize_tile<false>(G, l, blockIdx.x - frame_blocks, txC, nbC, box, gray, fpyr, cpyr, tab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -386,6 +401,28 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *c, int s) {
     return best > kFastMin ? min(best, 255) : 0;
 }
 
+// Necessary condition for M > kFastMin from the eight even circle pixels alone: an arc of 9 holds at least four consecutive
+// even positions, so a corner has four consecutive even pixels all darker than v - 5 or all brighter than v + 5.
+__device__ __forceinline__ bool fast_may_be_corner(const uint8_t *c, int s) {
+    const int v = c[0];
+    int e[8];
+    e[0] = v - c[3 * s];  e[1] = v - c[2 * s + 2];  e[2] = v - c[3];  e[3] = v - c[-2 * s + 2];
+    e[4] = v - c[-3 * s]; e[5] = v - c[-2 * s - 2]; e[6] = v - c[-3]; e[7] = v - c[2 * s - 2];
+    int lo2[8], hi2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo2[k] = min(e[k], e[(k + 1) & 7]);
+        hi2[k] = max(e[k], e[(k + 1) & 7]);
+    }
+    int dk = -256, br = 256;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        dk = max(dk, min(lo2[k], lo2[(k + 2) & 7]));
+        br = min(br, max(hi2[k], hi2[(k + 2) & 7]));
+    }
+    return dk > kFastMin || br < -kFastMin;
+}
+
 // exact i / d for i * d < 2^32 with m = floor(2^32 / d) + 1 (which is 2^32 for d = 1 and arrives here as 0)
 __device__ __forceinline__ int div_magic(int i, uint32_t m) { return m ? (int)__umulhi((uint32_t)i, m) : i; }
 
@@ -394,13 +431,17 @@ struct FastLds {
     uint8_t *S, *M;
     unsigned long long *mask5, *mask20;
     int *cnt5, *cnt20, *hist, *tot;
+    uint16_t *cand;       // M-tile pixels that pass the cheap corner test, [ccap]
+    int ccap;
 };
 
 // rows a strip may have with `bytes` of LDS (host and device agree through this one function)
 __host__ __device__ inline int fast_strip_rows(int rw, int bytes) {
     const int SW = (rw + 8 + 3) & ~3, MW = (rw + 2 + 3) & ~3, CPR = (rw + 63) >> 6;
-    const int fixed = 8 * SW + 2 * MW + 256 * 4 + 64, per_row = SW + MW + CPR * 24;
-    const int R = (bytes - fixed) / per_row;
+    const int fixed = 8 * SW + 2 * MW + 2 * MW + 256 * 4 + 64, per_row = SW + MW + MW + CPR * 24;   // S, M, candidates (u16 x half the M tile)
+    int R = (bytes - fixed) / per_row;
+    const int by_index = 65535 / MW - 2;   // candidates are 16-bit offsets into the M tile
+    R = R > by_index ? by_index : R;
     return R > 32 ? 32 : R;
 }
 
@@ -412,7 +453,7 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
                                                            int32_t *__restrict__ cnt0, int32_t *__restrict__ c1_20) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int l = blockIdx.x / units, u = blockIdx.x - l * units, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (in a scalar register: the chunk loops are per wave)
     const int rw = G.rw[l], rh = G.rh[l], cap = G.cap[l];
     int stride;
     const uint8_t *src = cell_level(G, gray, cpyr, u, l, stride);
@@ -431,11 +472,13 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
         L.cnt5 = reinterpret_cast<int *>(p);                       p += (size_t)nc * 4;
         L.cnt20 = reinterpret_cast<int *>(p);                      p += (size_t)nc * 4;
         L.S = p;                                                   p += (size_t)(L.R + 8) * L.SW;
-        L.M = p;
+        L.M = p;                                                   p += (size_t)(L.R + 2) * L.MW;
+        L.cand = reinterpret_cast<uint16_t *>(p);
+        L.ccap = ((L.R + 2) * L.MW) >> 1;
     }
     L.hist[tid] = 0;
-    if (tid < 2) L.tot[tid] = 0;
-    const uint32_t mS = 0xffffffffu / (uint32_t)(L.SW >> 2) + 1u, mM = 0xffffffffu / (uint32_t)(rw + 2) + 1u;
+    if (tid < 3) L.tot[tid] = 0;   // running list lengths (5, 20), candidate count of the strip
+    const uint32_t mS = 0xffffffffu / (uint32_t)(L.SW >> 2) + 1u, mM = 0xffffffffu / (uint32_t)(rw + 2) + 1u, mMW = 0xffffffffu / (uint32_t)L.MW + 1u;
     const uint32_t mC = 0xffffffffu / (uint32_t)L.CPR + 1u;
     uint32_t *list20 = lists + ((size_t)(u * 2 + 0)) * G.loff[G.nlv] + G.loff[l];
     uint32_t *list5 = lists + ((size_t)(u * 2 + 1)) * G.loff[G.nlv] + G.loff[l];
@@ -467,12 +510,47 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
             }
         }
         __syncthreads();
-        // 2. M for inner rows y0 - 1 .. y0 + rows and inner columns -1 .. rw
+        // 2. M for inner rows y0 - 1 .. y0 + rows and inner columns -1 .. rw.  First a cheap necessary test on every pixel (a few
+        //    per cent pass); the passing pixels are compacted so that the arc scores are computed by full waves.  A lane walks
+        //    the tile 256 pixels at a time; its (row, column) and the two tile offsets advance without a division.
         {
-            const int n = (rows + 2) * (rw + 2);
-            for (int i = tid; i < n; i += 256) {
-                const int r = div_magic(i, mM), c = i - r * (rw + 2);
-                L.M[r * L.MW + c] = (uint8_t)fast_arc_score(L.S + (r + 3) * L.SW + c + 3, L.SW);
+            const int W2 = rw + 2, n = (rows + 2) * W2;
+            const int q256 = 256 / W2, r256 = 256 - q256 * W2;
+            const int stepS = q256 * L.SW + r256, stepM = q256 * L.MW + r256, wrapS = L.SW - W2, wrapM = L.MW - W2;
+            int c = tid - div_magic(tid, mM) * W2;
+            int aM = div_magic(tid, mM) * L.MW + c, aS = (div_magic(tid, mM) + 3) * L.SW + c + 3;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                bool cnd = false;
+                if (i0 + tid < n) {
+                    cnd = fast_may_be_corner(L.S + aS, L.SW);
+                    L.M[aM] = 0;
+                }
+                const unsigned long long bal = __ballot(cnd);
+                if (bal) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&L.tot[2], (int)__popcll(bal));
+                    base = __shfl(base, 0, 64);
+                    if (cnd) {
+                        const int pos = base + (int)__popcll(bal & lt);
+                        if (pos < L.ccap) L.cand[pos] = (uint16_t)aM;
+                        else L.M[aM] = (uint8_t)fast_arc_score(L.S + aS, L.SW);   // list full: in place
+                    }
+                }
+                c += r256;
+                aS += stepS;
+                aM += stepM;
+                if (c >= W2) {
+                    c -= W2;
+                    aS += wrapS;
+                    aM += wrapM;
+                }
+            }
+            __syncthreads();
+            const int nc2 = min(L.tot[2], L.ccap);
+            for (int j = tid; j < nc2; j += 256) {
+                const int am = L.cand[j];
+                const int r = div_magic(am, mMW), cc = am - r * L.MW;
+                L.M[am] = (uint8_t)fast_arc_score(L.S + (r + 3) * L.SW + cc + 3, L.SW);
             }
         }
         __syncthreads();
@@ -517,6 +595,8 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
                 base += __shfl(inc, 63, 64);
             }
             if (lane == 0) L.tot[wave] = base;
+        } else if (tid == 128) {
+            L.tot[2] = 0;   // the next strip's candidate count (this strip's was last read two barriers ago)
         }
         __syncthreads();
         // 5. ordered writes
@@ -917,25 +997,45 @@ __device__ __forceinline__ void sincos_deg_pinned(float angle_deg, float &s_out,
     c_out = (float)c;
 }
 
+// largest distance of a pattern point from the patch centre, rounded up, + 1: no rotated and rounded sample lies farther out
+__global__ __launch_bounds__(512) void pattern_radius_kernel(const int8_t *__restrict__ pattern, int32_t *__restrict__ radius) {
+    __shared__ int s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    const int x = pattern[2 * threadIdx.x], y = pattern[2 * threadIdx.x + 1];
+    atomicMax(&s_max, x * x + y * y);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int r = 0;
+        while (r * r < s_max) r++;
+        *radius = r + 1;
+    }
+}
+
 // ICAngles + computeOrbDescriptors: half a wave per keypoint.
 // Angle: lane j of the half holds column j - 15 of the 31 x 31 patch around the keypoint in its CELL's pyramid level (rows are
 // contiguous bytes across the lanes); the two integer moments are summed over the half by shuffles.
 // Descriptor: a lane per byte on the FRAME's pyramid level.  A sample inside the level's image reads the blurred level;
-// outside it the unblurred reflect value (what OpenCV's in-place blur leaves in the level's border).
-__global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, const uint8_t *__restrict__ gray,
-                                                       const uint8_t *__restrict__ cpyr, const uint8_t *__restrict__ blur0,
-                                                       const uint8_t *__restrict__ fpyr, const uint8_t *__restrict__ fblur,
+// outside it the unblurred reflect value (what OpenCV's in-place blur leaves in the level's border).  A keypoint whose
+// whole sampling disc (pattern radius) lies inside the level -- nearly all -- takes a path without per-sample tests.
+// `images` = [gray frames | cell pyramids], `blurred` = [blurred frames | blurred frame pyramids]: one base each and 32-bit
+// offsets (gbytes = size of the first part).
+__global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, uint32_t gbytes, const uint8_t *__restrict__ images,
+                                                       const uint8_t *__restrict__ blurred, const uint8_t *__restrict__ fpyr,
                                                        const float4 *__restrict__ kps, const int32_t *__restrict__ n_arr,
                                                        int kp_cap, const int8_t *__restrict__ pattern,
-                                                       uint8_t *__restrict__ desc, float *__restrict__ out_xy,
-                                                       float *__restrict__ out_angle_octave) {
-    __shared__ int s_pat[256];
+                                                       const int32_t *__restrict__ pat_radius, uint8_t *__restrict__ desc,
+                                                       float *__restrict__ out_xy, float *__restrict__ out_angle_octave) {
     const int f = blockIdx.y, tid = threadIdx.x;
-    s_pat[tid] = reinterpret_cast<const int *>(pattern)[tid];   // (x1, y1, x2, y2) as int8 x 4 per bit
-    __syncthreads();
     const int kp = blockIdx.x * 8 + (tid >> 5), byte = tid & 31;
-    if (kp >= n_arr[f]) return;   // whole halves leave; the shuffles below stay inside a half
-    const float4 k4 = kps[(size_t)f * kp_cap + kp];
+    // the lane's eight pattern entries ((x1, y1, x2, y2) as int8 x 4 per bit), the frame's count and the keypoint record are
+    // independent loads: all in flight before the first use (the record of a slot past the count is never used)
+    const int4 pq0 = reinterpret_cast<const int4 *>(pattern)[byte * 2], pq1 = reinterpret_cast<const int4 *>(pattern)[byte * 2 + 1];
+    const int pat8[8] = {pq0.x, pq0.y, pq0.z, pq0.w, pq1.x, pq1.y, pq1.z, pq1.w};
+    const int n_f = n_arr[f];
+    const int R = *pat_radius;
+    const float4 k4 = kps[(size_t)f * kp_cap + (kp < kp_cap ? kp : 0)];
+    if (kp >= n_f) return;   // whole halves leave; the shuffles below stay inside a half
     const int idx = __float_as_int(k4.z), cl = __float_as_int(k4.w);
     const int l = cl & 15, c = cl >> 4;
     // per-level constants, selected without indexing the argument struct by a per-lane value
@@ -955,25 +1055,27 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, cons
         }
     float angle;
     {
-        const uint8_t *cimg;
+        uint32_t cbase;   // offset of the cell level's pixel (0, 0) in `images`
         if (l == 0) {
             const int ci = c / G.nrows, cj = c - ci * G.nrows;
-            cimg = gray + (size_t)f * G.w * G.h + (size_t)(cj * G.ch) * G.w + ci * G.cw;
+            cbase = (uint32_t)f * (uint32_t)(G.w * G.h) + (uint32_t)(cj * G.ch) * (uint32_t)G.w + (uint32_t)(ci * G.cw);
         } else {
-            cimg = cpyr + (size_t)(f * G.cells + c) * G.cunit + co;
+            cbase = gbytes + (uint32_t)(f * G.cells + c) * (uint32_t)G.cunit + (uint32_t)co;
         }
         const int py = idx / rw, px = idx - py * rw;
-        const uint8_t *center = cimg + (size_t)(py + kEdge) * cs + px + kEdge;
         const int uo = byte - 15, auo = uo < 0 ? -uo : uo;
+        const uint32_t center = cbase + (uint32_t)(py + kEdge) * (uint32_t)cs + (uint32_t)(px + kEdge + uo);
+        // every lane fetches its column of all 31 rows (lane 31's column 16 is still >= 15 px inside the level), unconditionally
+        // so that the loads are in flight together; the circular mask is applied to the values
+        int val[31];
+#pragma unroll
+        for (int v = -15; v <= 15; v++) val[v + 15] = images[center + (uint32_t)(v * cs)];
         int m_10 = 0, m_01 = 0;
 #pragma unroll
         for (int v = -15; v <= 15; v++) {
-            const int d = U.v[v < 0 ? -v : v];
-            if (auo <= d) {   // lane 31 (uo = 16) never
-                const int val = center[v * cs + uo];
-                m_10 += uo * val;
-                m_01 += v * val;
-            }
+            const int x = auo <= U.v[v < 0 ? -v : v] ? val[v + 15] : 0;
+            m_10 += uo * x;
+            m_01 += v * x;
         }
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) {
@@ -986,29 +1088,42 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, cons
     float a, b;
     sincos_deg_pinned(angle, b, a);
     const int cx = (int)rintf(k4.x * scale), cy = (int)rintf(k4.y * scale);
-    const uint8_t *img, *blr;   // pixel (0, 0) of the unblurred and the blurred level
-    if (l == 0) {
-        img = gray + (size_t)f * G.w * G.h;
-        blr = blur0 + (size_t)f * G.w * G.h;
-    } else {
-        img = fpyr + (size_t)f * G.fframe + fo + 3 * fs + 4;
-        blr = fblur + (size_t)f * G.fframe + fo + 3 * fs + 4;
-    }
+    // offset of the frame level's pixel (0, 0): in `blurred`, and (levels >= 1) of the unblurred level in fpyr
+    const uint32_t lbase = l == 0 ? (uint32_t)f * (uint32_t)(G.w * G.h) : gbytes + (uint32_t)f * (uint32_t)G.fframe + (uint32_t)(fo + 3 * fs + 4);
     uint32_t val = 0;
+    if (cx - R >= 0 && cx + R < lw && cy - R >= 0 && cy + R < lh) {
+        const uint32_t cbl = lbase + (uint32_t)cy * (uint32_t)fs + (uint32_t)cx;
 #pragma unroll
-    for (int bit = 0; bit < 8; bit++) {
-        const int pp = s_pat[byte * 8 + bit];
-        int t[2];
+        for (int bit = 0; bit < 8; bit++) {
+            const int pp = pat8[bit];
+            int t[2];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const float fx = (float)(int8_t)(pp >> (16 * e)), fy = (float)(int8_t)(pp >> (16 * e + 8));
-            const float a1 = fx * a, a2 = fy * b, b1 = fx * b, b2 = fy * a;
-            const float rx = a1 - a2, ry = b1 + b2;
-            const int x = cx + (int)rintf(rx), y = cy + (int)rintf(ry);
-            if ((unsigned)x < (unsigned)lw && (unsigned)y < (unsigned)lh) t[e] = blr[(size_t)y * fs + x];
-            else t[e] = img[(size_t)reflect101(y, lh) * fs + reflect101(x, lw)];
+            for (int e = 0; e < 2; e++) {
+                const float fx = (float)(int8_t)(pp >> (16 * e)), fy = (float)(int8_t)(pp >> (16 * e + 8));
+                const float a1 = fx * a, a2 = fy * b, b1 = fx * b, b2 = fy * a;
+                const float rx = a1 - a2, ry = b1 + b2;
+                t[e] = blurred[cbl + (uint32_t)((int)rintf(ry) * fs + (int)rintf(rx))];
+            }
+            val |= (uint32_t)(t[0] < t[1]) << bit;
         }
-        val |= (uint32_t)(t[0] < t[1]) << bit;
+    } else {
+        const uint8_t *img = l == 0 ? images + lbase : fpyr + (size_t)f * G.fframe + fo + 3 * fs + 4;
+        const uint8_t *blr = blurred + lbase;
+#pragma unroll 1
+        for (int bit = 0; bit < 8; bit++) {
+            const int pp = pat8[bit];
+            int t[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float fx = (float)(int8_t)(pp >> (16 * e)), fy = (float)(int8_t)(pp >> (16 * e + 8));
+                const float a1 = fx * a, a2 = fy * b, b1 = fx * b, b2 = fy * a;
+                const float rx = a1 - a2, ry = b1 + b2;
+                const int x = cx + (int)rintf(rx), y = cy + (int)rintf(ry);
+                if ((unsigned)x < (unsigned)lw && (unsigned)y < (unsigned)lh) t[e] = blr[(size_t)y * fs + x];
+                else t[e] = img[(size_t)reflect101(y, lh) * fs + reflect101(x, lw)];
+            }
+            val |= (uint32_t)(t[0] < t[1]) << bit;
+        }
     }
     desc[((size_t)f * kp_cap + kp) * VSLAM_DESC_BYTES + byte] = (uint8_t)val;
     if (byte == 0) {
@@ -1077,15 +1192,27 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
     VS_REQUIRE(ctx, frames > 0 && w > 0 && h > 0 && stride >= 3 * w && nrows > 0 && ncols > 0 && kp_cap > 0, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, w / ncols >= 7 && h / nrows >= 7, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, w <= 32768 && h <= 32768 && nrows * ncols <= 2048, VSLAM_ERR_CAPACITY);
-    VS_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(pattern) & 3) == 0, VSLAM_ERR_INVALID);
+    if (reinterpret_cast<uintptr_t>(pattern) & 15) {   // the descriptor kernel reads the table as 16-byte groups
+        int8_t *aligned = nullptr;
+        if (int prc = vs_arena_get(ctx, "grid.pattern", 1024, (void **)&aligned)) return prc;
+        VS_HIP(ctx, hipMemcpyAsync(aligned, pattern, 1024, hipMemcpyDeviceToDevice, ctx->stream));
+        pattern = aligned;
+    }
     Geom G;
     make_geom(w, h, nrows, ncols, G);
     const int cells = G.cells, units = frames * cells;
     hipStream_t st = ctx->stream;
 
-    uint8_t *gray = nullptr;
+    // [gray frames | cell pyramids] and [blurred frames | blurred frame pyramids] are one allocation each: the descriptor kernel
+    // addresses them with one base and 32-bit offsets
+    const size_t gbytes = ((size_t)frames * w * h + 16 + 255) & ~(size_t)255;   // + slack: rows are read as dwords
+    const size_t images_bytes = gbytes + (size_t)G.cunit * units + 16, blurred_bytes = gbytes + (size_t)G.fframe * frames + 16;
+    VS_REQUIRE(ctx, images_bytes < (1ull << 32) && blurred_bytes < (1ull << 32), VSLAM_ERR_CAPACITY);
+    uint8_t *images = nullptr, *blurred = nullptr;
     int rc;
-    if ((rc = vs_arena_get(ctx, "grid.gray", (size_t)frames * w * h + 16, (void **)&gray))) return rc;   // + slack: rows are read as dwords
+    if ((rc = vs_arena_get(ctx, "grid.images", images_bytes, (void **)&images))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.blurred", blurred_bytes, (void **)&blurred))) return rc;
+    uint8_t *gray = images, *cpyr = images + gbytes, *blur0 = blurred, *fblur = blurred + gbytes;
     {   // :32 outlines into the caller's image + gray of the result (ORB converts BGR ROIs to gray)
         VsProfScope ps(ctx, "grid_outline_gray_kernel");
         if (w % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0)
@@ -1106,7 +1233,7 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
     {
         const int rw0 = G.rw[0];
         const int SW = (rw0 + 8 + 3) & ~3, MW = (rw0 + 2 + 3) & ~3, CPR = (rw0 + 63) >> 6;
-        const int fixed = 8 * SW + 2 * MW + 256 * 4 + 64, per_row = SW + MW + CPR * 24;
+        const int fixed = 8 * SW + 2 * MW + 2 * MW + 256 * 4 + 64, per_row = SW + MW + MW + CPR * 24;   // as fast_strip_rows
         int R = std::min(24, G.rh[0]);
         while (R > 4 && fixed + per_row * R > 40 * 1024) R--;
         fast_lds = fixed + per_row * R;
@@ -1115,15 +1242,14 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
     }
 
     const size_t LT = (size_t)G.loff[G.nlv], slots = (size_t)units * 2 * LT;
-    uint8_t *cpyr = nullptr, *fpyr = nullptr, *fblur = nullptr, *blur0 = nullptr, *flags = nullptr;
+    uint8_t *fpyr = nullptr, *flags = nullptr;
+    int32_t *pat_r = nullptr;
     uint32_t *tab = nullptr, *ent = nullptr;
     float *resp = nullptr;
     float4 *fkp = nullptr;
     int32_t *cnt = nullptr;
-    if ((rc = vs_arena_get(ctx, "grid.cpyr", (size_t)G.cunit * units + 16, (void **)&cpyr))) return rc;
+    if ((rc = vs_arena_get(ctx, "grid.pat_r", 16, (void **)&pat_r))) return rc;
     if ((rc = vs_arena_get(ctx, "grid.fpyr", (size_t)G.fframe * frames + 16, (void **)&fpyr))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.fblur", (size_t)G.fframe * frames + 16, (void **)&fblur))) return rc;
-    if ((rc = vs_arena_get(ctx, "grid.blur0", (size_t)frames * w * h, (void **)&blur0))) return rc;
     if ((rc = vs_arena_get(ctx, "grid.tab", sizeof(uint32_t) * (size_t)(G.ttotal + 1), (void **)&tab))) return rc;
     if ((rc = vs_arena_get(ctx, "grid.ent", sizeof(uint32_t) * slots, (void **)&ent))) return rc;
     if ((rc = vs_arena_get(ctx, "grid.resp", sizeof(float) * slots, (void **)&resp))) return rc;
@@ -1149,7 +1275,7 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
         for (int l = 1; l < G.nlv; l++) {
             const int txF = vs_div_up(G.fstride[l], kRTW), txC = vs_div_up(G.cstride[l], kRTW);
             const int nbF = txF * vs_div_up(G.flh[l] + 6, kRTH), nbC = txC * vs_div_up(G.clh[l], kRTH);
-            pyr_resize_kernel<<<frames * nbF + units * nbC, 256, 0, st>>>(G, l, frames, nbF, nbC, txF, txC, gray, fpyr, cpyr, tab);
+            pyr_resize_kernel<<<frames * nbF + units * nbC, 256, 0, st>>>(G, l, frames * nbF, txF, nbF, txC, nbC, gray, fpyr, cpyr, tab);
         }
     }
     {
@@ -1185,8 +1311,9 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
             if ((rc = vs_launch_gaussian7_rows(ctx, fpyr + G.foff[l], fblur + G.foff[l], frames, (size_t)G.fframe, G.fstride[l],
                                                G.flh[l] + 6, 3, G.flh[l] + 3)))
                 return rc;
-        orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(G, U, gray, cpyr, blur0, fpyr, fblur, fkp, n_out, kp_cap,
-                                                                            pattern, desc, xy, angle_octave);
+        pattern_radius_kernel<<<1, 512, 0, st>>>(pattern, pat_r);
+        orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(G, U, (uint32_t)gbytes, images, blurred, fpyr, fkp, n_out,
+                                                                            kp_cap, pattern, pat_r, desc, xy, angle_octave);
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
