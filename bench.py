@@ -700,8 +700,8 @@ def main():
     def step(k):
         """One pass of the hot path over one batch: handed to the next context of the pipeline (returns once it is queued;
         acquire waits for the batch that used the context n_slots steps ago)."""
-        sl = slots[k % n_slots]
         t, c = pipe.acquire()
+        sl = slots[t % n_slots]      # the pipeline hands out context ticket % n: a slot's frames, outputs and communicator stay with ITS context
         c.frontend_pairs(sl.bgr, P, K, ca, sa, pat, sl.seeds, H, thr, out=sl.out)
         if multi:
             # the only exchange on the path: fixed-size per-pair result records to every rank, on this batch's own stream

@@ -51,6 +51,10 @@ int vslam_ctx_make_current(vslam_ctx *ctx);
 /* Borrow a caller-owned hipStream_t (e.g. torch's current stream).  Taken literally: NULL is
  * HIP's default stream.  A fresh context runs on a private non-blocking stream.               */
 int vslam_ctx_set_stream(vslam_ctx *ctx, void *hip_stream);
+/* Waits for the context's stream, then reads AND CLEARS the device-side error word (VSLAM_ERR_CAPACITY if a bounded list
+ * overflowed since the last call).  Not for a context that a vslam_pipeline owns: there the word belongs to the ticket in
+ * flight (vslam_pipeline_commit files it under the batch), and clearing it out of band would take that batch's status away --
+ * use vslam_ctx_wait / vslam_pipeline_wait on those.                                                                       */
 int vslam_ctx_synchronize(vslam_ctx *ctx);
 /* Waits for the context's stream and nothing else (vslam_ctx_synchronize also fetches the device-side error word). */
 int vslam_ctx_wait(vslam_ctx *ctx);
@@ -84,9 +88,9 @@ const int8_t *vslam_brief_pattern_31(void);
  *       (BASELINE.json configs[4]): conditioned 9x9 normal matrix on the matrix cores (v_mfma_f32_16x16x4_f32) +
  *       inverse iteration.  NOT bit-exact: F equals the exact solver's up to sign and about 1e-4 (unit-norm F) on
  *       well-conditioned samples; inlier masks may differ.  Never used unless set.
- *   VSLAM_OPT_MATCH_SHAPE  0 (default): the matcher picks its workgroup shape from kp_stride.  1: 8 waves x 32 query
- *       rows, 2: 4 waves x 64 query rows.  Same results bit for bit; a tuning / test knob (the two differ in how much
- *       room they leave the k-d build that runs beside the matcher).                                            */
+ *   VSLAM_OPT_MATCH_SHAPE  0 (default, and the only value the product library accepts: 8 waves x 32 query rows).
+ *       EXPERIMENTS build (libvslam_amd_exp.so, -DVSLAM_EXPERIMENTS) only: 1 the same, 2: 4 waves x 64 query rows.  Same
+ *       results bit for bit; kept there so that the choice can be re-measured (tools/ab_match.sh).                 */
 #define VSLAM_OPT_RANSAC_ALL_SUMS 1
 #define VSLAM_OPT_RANSAC_MIN_MATCHES 2
 #define VSLAM_OPT_RANSAC_SOLVER 3
@@ -109,8 +113,9 @@ const int8_t *vslam_brief_pattern_31(void);
  *       -1: every list sized for the whole image, as before round 4 (nothing can overflow; 16 bytes per pixel and frame). */
 #define VSLAM_OPT_CORNER_LIST_CAP 7
 /*   VSLAM_OPT_MATCH_FORM  0 (default) / 1: the matcher forms Hamming distances as FP4 (+-1) dot products on the matrix
- *       cores (v_mfma_scale_f32_32x32x64_f8f6f4); 2: as int8 (0 / 1) dot products (v_mfma_i32_32x32x32_i8).  Exact either
- *       way, same results bit for bit; a tuning / test knob.                                                       */
+ *       cores (v_mfma_scale_f32_32x32x64_f8f6f4).  EXPERIMENTS build only: 2 = as int8 (0 / 1) dot products
+ *       (v_mfma_i32_32x32x32_i8); the product library carries the FP4 kernel alone and answers 2 with VSLAM_ERR_INVALID.
+ *       Exact either way, same results bit for bit.                                                                */
 #define VSLAM_OPT_MATCH_FORM 8
 /*   VSLAM_OPT_TREE_FORK  where vslam_frontend_pairs / _sequence start the k-d build (an output of the path that no later
  *       stage reads) on the auxiliary stream: -1 (default) by size (behind the matcher up to 2048 keypoint slots, in front

@@ -51,3 +51,15 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_exp():
+    """A context of the EXPERIMENTS build (libvslam_amd_exp.so, -DVSLAM_EXPERIMENTS): the kernel variants that the product
+    library does not carry (the matcher's int8 form and other workgroup shape) are held to the oracle through it."""
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    from vslam_amd import Context, capi
+    c = Context(0, lib=capi.load_library(capi.EXP_LIB_PATH))
+    yield c
+    c.close()

@@ -11,7 +11,9 @@ import numpy as np
 import torch
 
 
-def run(ctx, o, seed, cases=None, seconds=None):
+def run(ctx, o, seed, cases=None, seconds=None, variants=True):
+    """variants: draw a workgroup shape and a matrix-core form per case (a context of the EXPERIMENTS build; the product
+    library carries one matcher and refuses the options)."""
     rng = np.random.default_rng(seed)
     t0, done = time.time(), 0
     while (cases is None or done < cases) and (seconds is None or time.time() - t0 < seconds):
@@ -51,15 +53,18 @@ def run(ctx, o, seed, cases=None, seconds=None):
         for b, (a, t) in enumerate(items):
             d1[b, :len(a)] = a; d2[b, :len(t)] = t
             n1[b], n2[b] = len(a), len(t)
-        ctx.set_option(ctx.OPT_MATCH_SHAPE, int(rng.integers(0, 3)))
-        ctx.set_option(ctx.OPT_MATCH_FORM, int(rng.integers(0, 3)))
+        shape_, form_ = int(rng.integers(0, 3)), int(rng.integers(0, 3))   # (drawn either way: the case stream does not depend on `variants`)
+        if variants:
+            ctx.set_option(ctx.OPT_MATCH_SHAPE, shape_)
+            ctx.set_option(ctx.OPT_MATCH_FORM, form_)
         try:
             pairs, m, knn = ctx.match_knn2_ratio(torch.from_numpy(d1).cuda(), torch.from_numpy(n1).cuda(), torch.from_numpy(d2).cuda(),
                                                  torch.from_numpy(n2).cuda(), want_knn=True)
             ctx.synchronize()
         finally:
-            ctx.set_option(ctx.OPT_MATCH_SHAPE, 0)
-            ctx.set_option(ctx.OPT_MATCH_FORM, 0)
+            if variants:
+                ctx.set_option(ctx.OPT_MATCH_SHAPE, 0)
+                ctx.set_option(ctx.OPT_MATCH_FORM, 0)
         pairs, m, knn = pairs.cpu().numpy(), m.cpu().numpy(), knn.cpu().numpy()
         for b, (a, t) in enumerate(items):
             if len(t) >= 2 and len(a) >= 1:
@@ -82,7 +87,9 @@ if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle_lib import Oracle
-    from vslam_amd import Context
+    from vslam_amd import Context, capi
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
-    print("fuzz ok:", run(Context(0), Oracle(), seed, seconds=secs), "cases")
+    print("fuzz ok (product):", run(Context(0), Oracle(), seed, seconds=secs / 2, variants=False), "cases")
+    print("fuzz ok (experiments build, all variants):",
+          run(Context(0, lib=capi.load_library(capi.EXP_LIB_PATH)), Oracle(), seed + 1, seconds=secs / 2), "cases")

@@ -66,3 +66,22 @@ def test_host_library_exports_its_c_entry_points():
     assert hasattr(host, "vslam_host_last_batches_redone")
     for n in names:
         assert hasattr(host, n), n
+
+
+def test_product_library_reads_no_environment_and_carries_no_variants():
+    """The A/B switches and the kernel variants that were measured and not chosen live in the experiments build only
+    (-DVSLAM_EXPERIMENTS -> libvslam_amd_exp.so): the product holds no VSLAM_* environment name, no getenv import, and none of
+    the variant kernels; the experiments build holds them."""
+    import subprocess
+    from vslam_amd import build
+    prod = subprocess.run(["strings", "-a", build.build()], capture_output=True, text=True, check=True).stdout
+    for name in ("VSLAM_MATCH_", "VSLAM_RANSAC_", "VSLAM_KD_", "VSLAM_RBRIEF_", "VSLAM_STREAM_", "VSLAM_OVERLAP_", "VSLAM_SHARED_",
+                 "VSLAM_LAZY_", "VSLAM_SETS_", "VSLAM_TREE_", "VSLAM_NO_GRAY", "VSLAM_CORNER_EXACT"):
+        assert name not in prod, name
+    for kernel in ("match_knn2_mfma_kernel", "ransac_close_kernel"):
+        assert kernel not in prod, kernel
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    exp = subprocess.run(["strings", "-a", build.build(experiments=True)], capture_output=True, text=True, check=True).stdout
+    assert "VSLAM_MATCH_POPCOUNT" in exp and "match_knn2_mfma_kernel" in exp and "ransac_close_kernel" in exp
+    assert os.path.getsize(build.LIB) < os.path.getsize(build.EXP_LIB)

@@ -10,9 +10,10 @@ def test_extraction_stages_on_random_shapes(ctx, oracle):
     assert fuzz_extract.run(ctx, oracle, seed=20261004, cases=150) == 150
 
 
-def test_matcher_on_random_ragged_batches(ctx, oracle):
+def test_matcher_on_random_ragged_batches(ctx, ctx_exp, oracle):
     import fuzz_match
-    assert fuzz_match.run(ctx, oracle, seed=20261006, cases=120) == 120
+    assert fuzz_match.run(ctx, oracle, seed=20261006, cases=60, variants=False) == 60      # the product's one matcher
+    assert fuzz_match.run(ctx_exp, oracle, seed=20261007, cases=60, variants=True) == 60   # its variants (experiments build)
 
 
 def test_ransac_kernels_on_random_and_degenerate_inputs(ctx, oracle):

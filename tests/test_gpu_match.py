@@ -18,18 +18,34 @@ def _pack(items, K):
     return torch.from_numpy(d).cuda(), torch.from_numpy(n).cuda()
 
 
-@pytest.fixture(params=[(1, 1), (2, 1), (1, 2), (2, 2)], ids=["fp4-8x32", "fp4-4x64", "i8-8x32", "i8-4x64"])
-def shape(ctx, request):
-    """Both workgroup shapes (VSLAM_OPT_MATCH_SHAPE; the default picks one by kp_stride) of both matrix-core forms of the
-    matcher (VSLAM_OPT_MATCH_FORM: FP4 +-1 products, the default, and int8 0 / 1 products)."""
-    ctx.set_option(ctx.OPT_MATCH_SHAPE, request.param[0])
-    ctx.set_option(ctx.OPT_MATCH_FORM, request.param[1])
-    yield request.param
-    ctx.set_option(ctx.OPT_MATCH_SHAPE, 0)
+@pytest.fixture(params=[(0, 0), (1, 1), (2, 1), (1, 2), (2, 2)], ids=["product", "exp-fp4-8x32", "exp-fp4-4x64", "exp-i8-8x32", "exp-i8-4x64"])
+def mctx(request):
+    """The product library's one matcher (FP4 +-1 products, 8 waves x 32 rows), and -- through the EXPERIMENTS build, the only
+    one that carries them -- both workgroup shapes (VSLAM_OPT_MATCH_SHAPE) of both matrix-core forms (VSLAM_OPT_MATCH_FORM:
+    FP4, int8 0 / 1 products).  Yields the context to use."""
+    if request.param == (0, 0):
+        yield request.getfixturevalue("ctx")
+        return
+    c = request.getfixturevalue("ctx_exp")
+    c.set_option(c.OPT_MATCH_SHAPE, request.param[0])
+    c.set_option(c.OPT_MATCH_FORM, request.param[1])
+    yield c
+    c.set_option(c.OPT_MATCH_SHAPE, 0)
+    c.set_option(c.OPT_MATCH_FORM, 0)
+
+
+def test_product_library_carries_one_matcher(ctx):
+    """The matcher's variants are settable in the experiments build only."""
+    from vslam_amd import VslamError
+    for opt, val in ((ctx.OPT_MATCH_SHAPE, 1), (ctx.OPT_MATCH_SHAPE, 2), (ctx.OPT_MATCH_FORM, 2)):
+        with pytest.raises(VslamError):
+            ctx.set_option(opt, val)
+    ctx.set_option(ctx.OPT_MATCH_FORM, 1)   # FP4 is the product's form
     ctx.set_option(ctx.OPT_MATCH_FORM, 0)
 
 
-def test_knn2_and_ratio_bit_exact_ragged_batch(ctx, oracle, shape):
+def test_knn2_and_ratio_bit_exact_ragged_batch(mctx, oracle):
+    ctx = mctx
     K = 700
     sizes = [(500, 500), (700, 650), (1, 2), (513, 257), (256, 512), (0, 10), (10, 1), (10, 0), (3, 2)]
     items = [synth.descriptors_pair(100 + i, a, b) for i, (a, b) in enumerate(sizes)]
@@ -55,7 +71,8 @@ def test_knn2_and_ratio_bit_exact_ragged_batch(ctx, oracle, shape):
             assert m[b] == 0      # reference reads m[1] of a 1-row result: undefined; we emit nothing
 
 
-def test_full_size_property_self_match(ctx, shape):
+def test_full_size_property_self_match(mctx):
+    ctx = mctx
     """At the headline size (K = 2000, B = 8 of the 256) every row's best match against a
     shuffled copy of itself is its own image at distance 0, and a copy is its own 2nd-NN-ratio
     survivor: checks index packing over the whole range without the oracle."""

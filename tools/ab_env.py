@@ -7,6 +7,7 @@ Context-level knobs with batches in flight, one process, alternating blocks: wha
 the auxiliary stream, stream priorities) may not with three batches filling each other's holes.
     python tools/ab_env.py [C3] [in_flight] [rounds] [hard|easy]"""
 import os
+os.environ.setdefault('VSLAM_AMD_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'vslam_amd', 'libvslam_amd_exp.so'))   # the knobs exist in the EXPERIMENTS build only
 import sys
 import time
 

@@ -1,6 +1,8 @@
 # A/B of the matcher at C3 and C5: kernel time (alone, its own launches, spreading pre-pass included) and step time for
 # the FP4 form (default: 8 waves x 32 rows, pre-spread train rows) and its variants, and the int8 form.
 # usage (on the GPU box): bash tools/ab_match.sh > gpurun_out/ab_match.txt
+# environment knobs exist in the EXPERIMENTS build of the library only (vslam_amd/build.py: libvslam_amd_exp.so)
+export VSLAM_AMD_LIB=${VSLAM_AMD_LIB:-$(dirname $0)/../vslam_amd/libvslam_amd_exp.so}
 run() {   # label, then VAR=value ...
   label=$1; shift
   for wl in C3 C5; do

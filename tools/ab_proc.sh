@@ -2,6 +2,8 @@
 # in the same order: which hardware queue a stream lands on depends on what the process created before it, and that mapping
 # moves the step by up to 9 % -- tools/ab_env.py's in-process comparison is blind to it), repeated and interleaved.
 #   bash tools/ab_proc.sh <reps> "NAME=VALUE ..." "NAME=VALUE ..." ...      ("-" = no variables)
+# environment knobs exist in the EXPERIMENTS build of the library only (vslam_amd/build.py: libvslam_amd_exp.so)
+export VSLAM_AMD_LIB=${VSLAM_AMD_LIB:-$(dirname $0)/../vslam_amd/libvslam_amd_exp.so}
 REPS=$1; shift
 B="--no-extras --cpu-pairs 0 --no-profile-pass --steps 60 --warmup 10"
 for r in $(seq $REPS); do

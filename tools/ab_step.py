@@ -3,6 +3,7 @@
 box-to-box differences cancel.  usage: python tools/ab_step.py [C3|C5] [rounds]
 Prints mean and spread of the step time per configuration."""
 import os
+os.environ.setdefault('VSLAM_AMD_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'vslam_amd', 'libvslam_amd_exp.so'))   # the knobs exist in the EXPERIMENTS build only
 import sys
 import time
 

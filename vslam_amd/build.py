@@ -23,25 +23,39 @@ EXTRA_FLAGS = {"response.hip": ["-fno-slp-vectorize"]}
 OBJDIR = os.path.join(HERE, "_obj")
 
 
-def _compile(hipcc, src, verbose):
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+# The experiments build: the same sources with -DVSLAM_EXPERIMENTS (ctx.h), i.e. WITH the environment-variable A/B switches and
+# the kernel variants that were measured and not chosen.  tools/ab_*.py and the variant tests load it through VSLAM_AMD_LIB /
+# capi.load_library(EXP_LIB); the product (LIB) reads no environment variable and carries one kernel per stage.
+EXP_LIB = os.path.join(HERE, "libvslam_amd_exp.so")
+EXP_OBJDIR = os.path.join(HERE, "_obj_exp")
+
+
+def _compile(hipcc, src, verbose, objdir=None, extra=()):
+    objdir = objdir or OBJDIR
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj, None
-    cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", "-o", obj, src]
+    cmd = [hipcc] + FLAGS + list(extra) + EXTRA_FLAGS.get(src, []) + ["-c", "-o", obj, src]
     if verbose:
         print(" ".join(cmd))
     return obj, subprocess.Popen(cmd, cwd=CSRC)
 
 
-def build(force=False, verbose=False):
-    """Every source is its own translation unit (no device code crosses files), compiled in parallel, then linked."""
+def build(force=False, verbose=False, experiments=False):
+    """Every source is its own translation unit (no device code crosses files), compiled in parallel, then linked.
+    experiments=True builds libvslam_amd_exp.so (-DVSLAM_EXPERIMENTS) instead of the product."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir, lib, extra = (EXP_OBJDIR, EXP_LIB, ("-DVSLAM_EXPERIMENTS",)) if experiments else (OBJDIR, LIB, ())
+    return _build(hipcc, objdir, lib, extra, force, verbose)
+
+
+def _build(hipcc, OBJDIR, LIB, extra, force, verbose):
     os.makedirs(OBJDIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJDIR):
             os.remove(os.path.join(OBJDIR, f))
-    jobs = [_compile(hipcc, src, verbose) for src in SOURCES]
+    jobs = [_compile(hipcc, src, verbose, OBJDIR, extra) for src in SOURCES]
     failed = [obj for obj, proc in jobs if proc is not None and proc.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, "hipcc -c (" + ", ".join(os.path.basename(f) for f in failed) + ")")
@@ -79,5 +93,7 @@ def build_host(force=False, verbose=False):
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     build_host(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, experiments=True)
     print(LIB)
+    print(EXP_LIB)
     print(HOST_LIB)

@@ -10,6 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSLAM_AMD_LIB: another build of the same library (A/B timing of kernel variants: tools/ab_kernels.py)
 LIB_PATH = os.environ.get("VSLAM_AMD_LIB") or os.path.join(_HERE, "libvslam_amd.so")
+# The experiments build of the same sources (-DVSLAM_EXPERIMENTS): the environment-variable A/B switches and the kernel variants
+# that were measured and not chosen live only there (tools/ab_*.py, the variant tests); the product library has neither.
+EXP_LIB_PATH = os.path.join(_HERE, "libvslam_amd_exp.so")
 
 OK = 0
 ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE",
@@ -66,10 +69,10 @@ def _ptr(t):
 class Context:
     """One vslam_ctx bound to a torch device/stream."""
 
-    def __init__(self, device=0, use_torch_stream=True):
+    def __init__(self, device=0, use_torch_stream=True, lib=None):
         import torch
         self.torch = torch
-        self.lib = load_library()
+        self.lib = lib if lib is not None else load_library()
         self.handle = C.c_void_p()
         rc = self.lib.vslam_ctx_create(C.c_int(device), C.byref(self.handle))
         if rc != OK:

@@ -414,9 +414,9 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
     VS_REQUIRE(ctx, blurred && xy_in && n_in && pattern && xy_out && desc && n_out, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, frames > 0 && kp_stride > 0, VSLAM_ERR_INVALID);
     // the tile-staged descriptor kernel (VSLAM_RBRIEF_PATCH=1 selects round 2's per-keypoint staging, for A/B timing)
-    static const bool patch_form = getenv("VSLAM_RBRIEF_PATCH") != nullptr;
+    static const bool patch_form = VS_EXPERIMENT_ENV("VSLAM_RBRIEF_PATCH") != nullptr;
     int tw = kTW, th = kTH;
-    if (const char *e = getenv("VSLAM_RBRIEF_TILE")) sscanf(e, "%dx%d", &tw, &th);   // A/B timing
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_RBRIEF_TILE")) sscanf(e, "%dx%d", &tw, &th);   // A/B timing
     while (vs_div_up(w, tw) * vs_div_up(h, th) > kTilesMax) {
         tw *= 2;
         th *= 2;

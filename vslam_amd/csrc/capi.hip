@@ -189,7 +189,16 @@ int vslam_ctx_create(int device, vslam_ctx **out) { return vs_ctx_create(device,
 // streams on one hardware queue run one after the other.  Measured in fresh processes (tools/ab_proc.sh, three batches in
 // flight at C3): the same kernels and forks 2.69 ms per batch with three streams per context, 2.85 with a fourth that is idle.
 static int vs_copy_stream(vslam_ctx *ctx, hipStream_t *out) {
-    if (!ctx->copy_stream) VS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->copy_stream) {
+        // on the context's device, whatever the caller's thread has current (two pipelines on two devices in one thread);
+        // the caller's device is put back
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        VS_HIP(ctx, hipSetDevice(ctx->device));
+        const hipError_t e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+        if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
+        VS_HIP(ctx, e);
+    }
     *out = ctx->copy_stream;
     return VSLAM_OK;
 }
@@ -197,7 +206,7 @@ static int vs_copy_stream(vslam_ctx *ctx, hipStream_t *out) {
 int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
     if (!out) return VSLAM_ERR_INVALID;
     *out = nullptr;
-    if (const char *e = getenv("VSLAM_SHARED_CHIP")) shared_chip = shared_chip && e[0] != '0';   // A/B: pipeline contexts as plain ones
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_SHARED_CHIP")) shared_chip = shared_chip && e[0] != '0';   // A/B: pipeline contexts as plain ones
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return VSLAM_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return VSLAM_ERR_INVALID;
@@ -208,12 +217,12 @@ int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
     // stream's workgroups go first whenever both have some ready (VSLAM_STREAM_PRIORITY=0: both at the default priority).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (const char *e = getenv("VSLAM_STREAM_PRIORITY")) {
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_STREAM_PRIORITY")) {
         if (e[0] == '0') prio_least = prio_greatest = 0;
         if (e[0] == '2') prio_greatest = 0;   // main at the default priority, auxiliary below it
     }
     bool shared_main_high = false;
-    if (const char *e = getenv("VSLAM_STREAM_PRIORITY")) shared_main_high = e[0] == '3';   // A/B: shared-chip mains above their auxiliaries
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_STREAM_PRIORITY")) shared_main_high = e[0] == '3';   // A/B: shared-chip mains above their auxiliaries
     if (shared_chip) {
         prio_least = 0;   // the auxiliary stream level with the main one, the main streams of all contexts at the default priority
         if (!shared_main_high) prio_greatest = 0;
@@ -230,7 +239,7 @@ int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
         return VSLAM_ERR_HIP;
     }
     ctx->lazy_streams = shared_chip;   // streams a context may never use are made on first use (see vs_copy_stream)
-    if (const char *e = getenv("VSLAM_LAZY_STREAMS")) ctx->lazy_streams = e[0] != '0';
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_LAZY_STREAMS")) ctx->lazy_streams = e[0] != '0';
     if ((!ctx->lazy_streams && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&ctx->ev_raw, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
@@ -239,10 +248,10 @@ int vs_ctx_create(int device, bool shared_chip, vslam_ctx **out) {
     }
     ctx->shared_chip = shared_chip;
     if (shared_chip) ctx->overlap_blur = 0;
-    if (const char *e = getenv("VSLAM_OVERLAP_BLUR")) ctx->overlap_blur = e[0] - '0';
-    if (const char *e = getenv("VSLAM_SETS_PREFETCH")) ctx->sets_prefetch = e[0] != '0';
-    if (const char *e = getenv("VSLAM_TREE_FORK")) ctx->tree_fork = atoi(e);   // A/B across processes (the option does the same)
-    if (const char *e = getenv("VSLAM_RANSAC_SOLVE_SPLIT")) ctx->solve_split = atoi(e);
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_OVERLAP_BLUR")) ctx->overlap_blur = e[0] - '0';
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_SETS_PREFETCH")) ctx->sets_prefetch = e[0] != '0';
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_TREE_FORK")) ctx->tree_fork = atoi(e);   // A/B across processes (the option does the same)
+    if (const char *e = VS_EXPERIMENT_ENV("VSLAM_RANSAC_SOLVE_SPLIT")) ctx->solve_split = atoi(e);
     *out = ctx;
     return VSLAM_OK;
 }
@@ -359,6 +368,9 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
     }
     if (option == VSLAM_OPT_MATCH_FORM) {
         VS_REQUIRE(ctx, value >= 0 && value <= 2, VSLAM_ERR_INVALID);
+#ifndef VSLAM_EXPERIMENTS
+        VS_REQUIRE(ctx, value <= 1 && "the int8 form of the matcher exists in the experiments build only", VSLAM_ERR_INVALID);
+#endif
         ctx->match_form = value;
         return VSLAM_OK;
     }
@@ -369,6 +381,9 @@ int vslam_ctx_set_option(vslam_ctx *ctx, int option, int value) {
     }
     if (option == VSLAM_OPT_MATCH_SHAPE) {
         VS_REQUIRE(ctx, value >= 0 && value <= 2, VSLAM_ERR_INVALID);
+#ifndef VSLAM_EXPERIMENTS
+        VS_REQUIRE(ctx, value == 0 && "the matcher's other workgroup shapes exist in the experiments build only", VSLAM_ERR_INVALID);
+#endif
         ctx->match_shape = value;
         return VSLAM_OK;
     }

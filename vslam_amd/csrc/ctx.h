@@ -120,6 +120,16 @@ struct VsProfScope {
 
 static inline int vs_div_up(int a, int b) { return (a + b - 1) / b; }
 
+// A/B switches (slower kernel variants, stream arrangements, tile shapes measured and not chosen) exist only in the
+// EXPERIMENTS build of the library (-DVSLAM_EXPERIMENTS -> libvslam_amd_exp.so, which tools/ab_*.py and the variant tests load
+// through VSLAM_AMD_LIB / capi.load_library): the default build reads no environment variable and carries one kernel per stage.
+#ifdef VSLAM_EXPERIMENTS
+#include <cstdlib>
+#define VS_EXPERIMENT_ENV(name) getenv(name)
+#else
+#define VS_EXPERIMENT_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 #ifdef __HIPCC__
 // Workgroups are dealt round-robin over the 8 XCDs (linear id L lands on XCD L % 8 — observed, used
 // for speed only, never for correctness).  Remap a 1-D grid of ceil(items/8)*8*per_item blocks so that

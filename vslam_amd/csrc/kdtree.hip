@@ -279,7 +279,7 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
     // Point indices and the partition's stopper lists as 16-bit values (keypoint slots are below VSLAM_MAX_KP = 16384): 14
     // instead of 20 bytes of LDS per point.  At 4000 keypoints that is 56 KB per tree, so two builds share a CU where
     // 80 KB allowed one (VSLAM_KD_IDX16=0 / 1 forces either form; same trees).
-    static const char *idx_env = getenv("VSLAM_KD_IDX16");
+    static const char *const idx_env = VS_EXPERIMENT_ENV("VSLAM_KD_IDX16");
     const bool idx16 = idx_env ? idx_env[0] == '1' : true;
     const size_t lds = idx16 ? (((size_t)kp_stride * 8 + (size_t)kp_stride * 2 * 3 + 4 + 15) & ~(size_t)15) : (size_t)kp_stride * 20 + 8;
     VS_REQUIRE(ctx, kp_stride <= VSLAM_MAX_KP, VSLAM_ERR_CAPACITY);
@@ -287,7 +287,7 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
     // Workgroup size by batch: with few trees in flight (the one-frame-at-a-time drop-in use) sixteen waves take the 8, 16
     // and 32 subtrees of depths 3-5 in one or two rounds instead of up to eight (one 2000-point tree: 0.24 -> 0.17 ms);
     // beside the matcher of a large batch the extra waves cost the step more than the build gains (2.92 -> 3.07 ms at C3).
-    static const char *shape_env = getenv("VSLAM_KD_THREADS");   // 256 / 1024 force one (A/B timing)
+    static const char *const shape_env = VS_EXPERIMENT_ENV("VSLAM_KD_THREADS");   // 256 / 1024 force one (A/B timing)
     const int threads = shape_env ? atoi(shape_env) : (batch <= 32 ? 1024 : 256);
     VsProfScope ps(ctx, "kdtree_build_kernel");
 #define VS_KD_LAUNCH(T, M, I)                                                                                               \
@@ -299,10 +299,13 @@ int vs_launch_kdtree_build(vslam_ctx *ctx, const float *xy, const int32_t *n, in
         }                                                                                                                   \
         kdtree_build_kernel<T, M, I><<<batch, T, lds, ctx->stream>>>(xy, n, kp_stride, nodes);                              \
     } while (0)
-    if (threads == 1024 && idx16) VS_KD_LAUNCH(1024, 48, uint16_t);
-    else if (threads == 1024) VS_KD_LAUNCH(1024, 48, int);
-    else if (idx16) VS_KD_LAUNCH(256, 48, uint16_t);
-    else VS_KD_LAUNCH(256, 48, int);
+#ifdef VSLAM_EXPERIMENTS
+    if (threads == 1024 && !idx16) VS_KD_LAUNCH(1024, 48, int);
+    else if (threads != 1024 && !idx16) VS_KD_LAUNCH(256, 48, int);
+    else
+#endif
+    if (threads == 1024) VS_KD_LAUNCH(1024, 48, uint16_t);
+    else VS_KD_LAUNCH(256, 48, uint16_t);
 #undef VS_KD_LAUNCH
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;

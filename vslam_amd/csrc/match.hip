@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+#ifdef VSLAM_EXPERIMENTS   // the vector-ALU matcher of round 1 (VSLAM_MATCH_POPCOUNT): kept for A/B timing only
 constexpr int kQueriesPerLane = 2;
 constexpr int kTile = 256;   // train rows per LDS tile (8 KiB)
 
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(kThreads) void match_knn2_kernel(
         match_knn2_body<2>(q4, t4, nq, nt, qbase, tile, sel_b, knn_b);
 }
 
+#endif   // VSLAM_EXPERIMENTS
+
 // ------------------------------------------------------------------------------------------------------------------
 // The same knn-2 on the matrix cores (the default).  For 0/1 vectors a, b of 256 bits, Hamming(a, b) = |a| + |b| - 2 a.b,
 // and a.b over 256 positions is an int8 dot product: v_mfma_i32_32x32x32_i8 forms 32 x 32 of them per instruction at
@@ -160,14 +163,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int kMQ = 256;         // query rows per workgroup
 constexpr int kMT = 32;          // train rows per tile
+#ifdef VSLAM_EXPERIMENTS   // (the int8 form's)
 constexpr int kMStride = 272;    // bytes per expanded train row in LDS: 256 + 16, so 16 consecutive rows cover all banks
 constexpr uint32_t kMBias = 512; // keeps |b| - 2 a.b positive
 constexpr uint32_t kMPad = 0x4000;   // "|b|" of a train row beyond nt: never among the two smallest of a real row
+#endif
 
 __device__ __forceinline__ uint32_t spread4(uint32_t nib) {   // 4 bits -> 4 bytes holding 0 / 1
     return (nib * 0x00204081u) & 0x01010101u;
 }
-__device__ __forceinline__ v4i spread16(uint32_t bits) {      // 16 bits -> 16 bytes
+[[maybe_unused]] __device__ __forceinline__ v4i spread16(uint32_t bits) {   // (int8 form: experiments build)      // 16 bits -> 16 bytes
     v4i r;
     r.x = (int)spread4(bits & 0xFu);
     r.y = (int)spread4((bits >> 4) & 0xFu);
@@ -183,7 +188,7 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
 // base - (dot << 17) in one instruction (dot <= 256 and -2^17 both fit the 24-bit operands: the compiler folds the
 // 24-bit multiply and the add into v_mad_i32_i24).  Not inline assembly: the operand comes straight out of an MFMA, and
 // the wait states a vector instruction needs after one are only inserted for instructions the compiler knows.
-__device__ __forceinline__ uint32_t mad24(int dot, int base, int neg_two_17) {
+[[maybe_unused]] __device__ __forceinline__ uint32_t mad24(int dot, int base, int neg_two_17) {
     return (uint32_t)(__mul24(dot, neg_two_17) + base);
 }
 // (smallest, second smallest) of this lane's pair and the pair of the lane a DPP pattern points at
@@ -195,6 +200,7 @@ __device__ __forceinline__ void merge2(uint32_t &x1, uint32_t &x2) {
     x1 = lo;
 }
 
+#ifdef VSLAM_EXPERIMENTS   // the int8 form (VSLAM_OPT_MATCH_FORM 2): kept for A/B timing only
 // RT = 32-row query tiles per wave; a workgroup is kMQ / (32 RT) waves.
 template <int RT>
 __global__ __launch_bounds__(64 * kMQ / (32 * RT)) void match_knn2_mfma_kernel(
@@ -345,6 +351,8 @@ __global__ __launch_bounds__(64 * kMQ / (32 * RT)) void match_knn2_mfma_kernel(
             }
         }
 }
+
+#endif   // VSLAM_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same knn-2 with FP4 operands (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1, unit block scales): a descriptor bit becomes
@@ -623,7 +631,21 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
     int32_t *sel = nullptr;
     int rc = vs_arena_get(ctx, "match.sel", sizeof(int32_t) * (size_t)batch * kp_stride, (void **)&sel);
     if (rc) return rc;
-    static const bool popcount_path = getenv("VSLAM_MATCH_POPCOUNT") != nullptr;   // the vector-ALU kernel, for A/B timing
+#ifndef VSLAM_EXPERIMENTS
+    {   // the product's one matcher: FP4 products, 8 waves x 32 rows, train rows spread once per pair, two tiles per trip
+        // (tools/ab_match.sh on the experiments build: 0.186 / 1.30 ms at C3 / C5 against 0.191-0.208 / 1.34-1.51 for the other
+        // FP4 arrangements and 0.279 / 1.97 for the int8 form)
+        VsProfScope ps(ctx, "match_knn2_kernel");
+        const int per_pair = vs_div_up(kp_stride, kMQ);
+        const int xgrid = vs_xcd_grid(batch, per_pair);
+        const int kp_pad = vs_div_up(kp_stride, 2 * kMT) * 2 * kMT;
+        uint8_t *tx = nullptr;
+        if ((rc = vs_arena_get(ctx, "match.spread", (size_t)batch * kp_pad * 128, (void **)&tx))) return rc;
+        match_spread_kernel<<<dim3(vs_div_up(kp_stride * 8, 256), batch), 256, 0, ctx->stream>>>(d2, n2, kp_stride, kp_pad, tx);
+        match_knn2_fp4_kernel<1, true, 2><<<xgrid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn, tx, kp_pad, batch, per_pair);
+    }
+#else
+    static const bool popcount_path = VS_EXPERIMENT_ENV("VSLAM_MATCH_POPCOUNT") != nullptr;   // the vector-ALU kernel, for A/B timing
     {
         VsProfScope ps(ctx, "match_knn2_kernel");
         if (popcount_path) {
@@ -636,12 +658,22 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
             // k-d build, which the front end runs beside the matcher, the wave slots it needs, and the STEP is faster
             // with it while the two take about equally long (C3: 3.70 vs 3.76 ms).  With more keypoints the matcher
             // dominates (quadratic against n log n) and the first shape wins the step too (C5: 18.1 vs 18.3 ms).
-            static const char *shape = getenv("VSLAM_MATCH_SHAPE");   // "8x32" / "4x64" force one (A/B timing)
+            static const char *const shape = VS_EXPERIMENT_ENV("VSLAM_MATCH_SHAPE");   // "8x32" / "4x64" force one (A/B timing)
+#ifdef VSLAM_EXPERIMENTS
             const int pick = ctx->match_shape ? ctx->match_shape : (shape ? (shape[0] == '4' ? 2 : 1) : 0);
+#else
+            constexpr int pick = 0;   // (VSLAM_OPT_MATCH_SHAPE / _FORM are settable in the experiments build only)
+            (void)shape;
+#endif
             const bool wide = pick ? pick == 2 : kp_stride <= 2048;
             dim3 grid(vs_div_up(kp_stride, kMQ), batch);
-            static const char *form = getenv("VSLAM_MATCH_FORM");   // "i8": the int8 form (A/B timing); default FP4
+            static const char *const form = VS_EXPERIMENT_ENV("VSLAM_MATCH_FORM");   // "i8": the int8 form (A/B timing); default FP4
+#ifdef VSLAM_EXPERIMENTS
             const bool fp4 = ctx->match_form ? ctx->match_form == 1 : !(form && form[0] == 'i');
+#else
+            constexpr bool fp4 = true;
+            (void)form;
+#endif
             if (fp4) {
                 // The FP4 form as measured (tools/ab_match.sh, kernel alone, C3 / C5 in ms; int8 form: 0.279 / 1.97):
                 //   8 x 32, pre-spread, 2 tiles per trip   0.186 / 1.30   <- the default
@@ -652,8 +684,8 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
                 const bool wide4 = pick == 2;
                 const int per_pair = vs_div_up(kp_stride, kMQ);
                 const int xgrid = vs_xcd_grid(batch, per_pair);
-                static const char *nopre = getenv("VSLAM_MATCH_NO_PRESPREAD");   // A/B timing: every workgroup spreads for itself
-                static const char *ct_env = getenv("VSLAM_MATCH_TILES_PER_TRIP");
+                static const char *const nopre = VS_EXPERIMENT_ENV("VSLAM_MATCH_NO_PRESPREAD");   // A/B timing: every workgroup spreads for itself
+                static const char *const ct_env = VS_EXPERIMENT_ENV("VSLAM_MATCH_TILES_PER_TRIP");
                 const int ct = ct_env ? atoi(ct_env) : 2;
                 if (!nopre) {
                     const int kp_pad = vs_div_up(kp_stride, 2 * kMT) * 2 * kMT;
@@ -673,6 +705,7 @@ int vs_launch_match(vslam_ctx *ctx, const uint8_t *d1, const int32_t *n1, const 
             else match_knn2_mfma_kernel<1><<<grid, 512, 0, ctx->stream>>>(d1, n1, d2, n2, kp_stride, sel, knn);
         }
     }
+#endif   // VSLAM_EXPERIMENTS
     {
         VsProfScope ps(ctx, "match_compact_kernel");
         match_compact_kernel<<<batch, kThreads, 0, ctx->stream>>>(sel, n1, kp_stride, pairs, m);

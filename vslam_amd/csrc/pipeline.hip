@@ -107,7 +107,15 @@ int commit_locked(vslam_pipeline *p, int64_t ticket) {
     if (e == hipSuccess) e = hipMemsetAsync(s.d_flag, 0, sizeof(int32_t), c->stream);
     if (e == hipSuccess) e = hipEventRecord(s.done, c->stream);
     if (e != hipSuccess) {
+        // The slot is already marked in flight.  Without its event it must not look finished while kernels may still run, and
+        // the ticket must not report a stale flag: drain the stream here and file the failure under the ticket.
         p->err = std::string("vslam_pipeline_commit: ") + hipGetErrorString(e);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipEventRecord(s.done, c->stream);
+        *s.h_flag = 0;
+        if (p->failures.size() >= kMaxFailures) p->failures.pop_front();
+        p->failures.push_back({ticket, VSLAM_ERR_HIP, p->err});
+        s.ticket = -1;   // drained and filed: nothing of this batch is in flight any more
         return VSLAM_ERR_HIP;
     }
     return VSLAM_OK;

@@ -768,7 +768,9 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(W
     }
 }
 
-// The closing part of the split form: four waves per workgroup, a lane per hypothesis, F0 in, F out, in place.
+#ifdef VSLAM_EXPERIMENTS
+// The closing part of the split form (experiments build; measured slower than the one-kernel solve): four waves per
+// workgroup, a lane per hypothesis, F0 in, F out, in place.
 constexpr int kCloseThreads = 256;
 __global__ __launch_bounds__(kCloseThreads) void ransac_close_kernel(const int32_t *__restrict__ m_arr, int min_m, int hyp,
                                                                      float *__restrict__ hypF) {
@@ -778,16 +780,17 @@ __global__ __launch_bounds__(kCloseThreads) void ransac_close_kernel(const int32
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = blockIdx.x * kCloseThreads + threadIdx.x;
     const bool live = h < hyp;
-    float *o = hypF + ((size_t)b * hyp + (live ? h : hyp - 1)) * 9;
+    float *o = hypF + ((size_t)b * hyp + (live ? h : 0)) * 9;
     float f0[9], F[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) f0[k] = o[k];
+    for (int k = 0; k < 9; k++) f0[k] = live ? o[k] : (k % 4 == 0 ? 1.f : 0.f);   // lanes past the end work on the identity: no read of a slot a live lane rewrites
     fundamental_rank2(f0, s[wave], s[wave] + 9 * kSolveThreads, lane, F);
     if (live) {
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = F[k];
     }
 }
+#endif   // VSLAM_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // compute_fundamental, opt-in approximate form: the 8-point system as a dense contraction on the matrix cores
@@ -2419,8 +2422,11 @@ int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, c
     }
     // VSLAM_RANSAC_SOLVE_SPLIT: 0 one kernel (rounds 2-4); 4 / 5: sweeps + null-space row at 4 / 5 waves per SIMD, then
     // ransac_close_kernel (the 3 x 3 SVD and U diag Vt, a launch of its own at full occupancy).  Same bits either way.
-    const int split = ctx->solve_split;
     VsProfScope ps(ctx, "ransac_solve_kernel");
+#ifndef VSLAM_EXPERIMENTS
+    ransac_solve_kernel<false, 4><<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
+#else
+    const int split = ctx->solve_split;
     if (split == 0) {
         ransac_solve_kernel<false, 4><<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
     } else {
@@ -2430,6 +2436,7 @@ int vs_launch_ransac_solve(vslam_ctx *ctx, const float *xy1, const float *xy2, c
             ransac_solve_kernel<true, 4><<<grid, kSolveThreads, 0, ctx->stream>>>(xy1, xy2, pairs, m, ctx->ransac_min_matches, sets, kp_stride, hyp, hypF);
         ransac_close_kernel<<<dim3(vs_div_up(hyp, kCloseThreads), batch), kCloseThreads, 0, ctx->stream>>>(m, ctx->ransac_min_matches, hyp, hypF);
     }
+#endif
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }
@@ -2461,7 +2468,7 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         if ((rc = vs_arena_get(ctx, "ransac.cbound", sizeof(int32_t) * (size_t)batch, (void **)&cbound))) return rc;
         unsigned long long *sfloor = nullptr;
         if ((rc = vs_arena_get(ctx, "ransac.sfloor", sizeof(unsigned long long) * (size_t)batch, (void **)&sfloor))) return rc;
-        static const bool no_sum_rule = getenv("VSLAM_RANSAC_NO_SUM_RULE") != nullptr;   // A/B timing: bail out on counts only
+        static const bool no_sum_rule = VS_EXPERIMENT_ENV("VSLAM_RANSAC_NO_SUM_RULE") != nullptr;   // A/B timing: bail out on counts only
         const unsigned long long *use_floor = no_sum_rule ? nullptr : sfloor;
         if ((rc = vs_arena_get(ctx, "ransac.pot0", sizeof(int32_t) * (size_t)batch * hyp, (void **)&pot0))) return rc;
         if ((rc = vs_arena_get(ctx, "ransac.rk", sizeof(float) * 4 * (size_t)kp_pad * batch, (void **)&rk))) return rc;
@@ -2502,7 +2509,7 @@ int vs_launch_ransac_evaluate(vslam_ctx *ctx, const float *xy1, const float *xy2
         }
         // the closing stages: one launch when the four waves' sum buffers fit LDS (kp_stride <= 4096), else three
         const size_t fin_lds = sizeof(float) * (size_t)kTieGrid * kp_stride;
-        static const bool split_finish = getenv("VSLAM_RANSAC_SPLIT_FINISH") != nullptr;   // A/B timing
+        static const bool split_finish = VS_EXPERIMENT_ENV("VSLAM_RANSAC_SPLIT_FINISH") != nullptr;   // A/B timing
         if (fin_lds <= 64 * 1024 && !split_finish) {
             VsProfScope ps(ctx, "ransac_finish_kernel");
             if (fin_lds > 32 * 1024 && !ctx->attr_done["ransac_finish"]) {

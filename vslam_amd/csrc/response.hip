@@ -1042,7 +1042,7 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
     *raw_list = fused ? 1 : 0;
     // the gray image has not been formed yet (bgr != nullptr): the two-tier detector does it on the way when the rows
     // are dword-aligned, a cvtColor launch in front otherwise
-    static const char *nofuse = getenv("VSLAM_NO_GRAY_FUSION");
+    static const char *const nofuse = VS_EXPERIMENT_ENV("VSLAM_NO_GRAY_FUSION");
     const bool from_bgr = bgr && fused && !nofuse && bgr->stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr->data) & 3) == 0 &&
                           vs_div_up(h, vs_stream_segments(h, frames, vs_div_up(w, kSW))) + 6 <= kTierMaxSteps;
     if (bgr && !from_bgr)
@@ -1100,7 +1100,7 @@ int vs_launch_corner_exact(vslam_ctx *ctx, const uint8_t *gray, int frames, int 
                            const unsigned long long *keys, unsigned long long *keys2, size_t key_cap, uint32_t n_safe,
                            int mode) {
     VsProfScope ps(ctx, mode == 0 ? "corner_exact_kernel" : "corner_rerun_kernels");
-    static const char *pf_env = getenv("VSLAM_CORNER_EXACT_WGS");
+    static const char *const pf_env = VS_EXPERIMENT_ENV("VSLAM_CORNER_EXACT_WGS");
     const int per_frame = pf_env ? atoi(pf_env) : 4;
     corner_exact_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
         gray, w, h, keys, c.counts, key_cap, c.hist, c.low, n_safe, keys2, mode == 0 ? c.count2 : c.count3, c.fmax, c.cutkey,
