@@ -306,6 +306,12 @@ int vslam_triangulate(vslam_ctx *ctx, const float *d_xy1, const float *d_xy2, co
                       const int32_t *d_best, int batch, int kp_stride, const float *h_K,
                       const float *d_c2, float *d_points4d);
 
+/* triangulate(p1, p2, c1, c2, points_4d) exactly as the reference declares it (include/helpers.h:19, src/helpers.cpp:37-80):
+ * n point pairs (d_p1, d_p2: [n][2] f32 on the device), any two 3 x 4 camera matrices (HOST, row-major) -> d_points4d [n][4]
+ * (x, y, z, 1).  What the C++ drop-in triangulate() of include/vslam/helpers.h calls.                                       */
+int vslam_triangulate_points(vslam_ctx *ctx, const float *d_p1, const float *d_p2, int n, const float *h_c1,
+                             const float *h_c2, float *d_points4d);
+
 /* Replaces the reprojection-error filter of src/vslam.cpp:192-251, reproducing the reference exactly,
  * including its two indexing quirks (the de-homogenise loop strides the flat N x 3 array by 3 up to N, and
  * map_point_ids is tested at the MATCH index).  d_points4d from vslam_triangulate; d_map_point_ids
@@ -354,6 +360,27 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
                          const uint32_t *d_seeds, int hyp, float threshold,
                          float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
                          int32_t *d_matches, int32_t *d_best, float *d_F);
+
+/* The capture loop's whole per-pair chain in one call, nothing leaving the device in between (src/vslam.cpp:60-88: extract,
+ * match_features, extract_Rt, R_t; :120-125 the camera matrices; :186 triangulate; :192-251 the reprojection filter):
+ * vslam_frontend_pairs, then vslam_extract_Rt, vslam_triangulate (c1 = [K | 0]) and vslam_reprojection_filter on its matches.
+ * h_K: HOST 3 x 3 intrinsics.  d_map_point_ids [pairs][kp_stride] of the current frames, or NULL for "none assigned" (-1
+ * everywhere).  Outputs as the four entry points write them; every pointer of `pose` is required.  Usable on a context of a
+ * vslam_pipeline like every other entry point.                                                                              */
+typedef struct vslam_pose_outputs {
+    float *d_R;             /* [pairs][9]  */
+    float *d_t;             /* [pairs][3]  */
+    float *d_c2;            /* [pairs][12] */
+    float *d_points4d;      /* [pairs][kp_stride][4] */
+    int32_t *d_inlier_idx;  /* [pairs][kp_stride] match indices that pass the reprojection filter, ascending */
+    int32_t *d_n_inliers;   /* [pairs] */
+    double *d_error;        /* [pairs] summed reprojection error of the kept matches */
+} vslam_pose_outputs;
+int vslam_frontend_pairs_pose(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int width, int height, int row_stride,
+                              const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                              float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                              int32_t *d_matches, int32_t *d_best, float *d_F, const float *h_K,
+                              const int32_t *d_map_point_ids, float reproj_threshold_sq, const vslam_pose_outputs *pose);
 
 /* Fixed-size per-pair result records for the one exchange of the multi-GPU path: per pair
  * 13 + kp_stride int32 words = F (9 words, bit-preserving), d_best's 4 words, then one word per match slot,

@@ -112,3 +112,61 @@ def test_cpp_surfaces_match_oracle(oracle, tmp_path):
     assert int(take(np.int32, 1)[0]) == r5["count"]
     assert int(take(np.int32, 1)[0]) == 1          # min_items = 9 overruns the sets in the reference: refused
     assert off == len(buf)
+
+
+def test_helpers_drop_in_matches_oracle(oracle, tmp_path):
+    """include/vslam/helpers.h: extract_Rt and triangulate with the reference's signatures (include/helpers.h:17-19), and the batch
+    form of the map-association block (src/vslam.cpp:129-161), driven the way the capture loop drives them."""
+    from vslam_amd import build
+    build.build_host()
+    exe = str(tmp_path / "helpers_demo")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "native", "helpers_demo.cpp"),
+                    "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vslam_amd"), "-lvslam_host", "-lvslam_amd",
+                    "-Wl,-rpath," + os.path.join(ROOT, "vslam_amd")], check=True)
+    w, h, maxc, H, seed = 320, 240, 400, 96, 4242
+    bgr = synth.frames_numpy(61, 1, w, h)
+    pat = synth.brief_pattern()
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("5i", w, h, maxc, H, seed))
+        f.write(bgr.tobytes())
+    subprocess.run([exe, fin, fout], check=True, timeout=120)
+    buf = open(fout, "rb").read()
+    off = 0
+
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(buf, dtype=dtype, count=n, offset=off)
+        off += a.nbytes
+        return a
+
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    ca, sa = synth.keypoint_rotation()
+    ex = [oracle.extract_features(bgr[i], maxc, ca, sa, pat) for i in range(2)]
+    mf = oracle.match_features(ex[0]["xy"], ex[0]["desc"], ex[1]["xy"], ex[1]["desc"], seed, H, 10.0)
+    n = int(take(np.int32, 1)[0])
+    matches = take(np.int32, 2 * n).reshape(n, 2)
+    assert n == len(mf["matches"]) and np.array_equal(matches, mf["matches"])
+    F = take(np.float32, 9)
+    assert np.array_equal(bits(F), bits(mf["F"]))
+    Kmat = np.array([[525, 0, w // 2], [0, 525, h // 2], [0, 0, 1]], np.float32)
+    Rr, tr = oracle.extract_Rt(F, Kmat)
+    assert np.array_equal(bits(take(np.float32, 9)), bits(Rr.reshape(9)))
+    assert np.array_equal(bits(take(np.float32, 3)), bits(tr))
+    c2 = take(np.float32, 12)
+    c2r = oracle.camera_matrix(Kmat, Rr, tr)
+    assert np.array_equal(bits(c2), bits(c2r.reshape(12)))            # the demo's K * [R | t] is cv::Mat's product
+    c1 = np.c_[Kmat, np.zeros(3, np.float32)]
+    p1, p2 = ex[0]["xy"][matches[:, 0]], ex[1]["xy"][matches[:, 1]]
+    pts = take(np.float32, 4 * n).reshape(n, 4)
+    assert np.array_equal(bits(pts), bits(oracle.triangulate(p1, p2, c1, c2r)))
+    nk = int(take(np.int32, 1)[0])
+    assert nk == ex[1]["n"]
+    ids_before, ids_after, claim = take(np.int32, nk), take(np.int32, nk), take(np.int32, n)
+    n_obs = int(take(np.int32, 1)[0])
+    offs = take(np.int32, n + 1)
+    od = take(np.uint8, 32 * n_obs).reshape(n_obs, 32)
+    ref_ids, ref_claim = oracle.associate(pts, c2r, w, h, ex[1]["nodes"], ex[1]["xy"], ex[1]["desc"], offs, od, ids_before)
+    assert np.array_equal(claim, ref_claim) and np.array_equal(ids_after, ref_ids)
+    assert (ref_claim >= 0).sum() >= n // 4, "the triangulated inliers should find their keypoints again"
+    assert off == len(buf)

@@ -140,3 +140,53 @@ def test_pose_chain_on_photographs(ctx, oracle, real):
         assert np.array_equal(bits(pts[b, :k]), bits(ref)), b
         kept, err = oracle.reprojection_filter(ref, p1, p2, c1, c2r, ids[b, :k], 4.0)
         assert rn[b] == len(kept) and np.array_equal(ridx[b, :rn[b]], kept) and rerr[b] == err, b
+
+
+def test_chained_pose_entry_on_photographs(ctx, oracle, real):
+    """vslam_frontend_pairs_pose: extract + match + RANSAC + extract_Rt + triangulate + reprojection filter in one call, the
+    matches never leaving the device; every output equals what the separate entry points give and what the oracle computes."""
+    g, bgr = real
+    P = bgr.shape[0] // 2
+    maxc, hyp, seed = (int(v) for v in g["params"])
+    ca, sa = synth.keypoint_rotation()
+    seeds = torch.from_numpy((np.uint32(seed) ^ np.arange(P, dtype=np.uint32)).view(np.int32)).cuda()
+    Kmat = np.array([[525.0, 0, 320], [0, 525.0, 240], [0, 0, 1]], np.float32)
+    d_bgr = torch.from_numpy(bgr).cuda()
+    out = ctx.frontend_pairs_pose(d_bgr, P, maxc, ca, sa, None, seeds, hyp, float(g["threshold"][0]), Kmat)
+    ctx.synchronize()
+    sep = ctx.frontend_pairs(d_bgr, P, maxc, ca, sa, None, seeds, hyp, float(g["threshold"][0]))
+    ctx.synchronize()
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    s_ = {k: v.cpu().numpy() for k, v in sep.items()}
+    for k in ("n", "xy", "desc", "nodes", "best", "matches"):
+        assert np.array_equal(o[k], s_[k]), k
+    assert np.array_equal(bits(o["F"]), bits(s_["F"]))
+    c1 = np.c_[Kmat, np.zeros(3, np.float32)]
+    for b in range(P):
+        assert o["best"][b, 0] >= 0 and np.array_equal(bits(o["F"][b]), bits(g[f"F{b}"]))
+        Rr, tr = oracle.extract_Rt(o["F"][b], Kmat)
+        c2r = oracle.camera_matrix(Kmat, Rr, tr)
+        assert np.array_equal(bits(o["R"][b]), bits(Rr.reshape(9))) and np.array_equal(bits(o["t"][b]), bits(tr)), b
+        assert np.array_equal(bits(o["c2"][b]), bits(c2r.reshape(12))), b
+        k = o["best"][b, 3]
+        mm = o["matches"][b, :k]
+        p1, p2 = o["xy"][b][mm[:, 0]], o["xy"][P + b][mm[:, 1]]
+        ref = oracle.triangulate(p1, p2, c1, c2r)
+        assert np.array_equal(bits(o["points4d"][b, :k]), bits(ref)), b
+        kept, err = oracle.reprojection_filter(ref, p1, p2, c1, c2r, np.full(k, -1, np.int32), 4.0)
+        assert o["n_inliers"][b] == len(kept) and np.array_equal(o["inlier_idx"][b, :len(kept)], kept) and o["error"][b] == err, b
+
+
+def test_triangulate_points_generic_form(ctx, oracle):
+    """vslam_triangulate_points: triangulate(p1, p2, c1, c2, points_4d) with any two camera matrices (include/helpers.h:19)."""
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 130, 1000):
+        p1 = rng.uniform(0, 640, (n, 2)).astype(np.float32)
+        p2 = (p1 + rng.normal(0, 3, (n, 2))).astype(np.float32)
+        c1 = rng.normal(0, 1, (3, 4)).astype(np.float32) * np.array([500, 500, 1], np.float32)[:, None]
+        c2 = rng.normal(0, 1, (3, 4)).astype(np.float32) * np.array([500, 500, 1], np.float32)[:, None]
+        pts = ctx.triangulate_points(torch.from_numpy(p1).cuda(), torch.from_numpy(p2).cuda(), c1, c2)
+        ctx.synchronize()
+        ref = oracle.triangulate(p1, p2, c1, c2)
+        assert np.array_equal(pts.cpu().numpy().view(np.uint32), ref.view(np.uint32)), n

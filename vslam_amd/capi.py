@@ -25,7 +25,7 @@ SYMBOLS = [
     "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
-    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_kdtree_cell_table", "vslam_extract_features", "vslam_extract_features_grid", "vslam_bgr2gray", "vslam_min_eigen",
+    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_kdtree_cell_table", "vslam_extract_features", "vslam_extract_features_grid", "vslam_triangulate_points", "vslam_frontend_pairs_pose", "vslam_bgr2gray", "vslam_min_eigen",
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points", "vslam_reprojection_filter",
     "vslam_match_features",
     "vslam_frontend_pairs", "vslam_frontend_sequence", "vslam_pack_records",
@@ -41,6 +41,11 @@ SYMBOLS = [
 class ExtractParams(C.Structure):
     _fields_ = [("max_corners", C.c_int32), ("quality", C.c_double), ("min_distance", C.c_double),
                 ("cos_a", C.c_float), ("sin_a", C.c_float), ("d_pattern", C.c_void_p)]
+
+
+class PoseOutputs(C.Structure):   # vslam_pose_outputs
+    _fields_ = [("d_R", C.c_void_p), ("d_t", C.c_void_p), ("d_c2", C.c_void_p), ("d_points4d", C.c_void_p),
+                ("d_inlier_idx", C.c_void_p), ("d_n_inliers", C.c_void_p), ("d_error", C.c_void_p)]
 
 
 class VslamError(RuntimeError):
@@ -444,6 +449,53 @@ class Context:
             self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(K),
             _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out["nodes"]),
             _ptr(out["n"]), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"])))
+        return out
+
+    def triangulate_points(self, p1, p2, c1, c2):
+        """triangulate(p1, p2, c1, c2, points_4d) as the reference declares it: (n, 2) device points, host 3 x 4 matrices."""
+        import numpy as np
+        torch = self.torch
+        n = p1.shape[0]
+        pts = torch.zeros((n, 4), dtype=torch.float32, device=p1.device)
+        c1h = np.ascontiguousarray(c1, dtype=np.float32).reshape(12)
+        c2h = np.ascontiguousarray(c2, dtype=np.float32).reshape(12)
+        self._check(self.lib.vslam_triangulate_points(self.handle, _ptr(p1), _ptr(p2), C.c_int(n), c1h.ctypes.data_as(C.c_void_p),
+                                                      c2h.ctypes.data_as(C.c_void_p), _ptr(pts)))
+        return pts
+
+    def frontend_pairs_pose(self, bgr, pairs, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, K, ids=None, thr_sq=4.0,
+                            kp_stride=None, out=None):
+        """frontend_pairs + extract_Rt + triangulate + reprojection filter in one call (vslam_frontend_pairs_pose)."""
+        import numpy as np
+        torch = self.torch
+        F, H, W, _ = bgr.shape
+        assert F == 2 * pairs
+        Kp = kp_stride or max_corners
+        dev = bgr.device
+        if out is None:
+            out = dict(xy=torch.zeros((F, Kp, 2), dtype=torch.float32, device=dev),
+                       desc=torch.zeros((F, Kp, 32), dtype=torch.uint8, device=dev),
+                       nodes=torch.full((F, Kp), -1, dtype=torch.int32, device=dev),
+                       n=torch.zeros((F,), dtype=torch.int32, device=dev),
+                       matches=torch.zeros((pairs, Kp, 2), dtype=torch.int32, device=dev),
+                       best=torch.zeros((pairs, 4), dtype=torch.int32, device=dev),
+                       F=torch.zeros((pairs, 9), dtype=torch.float32, device=dev),
+                       R=torch.zeros((pairs, 9), dtype=torch.float32, device=dev),
+                       t=torch.zeros((pairs, 3), dtype=torch.float32, device=dev),
+                       c2=torch.zeros((pairs, 12), dtype=torch.float32, device=dev),
+                       points4d=torch.zeros((pairs, Kp, 4), dtype=torch.float32, device=dev),
+                       inlier_idx=torch.zeros((pairs, Kp), dtype=torch.int32, device=dev),
+                       n_inliers=torch.zeros((pairs,), dtype=torch.int32, device=dev),
+                       error=torch.zeros((pairs,), dtype=torch.float64, device=dev))
+            self._ready()
+        p = self._params(max_corners, cos_a, sin_a, pattern)
+        po = PoseOutputs(*(C.c_void_p(out[k].data_ptr()) for k in ("R", "t", "c2", "points4d", "inlier_idx", "n_inliers", "error")))
+        Kh = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        self._check(self.lib.vslam_frontend_pairs_pose(
+            self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(Kp),
+            _ptr(seeds), C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out["nodes"]),
+            _ptr(out["n"]), _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"]), Kh.ctypes.data_as(C.c_void_p), _ptr(ids),
+            C.c_float(thr_sq), C.byref(po)))
         return out
 
     def pack_records(self, F, best, matches, out=None):

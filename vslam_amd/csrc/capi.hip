@@ -682,6 +682,13 @@ int vslam_extract_features_grid(vslam_ctx *ctx, uint8_t *d_bgr, int frames, int 
                                   d_xy, d_desc, d_angle_octave, d_n);
 }
 
+// triangulate(p1, p2, c1, c2, points_4d), src/helpers.cpp:37-80, as declared (any camera matrices, n point pairs)
+int vslam_triangulate_points(vslam_ctx *ctx, const float *d_p1, const float *d_p2, int n, const float *h_c1,
+                             const float *h_c2, float *d_points4d) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    return vs_launch_triangulate_points(ctx, d_p1, d_p2, n, h_c1, h_c2, d_points4d);
+}
+
 // extract_Rt + camera matrix, src/helpers.cpp:3-35, src/vslam.cpp:83-85,125
 int vslam_extract_Rt(vslam_ctx *ctx, const float *d_F, const int32_t *d_best, int batch, const float *h_K, float *d_R,
                      float *d_t, float *d_c2) {
@@ -817,6 +824,33 @@ int vslam_frontend_pairs(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int wi
     if (rc == VSLAM_OK && overlap && ctx->aux_job) rc = vs_aux_job_point(ctx, ctx->aux_job_at);
     if (overlap) VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return rc;
+}
+
+// extract + match + RANSAC + extract_Rt + triangulate + reprojection filter, src/vslam.cpp:60-88,120-125,186-251
+int vslam_frontend_pairs_pose(vslam_ctx *ctx, const uint8_t *d_bgr, int pairs, int width, int height, int row_stride,
+                              const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                              float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                              int32_t *d_matches, int32_t *d_best, float *d_F, const float *h_K,
+                              const int32_t *d_map_point_ids, float reproj_threshold_sq, const vslam_pose_outputs *pose) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VS_REQUIRE(ctx, h_K && pose, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, pose->d_R && pose->d_t && pose->d_c2 && pose->d_points4d && pose->d_inlier_idx && pose->d_n_inliers && pose->d_error,
+               VSLAM_ERR_INVALID);
+    int rc = vslam_frontend_pairs(ctx, d_bgr, pairs, width, height, row_stride, params, kp_stride, d_seeds, hyp, threshold, d_xy,
+                                  d_desc, d_nodes, d_n, d_matches, d_best, d_F);
+    if (rc) return rc;
+    const size_t half = (size_t)pairs * kp_stride;
+    const float *xy1 = d_xy, *xy2 = d_xy + 2 * half;
+    if (!d_map_point_ids) {   // nothing assigned yet: -1 everywhere (all bits set)
+        int32_t *ids = nullptr;
+        if ((rc = vs_arena_get(ctx, "pose.no_ids", sizeof(int32_t) * half, (void **)&ids))) return rc;
+        VS_HIP(ctx, hipMemsetAsync(ids, 0xFF, sizeof(int32_t) * half, ctx->stream));
+        d_map_point_ids = ids;
+    }
+    if ((rc = vs_launch_extract_Rt(ctx, d_F, d_best, pairs, h_K, pose->d_R, pose->d_t, pose->d_c2))) return rc;
+    if ((rc = vs_launch_triangulate(ctx, xy1, xy2, d_matches, d_best, pairs, kp_stride, h_K, pose->d_c2, pose->d_points4d))) return rc;
+    return vs_launch_reproj_filter(ctx, pose->d_points4d, xy1, xy2, d_matches, d_best, pairs, kp_stride, h_K, pose->d_c2,
+                                   d_map_point_ids, reproj_threshold_sq, pose->d_inlier_idx, pose->d_n_inliers, pose->d_error);
 }
 
 // result records for the gather of the sharded path

@@ -256,6 +256,8 @@ int vs_launch_extract_Rt(vslam_ctx *ctx, const float *F, const int32_t *best, in
 int vs_launch_triangulate(vslam_ctx *ctx, const float *xy1, const float *xy2, const int32_t *matches,
                           const int32_t *best, int batch, int kp_stride, const float *h_K, const float *c2,
                           float *points4d);
+int vs_launch_triangulate_points(vslam_ctx *ctx, const float *p1, const float *p2, int n, const float *h_c1, const float *h_c2,
+                                 float *points4d);
 int vs_launch_associate(vslam_ctx *ctx, const float *map_points, const int32_t *n_map, int batch, int map_stride,
                         const float *c2, int img_w, int img_h, const int32_t *nodes, const float *xy, const uint8_t *desc,
                         const int32_t *n_kp, int kp_stride, const int32_t *obs_offsets, const uint8_t *obs_desc,

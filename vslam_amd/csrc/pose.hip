@@ -268,6 +268,28 @@ __global__ __launch_bounds__(64) void pose_from_F_kernel(const float *__restrict
     for (int i = 0; i < 12; i++) c2_out[(size_t)b * 12 + i] = c2[i];
 }
 
+// one point of triangulate() (src/helpers.cpp:48-76): the 4 x 4 system from the two image points and camera matrices, its
+// SVD, the last row of V^T de-homogenised
+__device__ __forceinline__ float4 triangulate_one(float2 p1, float2 p2, const float *c1, const float *c2) {
+    float A[16];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {   // s*row - row in float: fl(fl(a*s) - b)
+        const float a0 = p1.x * c1[8 + c], a1 = p1.y * c1[8 + c], a2 = p2.x * c2[8 + c], a3 = p2.y * c2[8 + c];
+        A[0 + c] = a0 - c1[0 + c];
+        A[4 + c] = a1 - c1[4 + c];
+        A[8 + c] = a2 - c2[0 + c];
+        A[12 + c] = a3 - c2[4 + c];
+    }
+    float D[4], U[16], Vt[16];
+    svd_square<4>(A, D, U, Vt);
+    float4 o;
+    o.x = Vt[12] / Vt[15];
+    o.y = Vt[13] / Vt[15];
+    o.z = Vt[14] / Vt[15];
+    o.w = 1.f;
+    return o;
+}
+
 __global__ __launch_bounds__(128) void triangulate_kernel(const float *__restrict__ xy1, const float *__restrict__ xy2,
                                                           const int32_t *__restrict__ matches,
                                                           const int32_t *__restrict__ best, int kp_stride, Mat3 Kc,
@@ -289,23 +311,26 @@ __global__ __launch_bounds__(128) void triangulate_kernel(const float *__restric
     }
 #pragma unroll
     for (int k = 0; k < 12; k++) c2[k] = c2_all[(size_t)b * 12 + k];
-    float A[16];
+    reinterpret_cast<float4 *>(points4d)[(size_t)b * kp_stride + i] = triangulate_one(p1, p2, c1, c2);
+}
+
+// triangulate(p1, p2, c1, c2, points_4d) as the reference declares it (include/helpers.h:19): n point pairs, any two 3 x 4
+// camera matrices
+struct Mat34 {
+    float v[12];
+};
+__global__ __launch_bounds__(128) void triangulate_points_kernel(const float *__restrict__ p1, const float *__restrict__ p2, int n,
+                                                                 Mat34 C1, Mat34 C2, float *__restrict__ points4d) {
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) return;
+    float c1[12], c2[12];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {   // s*row - row in float: fl(fl(a*s) - b)
-        const float a0 = p1.x * c1[8 + c], a1 = p1.y * c1[8 + c], a2 = p2.x * c2[8 + c], a3 = p2.y * c2[8 + c];
-        A[0 + c] = a0 - c1[0 + c];
-        A[4 + c] = a1 - c1[4 + c];
-        A[8 + c] = a2 - c2[0 + c];
-        A[12 + c] = a3 - c2[4 + c];
+    for (int k = 0; k < 12; k++) {
+        c1[k] = C1.v[k];
+        c2[k] = C2.v[k];
     }
-    float D[4], U[16], Vt[16];
-    svd_square<4>(A, D, U, Vt);
-    float4 o;
-    o.x = Vt[12] / Vt[15];
-    o.y = Vt[13] / Vt[15];
-    o.z = Vt[14] / Vt[15];
-    o.w = 1.f;
-    reinterpret_cast<float4 *>(points4d)[(size_t)b * kp_stride + i] = o;
+    reinterpret_cast<float4 *>(points4d)[i] =
+        triangulate_one(reinterpret_cast<const float2 *>(p1)[i], reinterpret_cast<const float2 *>(p2)[i], c1, c2);
 }
 
 // Reprojection-error filter of src/vslam.cpp:192-251, bug for bug (see oracle/vso_pose.cpp): one workgroup per pair.
@@ -450,6 +475,22 @@ int vs_launch_triangulate(vslam_ctx *ctx, const float *xy1, const float *xy2, co
     VsProfScope ps(ctx, "triangulate_kernel");
     triangulate_kernel<<<dim3(vs_div_up(kp_stride, 128), batch), 128, 0, ctx->stream>>>(xy1, xy2, matches, best, kp_stride, K,
                                                                                         c2, points4d);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_triangulate_points(vslam_ctx *ctx, const float *p1, const float *p2, int n, const float *h_c1, const float *h_c2,
+                                 float *points4d) {
+    VS_REQUIRE(ctx, p1 && p2 && h_c1 && h_c2 && points4d, VSLAM_ERR_INVALID);
+    VS_REQUIRE(ctx, n >= 0, VSLAM_ERR_INVALID);
+    if (n == 0) return VSLAM_OK;
+    Mat34 C1, C2;
+    for (int i = 0; i < 12; i++) {
+        C1.v[i] = h_c1[i];
+        C2.v[i] = h_c2[i];
+    }
+    VsProfScope ps(ctx, "triangulate_kernel");
+    triangulate_points_kernel<<<vs_div_up(n, 128), 128, 0, ctx->stream>>>(p1, p2, n, C1, C2, points4d);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
 }

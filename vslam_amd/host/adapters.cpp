@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/vslam/Frame.h"
+#include "../../include/vslam/helpers.h"
 #ifdef VSLAM_HAVE_OPENCV
 #include <opencv2/imgproc.hpp>
 #endif
@@ -965,3 +966,108 @@ void match_features(const Frame &frame1, const Frame &frame2, RansacFilter &rf,
     const int32_t *kept = c.hout<int32_t>(o_kept);
     for (int i = 0; i < best[3]; i++) matches.emplace_back(kept[2 * i], kept[2 * i + 1]);   // appended, not cleared (:98-102)
 }
+
+// ------------------------------------------------------------------------------------ helpers.h
+namespace {
+// a 32-bit float matrix of the given shape, row by row into `dst` (rows may be padded: cv::Mat::step)
+void read_f32(const cv::Mat &m, int rows, int cols, float *dst, const char *what) {
+    if (m.empty() || m.rows != rows || m.cols != cols || m.depth() != CV_32F || m.channels() != 1)
+        throw std::invalid_argument(std::string("vslam_amd: ") + what + " must be a " + std::to_string(rows) + " x " +
+                                    std::to_string(cols) + " CV_32F matrix");
+    for (int r = 0; r < rows; r++) std::memcpy(dst + (size_t)r * cols, m.ptr<float>(r), sizeof(float) * (size_t)cols);
+}
+}  // namespace
+
+// reference: src/helpers.cpp:3-35
+void extract_Rt(const cv::Mat &fundamental, const cv::Mat &K, cv::Mat &rotation, cv::Mat &translation) {
+    Lock lk(g_mu);
+    float Kh[9];
+    read_f32(K, 3, 3, Kh, "K");
+    Layout in, out, work;
+    const size_t o_F = in.add(sizeof(float) * 9);
+    const size_t o_R = out.add(sizeof(float) * 9), o_t = out.add(sizeof(float) * 3), o_c2 = out.add(sizeof(float) * 12);
+    Call c(in, out, work);
+    read_f32(fundamental, 3, 3, c.hin<float>(o_F), "fundamental");
+    c.upload();
+    check(vslam_extract_Rt(ctx(), c.din<float>(o_F), nullptr, 1, Kh, c.dout<float>(o_R), c.dout<float>(o_t), c.dout<float>(o_c2)),
+          "extract_Rt");
+    c.download();
+    rotation.create(3, 3, CV_32FC1);
+    translation.create(3, 1, CV_32FC1);
+    for (int r = 0; r < 3; r++) {
+        std::memcpy(rotation.ptr<float>(r), c.hout<float>(o_R) + 3 * r, sizeof(float) * 3);
+        translation.ptr<float>(r)[0] = c.hout<float>(o_t)[r];
+    }
+}
+
+// reference: src/helpers.cpp:37-80
+void triangulate(const cv::Mat &p1, const cv::Mat &p2, const cv::Mat &c1, const cv::Mat &c2, cv::Mat &points_4d) {
+    Lock lk(g_mu);
+    float c1h[12], c2h[12];
+    read_f32(c1, 3, 4, c1h, "c1");
+    read_f32(c2, 3, 4, c2h, "c2");
+    const int n = p1.rows;
+    points_4d.create(n, 4, CV_32FC1);   // points_4d = cv::Mat(N, 4, CV_32F), :41
+    if (n == 0) return;
+    Layout in, out, work;
+    const size_t o_p1 = in.add(sizeof(float) * 2 * (size_t)n), o_p2 = in.add(sizeof(float) * 2 * (size_t)n);
+    const size_t o_pts = out.add(sizeof(float) * 4 * (size_t)n);
+    Call c(in, out, work);
+    read_f32(p1, n, 2, c.hin<float>(o_p1), "p1");
+    read_f32(p2, n, 2, c.hin<float>(o_p2), "p2");
+    c.upload();
+    check(vslam_triangulate_points(ctx(), c.din<float>(o_p1), c.din<float>(o_p2), n, c1h, c2h, c.dout<float>(o_pts)),
+          "triangulate_points");
+    c.download();
+    for (int r = 0; r < n; r++) std::memcpy(points_4d.ptr<float>(r), c.hout<float>(o_pts) + 4 * (size_t)r, sizeof(float) * 4);
+}
+
+namespace vslam {
+// reference: src/vslam.cpp:129-161, src/PointMap.cpp:36-46
+std::vector<s32> associate_map_points(Frame &frame, const cv::Mat &map_points, const cv::Mat &c2, int W, int H,
+                                      const std::vector<u32> &obs_offsets, const cv::Mat &obs_desc, float radius,
+                                      u32 dist_threshold) {
+    const int n_map = map_points.rows;
+    std::vector<s32> claim((size_t)n_map, -1);
+    const int n_kp = (int)frame.points.size();
+    if (n_map == 0 || n_kp == 0 || frame.kdtree.root == nullptr) return claim;
+    if (obs_offsets.size() != (size_t)n_map + 1)
+        throw std::invalid_argument("vslam_amd: obs_offsets needs one entry per map point plus one");
+    if (frame.map_point_ids.size() < (size_t)n_kp || frame.descriptors.rows < n_kp || frame.descriptors.cols != VSLAM_DESC_BYTES)
+        throw std::invalid_argument("vslam_amd: frame.map_point_ids / frame.descriptors do not cover frame.points");
+    const int n_obs = (int)obs_offsets.back();
+    if (obs_desc.rows < n_obs || (n_obs > 0 && obs_desc.cols != VSLAM_DESC_BYTES))
+        throw std::invalid_argument("vslam_amd: obs_desc does not hold the rows obs_offsets names");
+    Lock lk(g_mu);
+    auto t = device_tree_for(frame.kdtree, frame.points);
+    const int kp_stride = t->stride, obs_stride = n_obs > 0 ? n_obs : 1;
+    float c2h[12];
+    read_f32(c2, 3, 4, c2h, "c2");
+    Layout in, out, work;
+    const size_t o_nmap = in.add(4), o_mp = in.add(sizeof(float) * 4 * (size_t)n_map), o_c2 = in.add(sizeof(float) * 12);
+    const size_t o_desc = in.add((size_t)kp_stride * VSLAM_DESC_BYTES), o_off = in.add(4 * ((size_t)n_map + 1));
+    const size_t o_obs = in.add((size_t)obs_stride * VSLAM_DESC_BYTES), o_ids_in = in.add(4 * (size_t)kp_stride);
+    const size_t o_claim = out.add(4 * (size_t)n_map);
+    Call c(in, out, work);
+    *c.hin<int32_t>(o_nmap) = n_map;
+    read_f32(map_points, n_map, 4, c.hin<float>(o_mp), "map_points");
+    std::memcpy(c.hin<float>(o_c2), c2h, sizeof(c2h));
+    for (int r = 0; r < n_kp; r++) std::memcpy(c.hin<uint8_t>(o_desc) + (size_t)r * VSLAM_DESC_BYTES, frame.descriptors.ptr<uint8_t>(r), VSLAM_DESC_BYTES);
+    for (int i = 0; i <= n_map; i++) c.hin<int32_t>(o_off)[i] = (int32_t)obs_offsets[(size_t)i];
+    for (int r = 0; r < n_obs; r++) std::memcpy(c.hin<uint8_t>(o_obs) + (size_t)r * VSLAM_DESC_BYTES, obs_desc.ptr<uint8_t>(r), VSLAM_DESC_BYTES);
+    for (int i = 0; i < kp_stride; i++) c.hin<int32_t>(o_ids_in)[i] = i < n_kp ? frame.map_point_ids[(size_t)i] : 0;
+    c.upload();
+    // map_point_ids is in/out: the kernel updates the uploaded copy in place, which then comes back by itself
+    check(vslam_associate_map_points(ctx(), c.din<float>(o_mp), c.din<int32_t>(o_nmap), 1, n_map, c.din<float>(o_c2), W, H, t->nodes,
+                                     t->xy, c.din<uint8_t>(o_desc), t->n, kp_stride, c.din<int32_t>(o_off), c.din<uint8_t>(o_obs),
+                                     obs_stride, radius, dist_threshold, c.din<int32_t>(o_ids_in), c.dout<int32_t>(o_claim)),
+          "associate_map_points");
+    c.download();
+    if (c.din<int32_t>(o_ids_in) != c.hin<int32_t>(o_ids_in))   // (a small call runs on the page-locked staging memory itself)
+        check(vslam_copy_d2h(ctx(), c.hin<int32_t>(o_ids_in), c.din<int32_t>(o_ids_in), 4 * (size_t)kp_stride), "copy_d2h");
+    check(vslam_ctx_synchronize(ctx()), "associate_map_points (more than 16 acceptable hits for one map point)");
+    for (int i = 0; i < n_kp; i++) frame.map_point_ids[(size_t)i] = c.hin<int32_t>(o_ids_in)[i];
+    for (int i = 0; i < n_map; i++) claim[(size_t)i] = c.hout<int32_t>(o_claim)[i];
+    return claim;
+}
+}  // namespace vslam
