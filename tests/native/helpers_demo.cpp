@@ -101,7 +101,7 @@ int main(int argc, char **argv) {
     }
     cv::Mat obs_desc((int)(obs.size() / 32), 32, CV_8UC1, obs.data());
     const std::vector<s32> ids_before = cur.map_point_ids;
-    const std::vector<s32> claim = vslam::associate_map_points(cur, points_4d, c2, w, h, offs, obs_desc, 2.f, 64);
+    const std::vector<s32> claim = vslam::associate_map_points(cur, points_4d, c2, w, h, offs, obs_desc, 6.f, 64);   // (a wider radius than the loop's 2: more of this synthetic pair's points find a keypoint)
     if ((int)claim.size() != n) return 7;
 
     // print_matrix goes to stdout in OpenCV's default format

@@ -91,7 +91,8 @@ def test_full_size_property_self_match(mctx):
     assert torch.equal(pairs[:, :, 1], inv)
 
 
-def test_extreme_distances_and_index_range(ctx, oracle, shape):
+def test_extreme_distances_and_index_range(mctx, oracle):
+    ctx = mctx
     """Distances 0, 1, 255 and 256 (the +-1 products of the FP4 form then sum to +-256, where the key arithmetic changes
     sign), all-zero and all-one descriptors, and train indices up to the largest a key can carry at this stride."""
     rng = np.random.default_rng(77)
