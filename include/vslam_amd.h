@@ -440,6 +440,12 @@ int vslam_pipeline_submit_sequence(vslam_pipeline *p, const uint8_t *d_bgr, int 
 int vslam_pipeline_poll(vslam_pipeline *p, int64_t ticket);
 int vslam_pipeline_wait(vslam_pipeline *p, int64_t ticket);
 int vslam_pipeline_drain(vslam_pipeline *p);
+/* Batches that vslam_pipeline_submit_pairs / _sequence queued and the pipeline then queued a SECOND time by itself: a batch in
+ * which more frames needed the corner detector's whole-image fallback than its pool holds (VSLAM_OPT_CORNER_LIST_CAP; pure
+ * noise, response plateaus) is done again, when its status is collected, with every list sized for the whole image; its
+ * outputs are then complete and the ticket reports VSLAM_OK.  (A ticket built with acquire / commit cannot be queued again --
+ * the pipeline does not know what was enqueued -- and reports VSLAM_ERR_CAPACITY as before.)                                */
+int64_t vslam_pipeline_batches_redone(vslam_pipeline *p);
 
 /* ------------------------------------------------------------ several devices
  * Frame pairs are independent (src/RansacFilter.cpp:38: all state is per call), so a batch shards by contiguous slices,

@@ -161,8 +161,10 @@ def test_drain_reports_the_first_uncollected_failure():
     try:
         pipe.set_option(capi.Context.OPT_CORNER_LIST_CAP, 40)
         outs = [capi.Pipeline.alloc_outputs(torch, 8, 4, maxc, bgr.device) for _ in range(2)]
-        pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[0])
-        pipe.submit_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, outs[1])
+        for o_ in outs:   # tickets built by hand: the pipeline cannot queue these again, their overflow is reported
+            t_, c_ = pipe.acquire()
+            c_.frontend_pairs(bgr, 4, maxc, ca, sa, None, seeds, HYP, THR, out=o_)
+            pipe.commit(t_)
         with pytest.raises(capi.VslamError, match=r"CAPACITY: ticket 0: .*\+1 more"):
             pipe.drain()
         pipe.drain()
@@ -241,3 +243,44 @@ def test_the_cpp_example_runs(tmp_path):
     assert "21 records" in r.stdout
     first = [ln for ln in r.stdout.splitlines() if ln.startswith("pair 0:")]
     assert first and "hypothesis -1" not in first[0], r.stdout       # the shifted scene gives a model
+
+
+def test_submitted_batch_that_exhausts_the_corner_pool_is_done_again(oracle):
+    """More frames of one batch need the corner detector's whole-image fallback than its pool holds (here: pure noise, every
+    frame): a batch that came through submit_pairs is queued once more with whole-image lists when its status is collected,
+    reports VSLAM_OK, and its outputs are those of an unbounded run -- and of the oracle."""
+    w, h, maxc, P = 320, 240, 200, 12
+    ca, sa = synth.keypoint_rotation()
+    rng = np.random.default_rng(11)
+    bgr_np = rng.integers(0, 256, (2 * P, h, w, 3), dtype=np.uint8)
+    bgr = torch.from_numpy(bgr_np).cuda()
+    seeds_np = np.arange(P, dtype=np.int32) + 77
+    seeds = torch.from_numpy(seeds_np).cuda()
+    pipe = capi.Pipeline(0, 2)
+    try:
+        out = capi.Pipeline.alloc_outputs(torch, 2 * P, P, maxc, bgr.device)
+        ref = capi.Pipeline.alloc_outputs(torch, 2 * P, P, maxc, bgr.device)
+        torch.cuda.synchronize()
+        pipe.set_option(capi.Context.OPT_CORNER_LIST_CAP, 40)   # (the test knob: lists of 40 entries, so every frame of this small batch overflows)
+        t = pipe.submit_pairs(bgr, P, maxc, ca, sa, None, seeds, HYP, THR, out)
+        assert pipe.wait_status(t)[0] == 0
+        assert pipe.batches_redone() == 1
+        pipe.set_option(capi.Context.OPT_CORNER_LIST_CAP, 0)
+        # the same batch with nothing bounded, by hand
+        t2, c2 = pipe.acquire()
+        c2.set_option(c2.OPT_CORNER_LIST_CAP, -1)
+        c2.frontend_pairs(bgr, P, maxc, ca, sa, None, seeds, HYP, THR, out=ref)
+        c2.set_option(c2.OPT_CORNER_LIST_CAP, 0)
+        pipe.commit(t2)
+        assert pipe.wait_status(t2)[0] == 0 and pipe.batches_redone() == 1
+        o = {k: v.cpu().numpy() for k, v in out.items()}
+        r = {k: v.cpu().numpy() for k, v in ref.items()}
+        for k in ("n", "xy", "desc", "nodes", "best", "matches"):
+            assert np.array_equal(o[k], r[k]), k
+        assert np.array_equal(o["F"].view(np.uint32), r["F"].view(np.uint32))
+        assert (o["n"] > 50).all()            # every frame has its corners: none came back empty
+        pat = synth.brief_pattern()
+        a = oracle.extract_features(bgr_np[0], maxc, ca, sa, pat)
+        assert o["n"][0] == a["n"] and np.array_equal(o["xy"][0, :a["n"]], a["xy"]) and np.array_equal(o["desc"][0, :a["n"]], a["desc"])
+    finally:
+        pipe.close()

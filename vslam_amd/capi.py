@@ -25,7 +25,7 @@ SYMBOLS = [
     "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
-    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_kdtree_cell_table", "vslam_extract_features", "vslam_extract_features_grid", "vslam_triangulate_points", "vslam_frontend_pairs_pose", "vslam_bgr2gray", "vslam_min_eigen",
+    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_kdtree_cell_table", "vslam_extract_features", "vslam_extract_features_grid", "vslam_triangulate_points", "vslam_frontend_pairs_pose", "vslam_pipeline_batches_redone", "vslam_bgr2gray", "vslam_min_eigen",
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points", "vslam_reprojection_filter",
     "vslam_match_features",
     "vslam_frontend_pairs", "vslam_frontend_sequence", "vslam_pack_records",
@@ -714,6 +714,11 @@ class Pipeline:
         """(rc, message) instead of raising."""
         rc = self.lib.vslam_pipeline_wait(self.handle, C.c_int64(ticket))
         return rc, (self.lib.vslam_pipeline_last_error(self.handle).decode() if rc else "")
+
+    def batches_redone(self):
+        """Batches submit_pairs / submit_sequence queued that the pipeline queued a second time with whole-image corner lists."""
+        self.lib.vslam_pipeline_batches_redone.restype = C.c_int64
+        return int(self.lib.vslam_pipeline_batches_redone(self.handle))
 
     def drain(self):
         self._check(self.lib.vslam_pipeline_drain(self.handle))

@@ -19,6 +19,20 @@
 #include <mutex>
 
 namespace {
+// what vslam_pipeline_submit_pairs / _sequence queued for a ticket: enough to queue it again (the caller's buffers stay valid
+// until the ticket has been waited for)
+struct Submitted {
+    int kind = 0;   // 0: nothing recorded (a ticket built with acquire / commit), 1: pairs, 2: sequence
+    const uint8_t *d_bgr = nullptr;
+    int count = 0, width = 0, height = 0, row_stride = 0, kp_stride = 0, hyp = 0;
+    vslam_extract_params params{};
+    const uint32_t *d_seeds = nullptr;
+    float threshold = 0.f;
+    float *d_xy = nullptr;
+    uint8_t *d_desc = nullptr;
+    int32_t *d_nodes = nullptr, *d_n = nullptr, *d_matches = nullptr, *d_best = nullptr, *d_records = nullptr;
+    float *d_F = nullptr;
+};
 struct Slot {
     vslam_ctx *ctx = nullptr;
     hipEvent_t done = nullptr;
@@ -26,6 +40,7 @@ struct Slot {
     int32_t *d_flag = nullptr;
     int64_t ticket = -1;         // batch in flight on this slot (committed, not yet retired); -1: none
     bool open = false;           // acquired, not yet committed
+    Submitted sub;               // of the batch in flight, when it came through submit_*
 };
 struct Failure {
     int64_t ticket;
@@ -38,6 +53,7 @@ struct vslam_pipeline {
     int device = 0;
     std::vector<Slot> slots;
     int64_t next_ticket = 0;
+    int64_t redone = 0;             // batches queued a second time with whole-image corner lists (see retire)
     std::deque<Failure> failures;   // retired batches that failed and have not been asked about yet (bounded)
     std::string err;
     std::mutex mu;
@@ -62,12 +78,52 @@ int retire(vslam_pipeline *p, Slot &s) {
     } else if (*s.h_flag) {
         rc = VSLAM_ERR_CAPACITY;
         err = vs_errflag_message(*s.h_flag);
+        // The one overflow a well-formed batch can meet: more of its frames needed the corner detector's whole-image fallback
+        // than the pool holds (plateaus, pure noise), and those frames came back without corners.  A batch that came through
+        // submit_* is queued ONCE more, here, with every list sized for the whole image (VSLAM_OPT_CORNER_LIST_CAP = -1: nothing
+        // can overflow; 16 bytes per pixel and frame of workspace for this context from now on) -- its outputs are then what
+        // an unbounded run gives, in the caller's same buffers -- and only what that second run reports is filed.  (The context
+        // is idle at this point: its only batch in flight has just completed.)
+        if ((*s.h_flag & 4) && s.sub.kind != 0 && s.ctx->corner_list_cap != -1) {
+            const Submitted &q = s.sub;
+            const int cap = s.ctx->corner_list_cap;
+            s.ctx->corner_list_cap = -1;
+            int rc2 = q.kind == 1 ? vslam_frontend_pairs(s.ctx, q.d_bgr, q.count, q.width, q.height, q.row_stride, &q.params, q.kp_stride,
+                                                          q.d_seeds, q.hyp, q.threshold, q.d_xy, q.d_desc, q.d_nodes, q.d_n, q.d_matches,
+                                                          q.d_best, q.d_F)
+                                  : vslam_frontend_sequence(s.ctx, q.d_bgr, q.count, q.width, q.height, q.row_stride, &q.params,
+                                                            q.kp_stride, q.d_seeds, q.hyp, q.threshold, q.d_xy, q.d_desc, q.d_nodes, q.d_n,
+                                                            q.d_matches, q.d_best, q.d_F);
+            if (rc2 == VSLAM_OK && q.d_records)
+                rc2 = vslam_pack_records(s.ctx, q.d_F, q.d_best, q.d_matches, q.kind == 1 ? q.count : q.count - 1, q.kp_stride, q.d_records);
+            if (rc2 == VSLAM_OK) rc2 = vslam_ctx_synchronize(s.ctx);   // waits, reads and clears the word: the context is this slot's alone
+            else (void)vslam_ctx_wait(s.ctx);
+            s.ctx->corner_list_cap = cap;
+            p->redone++;
+            if (rc2 == VSLAM_OK) {
+                rc = VSLAM_OK;
+            } else {
+                rc = rc2;
+                err = std::string("queued again with whole-image corner lists: ") + vslam_last_error(s.ctx);
+            }
+        }
     }
+    s.sub.kind = 0;
     if (rc != VSLAM_OK) {
         if (p->failures.size() >= kMaxFailures) p->failures.pop_front();
         p->failures.push_back({t, rc, err});
     }
     return VSLAM_OK;
+}
+
+void remember(vslam_pipeline *p, int64_t ticket, int kind, const uint8_t *d_bgr, int count, int width, int height, int row_stride,
+              const vslam_extract_params &params, int kp_stride, const uint32_t *d_seeds, int hyp, float threshold, float *d_xy,
+              uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n, int32_t *d_matches, int32_t *d_best, float *d_F, int32_t *d_records) {
+    Submitted &q = p->slots[(size_t)(ticket % (int64_t)p->slots.size())].sub;
+    q.kind = kind; q.d_bgr = d_bgr; q.count = count; q.width = width; q.height = height; q.row_stride = row_stride;
+    q.params = params; q.kp_stride = kp_stride; q.d_seeds = d_seeds; q.hyp = hyp; q.threshold = threshold;
+    q.d_xy = d_xy; q.d_desc = d_desc; q.d_nodes = d_nodes; q.d_n = d_n; q.d_matches = d_matches; q.d_best = d_best; q.d_F = d_F;
+    q.d_records = d_records;
 }
 
 int acquire_locked(vslam_pipeline *p, vslam_ctx **ctx_out, int64_t *ticket_out) {
@@ -83,6 +139,7 @@ int acquire_locked(vslam_pipeline *p, vslam_ctx **ctx_out, int64_t *ticket_out) 
     }
     retire(p, s);
     s.open = true;
+    s.sub.kind = 0;
     *ctx_out = s.ctx;
     *ticket_out = p->next_ticket++;
     return VSLAM_OK;
@@ -210,6 +267,9 @@ int vslam_pipeline_submit_pairs(vslam_pipeline *p, const uint8_t *d_bgr, int pai
     rc = vslam_frontend_pairs(c, d_bgr, pairs, width, height, row_stride, params, kp_stride, d_seeds, hyp, threshold, d_xy,
                               d_desc, d_nodes, d_n, d_matches, d_best, d_F);
     if (rc == VSLAM_OK && d_records) rc = vslam_pack_records(c, d_F, d_best, d_matches, pairs, kp_stride, d_records);
+    if (rc == VSLAM_OK && params)
+        remember(p, t, 1, d_bgr, pairs, width, height, row_stride, *params, kp_stride, d_seeds, hyp, threshold, d_xy, d_desc, d_nodes, d_n,
+                 d_matches, d_best, d_F, d_records);
     // close the batch either way: whatever part of it was queued has to be waited for before the slot is used again (the
     // caller has the error in hand: it is not filed under the ticket as well)
     const int crc = commit_locked(p, t);
@@ -236,6 +296,9 @@ int vslam_pipeline_submit_sequence(vslam_pipeline *p, const uint8_t *d_bgr, int 
     rc = vslam_frontend_sequence(c, d_bgr, frames, width, height, row_stride, params, kp_stride, d_seeds, hyp, threshold, d_xy,
                                  d_desc, d_nodes, d_n, d_matches, d_best, d_F);
     if (rc == VSLAM_OK && d_records) rc = vslam_pack_records(c, d_F, d_best, d_matches, frames - 1, kp_stride, d_records);
+    if (rc == VSLAM_OK && params)
+        remember(p, t, 2, d_bgr, frames, width, height, row_stride, *params, kp_stride, d_seeds, hyp, threshold, d_xy, d_desc, d_nodes, d_n,
+                 d_matches, d_best, d_F, d_records);
     const int crc = commit_locked(p, t);
     if (rc) {
         p->err = std::string("ticket ") + std::to_string(t) + ": " + vslam_last_error(c);
@@ -278,6 +341,12 @@ int vslam_pipeline_wait(vslam_pipeline *p, int64_t ticket) {
     p->err = "ticket " + std::to_string(ticket) + ": " + it->err;
     p->failures.erase(it);
     return rc;
+}
+
+int64_t vslam_pipeline_batches_redone(vslam_pipeline *p) {
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return p->redone;
 }
 
 int vslam_pipeline_drain(vslam_pipeline *p) {
