@@ -362,7 +362,7 @@ def grid_workload(args):
     n_slots = max(1, min(16, args.in_flight))
     pipe = Pipeline(0, n_slots)
     ctx = pipe.contexts[0]
-    make_frames = synth.frames_torch if args.data == "easy" else synth.frames_torch_hard
+    make_frames = {"easy": synth.frames_torch, "hard": synth.frames_torch_hard, "photo": synth.frames_torch_photo}[args.data]
     pat = torch.from_numpy(synth.brief_pattern()).to(dev)
 
     class Slot:
@@ -417,7 +417,8 @@ def grid_workload(args):
     n_kp = np.concatenate([sl.host["n"] for sl in used])
     best = np.concatenate([sl.host["best"] for sl in used])
     data_label = {"easy": "easy data: translated texture + one moving block",
-                  "hard": "SURVEY 8(d) data: rotation + parallax, sub-pixel resampling"}[args.data]
+                  "hard": "SURVEY 8(d) data: rotation + parallax, sub-pixel resampling",
+                  "photo": "photographic data: windows of four public-domain photographs under small camera motions"}[args.data]
     result = {
         "metric": "frame-pairs/sec (grid ORB/FAST extract+match+RANSAC) @1280x720, 4x4 cells, 4096 hyp; secondary workload, not BASELINE.json's headline",
         "value": P * args.steps / dt, "unit": "frame-pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -507,10 +508,13 @@ def grid_workload(args):
     return exit_code
 
 
-def self_launch(n_gpus, argv):
+def self_launch(n_gpus, argv, limit_s):
     """--gpus N > 1 without a launcher: start the ranks as a CHILD process tree (never exec: this parent has
     not imported torch or touched the GPU, and it stays alive to relay the result).  Rank 0's JSON line is the
-    only thing the ranks write to stdout."""
+    only thing the ranks write to stdout.  The tree gets a wall-clock limit: a rank stuck in a rendezvous or a
+    collective would otherwise hang the caller; on expiry the whole process group is ended (TERM, then KILL) and
+    the exit code is non-zero with one line of reason on stderr."""
+    import signal
     import socket
     import subprocess
     s = socket.socket()
@@ -521,13 +525,33 @@ def self_launch(n_gpus, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout.splitlines():
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)   # its own process group
+    try:
+        out, _ = proc.communicate(timeout=limit_s)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 5)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            out, _ = proc.communicate(timeout=5)
+        except Exception:
+            out = ""
+        print(f"bench.py: the {n_gpus} ranks did not finish within {limit_s:.0f} s (--launch-timeout): process group ended", file=sys.stderr)
+        rc = 124
+    for line in (out or "").splitlines():
         # the contract is ONE JSON line on stdout; anything else a library printed there (gloo's connection notes)
         # goes to stderr
         print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
     sys.stdout.flush()
-    return proc.returncode
+    return rc
 
 
 def dry_run(args, rank, world):
@@ -543,6 +567,8 @@ def dry_run(args, rank, world):
     from vslam_amd import shard
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
+    if os.environ.get("VSLAM_BENCH_DRY_SLEEP"):   # a rank that hangs (tests/test_bench_launch.py: the launcher's wall-clock limit)
+        time.sleep(float(os.environ["VSLAM_BENCH_DRY_SLEEP"]))
     _, _, K, _, P = WORKLOADS[args.workload]
     P = args.pairs or 4
     lo, hi = shard.shard_range(world * P, rank, world)
@@ -594,9 +620,11 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=150,
                     help="pairs of the timed batches that the oracle recomputes on the host, spread over the contexts: the CPU baseline "
                          "and the in-bench parity check at once (0 = no CPU leg; the parity check then still covers 4 pairs)")
-    ap.add_argument("--data", default="hard", choices=["easy", "hard"],
+    ap.add_argument("--data", default="hard", choices=["easy", "hard", "photo"],
                     help="hard (default since round 5) = SURVEY 8(d)'s regime: rotation + parallax, sub-pixel resampling, 40-45 %% outlier "
-                         "matches (synth.frames_torch_hard); easy = translated texture + one moving block (the headline's data of rounds 1-4)")
+                         "matches (synth.frames_torch_hard); easy = translated texture + one moving block (the headline's data of rounds 1-4); "
+                         "photo = windows of the four public-domain photographs of tests/golden/real_v1.npz under small camera motions "
+                         "(synth.frames_torch_photo): real image statistics, a secondary regime")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (other data regime, full-evaluation worst case, in-flight sweep, C2 / C5)")
     ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
@@ -605,13 +633,19 @@ def main():
     ap.add_argument("--solver", default="exact", choices=["exact", "gram"],
                     help="gram = the opt-in MFMA / normal-matrix 8-point solver (VSLAM_OPT_RANSAC_SOLVER 1): NOT bit-exact, "
                          "never the headline number; the line is labelled")
+    ap.add_argument("--comm", default="per-rank", choices=["per-rank", "per-context"],
+                    help="N > 1: RCCL communicators for the record gather.  per-rank (default): ONE communicator per rank, the gathers of "
+                         "the batches in flight issued on it in ticket order, each on its batch's stream; per-context: one communicator per "
+                         "batch in flight (its collectives can overlap those of the other batches)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("VSLAM_BENCH_LAUNCH_TIMEOUT", "1500")),
+                    help="wall-clock limit in seconds for the ranks this process starts itself (--gpus N > 1 without a launcher)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also run two 1 GiB streaming copies (4 B and 16 B per lane) so FETCH_SIZE/WRITE_SIZE can be calibrated")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: be the launcher (child processes; see self_launch)
-        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
     if os.environ.get("VSLAM_BENCH_DRY"):
         sys.exit(dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))))
     if args.workload == "C3g":
@@ -665,7 +699,8 @@ def main():
     if args.solver == "gram":
         pipe.set_option(capi.Context.OPT_RANSAC_SOLVER, 1)
     ctx = pipe.contexts[0]
-    make_frames = synth.frames_torch if args.data == "easy" else synth.frames_torch_hard
+    FRAME_MAKERS = {"easy": synth.frames_torch, "hard": synth.frames_torch_hard, "photo": synth.frames_torch_photo}
+    make_frames = FRAME_MAKERS[args.data]
     pat = torch.from_numpy(synth.brief_pattern()).to(dev)
     ca, sa = synth.keypoint_rotation()
     lo, hi = shard.shard_range(world * P, rank, world)          # this rank's slice of a global batch
@@ -676,11 +711,16 @@ def main():
     class Slot:
         pass
     slots = []
-    uids = [None] * n_slots
+    n_comms = (1 if args.comm == "per-rank" else n_slots) if gather_mode == "rccl" else 0
+    uids = [None] * n_comms
+    comms = []
     if gather_mode == "rccl":
         if rank == 0:
-            uids = [capi.comm_unique_id() for _ in range(n_slots)]
+            uids = [capi.comm_unique_id() for _ in range(n_comms)]
         dist.broadcast_object_list(uids, src=0)               # 128 bytes per communicator through the torch store
+        # collective: same order on every rank.  per-rank: the one communicator lives on context 0's device state and is
+        # used from every context's stream in turn (RCCL orders the collectives of a communicator in issue order)
+        comms = [capi.Comm(pipe.contexts[i], uids[i], world, rank) for i in range(n_comms)]
     for s in range(n_slots):
         sl = Slot()
         sl.bgr = make_frames(seed + 1000 * rank + 7919 * s, P, w, h, dev)
@@ -689,7 +729,7 @@ def main():
         sl.out = Pipeline.alloc_outputs(torch, 2 * P, P, K, dev)
         sl.rec = torch.zeros((P, words), dtype=torch.int32, device=dev) if multi else None
         sl.gathered = torch.zeros((world * P, words), dtype=torch.int32, device=dev) if multi else None
-        sl.comm = capi.Comm(pipe.contexts[s], uids[s], world, rank) if gather_mode == "rccl" else None   # collective: same order on every rank
+        sl.comm = comms[s % n_comms] if n_comms else None
         sl.used = 0
         slots.append(sl)
     rccl_ranks = slots[0].comm.info()[0] if gather_mode == "rccl" else None
@@ -760,7 +800,7 @@ def main():
         sl.host = {k: sl.out[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
         # (VSLAM_BENCH_ALLOW_DEGENERATE: tools/ab_kernels.py times kernel variants that produce wrong results on purpose)
         assert os.environ.get("VSLAM_BENCH_ALLOW_DEGENERATE") or (
-            (sl.host["best"][:, 0] >= 0).all() and (sl.host["best"][:, 3] >= 8).all() and (sl.host["n"] > K // 2).all()), "bench output degenerate"
+            (sl.host["best"][:, 0] >= 0).all() and (sl.host["best"][:, 3] >= 8).all() and (sl.host["n"] > (K // 2 if args.data != "photo" else K // 8)).all()), "bench output degenerate"
     gather_ok = None
     if multi:   # what the gather delivered: this rank's block of every used context's last gather is this rank's records
         gather_ok = all(torch.equal(sl.gathered[lo:hi], sl.rec) for sl in used)
@@ -781,7 +821,8 @@ def main():
         except OSError:
             pass
         data_label = {"easy": "easy data: translated texture + one moving block, 13 % outlier matches",
-                      "hard": "SURVEY 8(d) data: rotation + parallax, sub-pixel resampling, 40-45 % outlier matches"}[args.data]
+                      "hard": "SURVEY 8(d) data: rotation + parallax, sub-pixel resampling, 40-45 % outlier matches",
+                      "photo": "photographic data: windows of four public-domain photographs, rotation <= 1.5 deg + shift <= 12 px"}[args.data]
         par = f"pairs sharded x{world}; {n_slots} batch{'es' if n_slots > 1 else ''} in flight per GPU (vslam_pipeline_*: {n_slots} context{'s' if n_slots > 1 else ''}, steps round-robin)"
         if multi:
             par += {"rccl": ", vslam_gather_records (RCCL all-gather of result records on each batch's stream)",
@@ -805,7 +846,7 @@ def main():
             result["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms}
         if multi:
             result["record_gather"] = {"through": gather_mode, "rccl_ranks": rccl_ranks, "own_block_intact_on_every_rank": gather_ok,
-                                       "words_per_rank": P * words, "communicators_per_rank": n_slots if gather_mode == "rccl" else 0}
+                                       "words_per_rank": P * words, "communicators_per_rank": n_comms, "comm": args.comm if n_comms else None}
         if args.solver != "exact":
             result["solver"] = "gram-mfma: opt-in approximate 8-point solver, results NOT bit-exact with the reference path"
             result["metric"] += " [NON-PARITY SOLVER]"
@@ -1044,14 +1085,28 @@ def main():
             scoring = ("ransac_rank_kernel", "ransac_screen_kernel", "ransac_cand_kernel", "ransac_count_kernel",
                        "ransac_ties_kernel", "ransac_tiesum_kernel", "ransac_select_kernel", "ransac_score_kernel")
             regimes = {}
-            other = "hard" if args.data == "easy" else "easy"
-            for kind in (args.data, other):
-                frames = s0.bgr if kind == args.data else (synth.frames_torch if kind == "easy" else synth.frames_torch_hard)(seed, P, w, h, dev)
+            for kind in [args.data] + [k_ for k_ in ("hard", "easy", "photo") if k_ != args.data]:
+                frames = s0.bgr if kind == args.data else FRAME_MAKERS[kind](seed, P, w, h, dev)
                 ms, o = timed_single(ctx, frames, P, K, H, s0.seeds)
                 ho = {k: o[k].cpu().numpy() for k in ("best", "n", "F", "matches")}
+                cs = ctx.corner_stats()   # of the batch just run: what only the data decides
                 entry = {"ms_per_step": ms, "frame_pairs_per_s": P / ms * 1e3, "contexts": 1, "mean_keypoints": float(ho["n"].mean()),
                          "mean_inlier_matches": float(ho["best"][:, 3].mean()),
-                         "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring)}
+                         "corner_detector": {"share_of_pixels_sent_to_the_exact_tier": cs["listed_pixels"] / float(cs["frames"] * cs["px_per_frame"]),
+                                             "frames_whose_bounded_list_overflowed_per_batch": cs["frames_overflowed"],
+                                             "whole_image_sets_in_the_pool": cs["pool_sets"], "frames_per_batch": cs["frames"]},
+                         "scoring_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds, scoring),
+                         "front_kernels_ms": kernel_ms(ctx, frames, P, K, H, s0.seeds,
+                                                       ("min_eigen_kernel", "corner_exact_kernel", "corner_select_kernel", "match_knn2_kernel",
+                                                        "ransac_solve_kernel"))}
+                if kind != args.data:   # this regime with batches in flight too, in a process of its own (with its own parity check)
+                    cf = child(["--workload", args.workload, "--pairs", str(P), "--data", kind, "--in-flight", str(n_slots), "--steps", "24",
+                                "--warmup", "4", "--no-profile-pass", "--cpu-pairs", "8"])
+                    if not child_parity_ok(cf):
+                        exit_code = 3
+                    entry["in_flight"] = ({k: v for k, v in cf.items() if k != "line"} if cf.get("failed") else
+                                          {"contexts": n_slots, "ms_per_step": cf["ms_per_step"], "frame_pairs_per_s": cf["value"],
+                                           "parity_in_bench": cf["parity_in_bench"]["bit_exact"], "from": "a fresh process, 24 steps"})
                 # worst case of the data-dependent scoring kernels: every (hypothesis, match) pair evaluated, every sum formed
                 ctx.set_option(ctx.OPT_RANSAC_ALL_SUMS, True)
                 ms_all, _ = timed_single(ctx, frames, P, K, H, s0.seeds, steps=5)
@@ -1107,9 +1162,8 @@ def main():
 
     if multi:
         dist.barrier()
-        for sl in slots:
-            if sl.comm is not None:
-                sl.comm.close()
+        for cm in comms:
+            cm.close()
         dist.destroy_process_group()
     pipe.close()
     sys.stdout.flush()

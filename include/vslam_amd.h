@@ -59,6 +59,12 @@ int vslam_ctx_synchronize(vslam_ctx *ctx);
 /* Waits for the context's stream and nothing else (vslam_ctx_synchronize also fetches the device-side error word). */
 int vslam_ctx_wait(vslam_ctx *ctx);
 const char *vslam_last_error(vslam_ctx *ctx);
+/* Diagnostics of the corner detector's LAST batch on this context (vslam_extract_features / vslam_frontend_* /
+ * vslam_good_features); waits for the context's stream.  h_stats[0] = frames, [1] = pixels per frame, [2] = pixels the certified
+ * cheap tier listed as possible corners, summed over the frames (the reference's exact arithmetic runs on these only),
+ * [3] = frames whose bounded list overflowed and were redone from whole-image scratch, [4] = scratch sets in the pool (more
+ * overflowing frames than this in one call: VSLAM_ERR_CAPACITY).  What bench.py reports per data regime.                   */
+int vslam_corner_stats(vslam_ctx *ctx, uint64_t h_stats[5]);
 /* Device memory the context's grow-only workspaces hold at the moment (bytes; what a batch shape costs beside its own
  * inputs and outputs).                                                                                    */
 int vslam_ctx_workspace_bytes(vslam_ctx *ctx, size_t *bytes_out);

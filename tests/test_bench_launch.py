@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -75,3 +77,43 @@ def test_the_drivers_scale_command_at_eight_ranks():
     assert d["n_gpus"] == 8 and d["gather_ok"] is True and d["steps"] == 2 and d["warmup"] == 1
     pr = d["per_rank_ms_per_step"]
     assert len(pr["ranks"]) == 8 and pr["min"] <= pr["max"]
+
+
+def test_self_launch_ends_ranks_that_exceed_the_wall_clock_limit():
+    """A rank stuck in a rendezvous or a collective must not hang the caller: the parent gives its ranks a wall-clock limit,
+    ends the whole process group on expiry and exits non-zero with one line of reason (VSLAM_BENCH_DRY_SLEEP makes the dry
+    ranks sleep)."""
+    env = dict(os.environ, VSLAM_BENCH_DRY="1", VSLAM_BENCH_BACKEND="gloo", VSLAM_BENCH_DRY_SLEEP="60")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--launch-timeout", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124 and "did not finish within 8 s" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 60 and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comm", ["per-rank", "per-context"])
+def test_the_n_gt_1_path_with_one_rccl_rank(comm):
+    """The whole bench through the code path of N > 1 -- process group, the library's RCCL communicator(s), the record gather
+    on the batches' streams, max-over-ranks timing -- with the single rank a one-GPU box allows (VSLAM_BENCH_FORCE_DIST=1)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VSLAM_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-extras",
+                        "--no-profile-pass", "--cpu-pairs", "8", "--cpu-all-cores-pairs", "0", "--pairs", "32", "--comm", comm],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    g = d["record_gather"]
+    assert g["through"] == "rccl" and g["rccl_ranks"] == 1 and g["own_block_intact_on_every_rank"] is True
+    assert g["communicators_per_rank"] == (1 if comm == "per-rank" else d["config"]["batches_in_flight"]) and g["comm"] == comm
+    assert d["parity_in_bench"]["bit_exact"] is True and d["n_gpus"] == 1 and d["value"] > 0

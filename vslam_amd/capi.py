@@ -25,7 +25,7 @@ SYMBOLS = [
     "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
-    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_kdtree_cell_table", "vslam_extract_features", "vslam_extract_features_grid", "vslam_triangulate_points", "vslam_frontend_pairs_pose", "vslam_pipeline_batches_redone", "vslam_bgr2gray", "vslam_min_eigen",
+    "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_kdtree_cell_table", "vslam_extract_features", "vslam_extract_features_grid", "vslam_triangulate_points", "vslam_frontend_pairs_pose", "vslam_pipeline_batches_redone", "vslam_corner_stats", "vslam_bgr2gray", "vslam_min_eigen",
     "vslam_good_features", "vslam_gaussian7", "vslam_orb_describe", "vslam_extract_Rt", "vslam_triangulate", "vslam_associate_map_points", "vslam_reprojection_filter",
     "vslam_match_features",
     "vslam_frontend_pairs", "vslam_frontend_sequence", "vslam_pack_records",
@@ -120,6 +120,13 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.vslam_ctx_synchronize(self.handle))
+
+    def corner_stats(self):
+        """{frames, px, listed, overflowed, pool}: the corner detector's counters of the last batch (vslam_corner_stats)."""
+        a = (C.c_uint64 * 5)()
+        self._check(self.lib.vslam_corner_stats(self.handle, a))
+        return {"frames": int(a[0]), "px_per_frame": int(a[1]), "listed_pixels": int(a[2]), "frames_overflowed": int(a[3]),
+                "pool_sets": int(a[4])}
 
     def workspace_bytes(self):
         n = C.c_size_t()

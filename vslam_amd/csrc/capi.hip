@@ -327,6 +327,27 @@ int vslam_ctx_wait(vslam_ctx *ctx) {
 
 const char *vslam_last_error(vslam_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// diagnostics of the corner detector's last batch (bench.py's data regimes): waits for the stream, copies the counters
+int vslam_corner_stats(vslam_ctx *ctx, uint64_t *h_stats) {
+    if (!ctx || !h_stats) return VSLAM_ERR_INVALID;
+    for (int i = 0; i < 5; i++) h_stats[i] = 0;
+    VS_REQUIRE(ctx, ctx->stat_counts && ctx->stat_pool_count && ctx->stat_frames > 0, VSLAM_ERR_INVALID);
+    VS_HIP(ctx, hipSetDevice(ctx->device));
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> counts((size_t)ctx->stat_frames);
+    int32_t tickets = 0;
+    VS_HIP(ctx, hipMemcpy(counts.data(), ctx->stat_counts, sizeof(uint32_t) * counts.size(), hipMemcpyDeviceToHost));
+    VS_HIP(ctx, hipMemcpy(&tickets, ctx->stat_pool_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    uint64_t listed = 0;
+    for (uint32_t v : counts) listed += v;
+    h_stats[0] = (uint64_t)ctx->stat_frames;
+    h_stats[1] = (uint64_t)ctx->stat_px;
+    h_stats[2] = listed;
+    h_stats[3] = (uint64_t)(tickets < 0 ? 0 : tickets);
+    h_stats[4] = (uint64_t)ctx->stat_pool_slots;
+    return VSLAM_OK;
+}
+
 int vslam_ctx_workspace_bytes(vslam_ctx *ctx, size_t *bytes_out) {
     if (!ctx || !bytes_out) return VSLAM_ERR_INVALID;
     size_t total = 0;

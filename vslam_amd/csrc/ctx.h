@@ -63,6 +63,11 @@ struct vslam_ctx {
     int corner_window_pct = 135;                // VSLAM_OPT_CORNER_WINDOW_PCT
     int corner_list_cap = 0;                    // VSLAM_OPT_CORNER_LIST_CAP: 0 = 16 x max_corners + 4096, -1 = whole image
     bool ransac_all_sums = false;   // VSLAM_OPT_RANSAC_ALL_SUMS: exact residual sum of every hypothesis (ransac_score_kernel)
+    // where the corner detector's last batch left its per-frame counters (vslam_corner_stats reads them after a stream wait)
+    const uint32_t *stat_counts = nullptr;
+    const int32_t *stat_pool_count = nullptr;
+    int stat_frames = 0, stat_pool_slots = 0;
+    size_t stat_px = 0;
     std::string err;
 
     // named, grow-only device buffers (never allocated inside a timed loop after warm-up)

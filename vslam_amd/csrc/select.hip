@@ -878,6 +878,11 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
         pool.counts = pw + 1 + pool.slots;
         pool.fmax = pw + 1 + 2 * (size_t)pool.slots;
     }
+    ctx->stat_counts = two_tier ? c.counts : nullptr;
+    ctx->stat_pool_count = two_tier ? pool.count : nullptr;
+    ctx->stat_frames = frames;
+    ctx->stat_pool_slots = pool.slots;
+    ctx->stat_px = px;
     int32_t *errflag = nullptr;
     if ((rc = vs_device_errflag(ctx, &errflag))) return rc;
     if (two_tier) {

@@ -249,3 +249,59 @@ def real_pair(first, motion):
     # source position of output (x, y): rotate (x - 320, y - 240) by rot, add centre + shift
     b = resample_fixed(first, 480, 640, ca, -sa, sa, ca, cx + dx - 320 * ca + 240 * sa, cy + dy - 320 * sa - 240 * ca)
     return a, b
+
+
+def frames_torch_photo(seed, n_pairs, width, height, device, npz=None):
+    """A batch with PHOTOGRAPHIC statistics (bench.py --data photo): every frame is a window of one of the four public-domain
+    photographs of tests/golden/real_v1.npz (736 x 576 crops: saturated plateaus, smooth gradients, JPEG block structure),
+    magnified by a per-pair factor of 1.0 .. 1.4 and continued by mirror images of itself where the window leaves the crop
+    (so any frame size can be cut; content stays photographic, nothing is synthesised).  Frame B of a pair is frame A after a
+    small camera motion -- rotation up to 1.5 degrees about the image centre, shift up to 12 px -- resampled at sub-pixel
+    positions.  Bilinear resampling in integer arithmetic (16.16 fixed point, 8-bit weights, as resample_fixed): the same bytes
+    on every device.  Returns uint8 (2 * n_pairs, H, W, 3): frames [0, n) are 'last', [n, 2n) 'current'."""
+    import os
+    import torch
+    if npz is None:
+        npz = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real_v1.npz")
+    g = np.load(npz)
+    crops = [torch.from_numpy(g[f"crop{i}"]).to(device) for i in range(4)]
+    out = torch.empty((2 * n_pairs, height, width, 3), dtype=torch.uint8, device=device)
+    Q = 1 << 16
+    xs = torch.arange(width, device=device, dtype=torch.int64)[None, :]
+    ys = torch.arange(height, device=device, dtype=torch.int64)[:, None]
+    rng = np.random.default_rng(int(seed) ^ 0xF070)
+
+    def sample(img, a, b, c, d, tx, ty):
+        H, W = img.shape[:2]
+        fx = int(round(a * Q)) * xs + int(round(b * Q)) * ys + int(round(tx * Q))
+        fy = int(round(c * Q)) * xs + int(round(d * Q)) * ys + int(round(ty * Q))
+        # mirror continuation: reflect the 16.16 coordinate into [0, (n - 1) Q] (period 2 (n - 1) Q)
+        px, py = 2 * (W - 1) * Q, 2 * (H - 1) * Q
+        fx = torch.remainder(fx, px)
+        fx = torch.where(fx > (W - 1) * Q, px - fx, fx)
+        fy = torch.remainder(fy, py)
+        fy = torch.where(fy > (H - 1) * Q, py - fy, fy)
+        x0, y0 = fx >> 16, fy >> 16
+        x1, y1 = torch.clamp(x0 + 1, max=W - 1), torch.clamp(y0 + 1, max=H - 1)
+        wx, wy = ((fx & (Q - 1)) >> 8)[..., None], ((fy & (Q - 1)) >> 8)[..., None]
+        src = img.to(torch.int64)
+        top = src[y0, x0] * (256 - wx) + src[y0, x1] * wx
+        bot = src[y1, x0] * (256 - wx) + src[y1, x1] * wx
+        return ((top * (256 - wy) + bot * wy + (1 << 15)) >> 16).to(torch.uint8)
+
+    for p in range(n_pairs):
+        img = crops[p % 4]
+        zoom = 1.0 + 0.4 * rng.random()
+        ox, oy = rng.uniform(-200, 400), rng.uniform(-150, 300)     # where the window sits (may leave the crop: mirrored)
+        rot = np.deg2rad(rng.uniform(-1.5, 1.5))
+        dx, dy = rng.uniform(-12, 12), rng.uniform(-12, 12)
+        k = 1.0 / zoom
+        out[p] = sample(img, k, 0.0, 0.0, k, ox, oy)
+        ca, sa = float(np.cos(rot)), float(np.sin(rot))
+        cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
+        # B's pixel (x, y) shows A's position R (x - c) + c + shift; A's position (u, v) shows the crop at (k u + ox, k v + oy)
+        a_, b_, c_, d_ = k * ca, -k * sa, k * sa, k * ca
+        tx = k * (cx + dx - ca * cx + sa * cy) + ox
+        ty = k * (cy + dy - sa * cx - ca * cy) + oy
+        out[n_pairs + p] = sample(img, a_, b_, c_, d_, tx, ty)
+    return out
