@@ -90,7 +90,7 @@ INT32_PEAK_TOPS = FP32_PEAK_TFLOPS / 2.0       # one 32-bit integer op per lane 
 INT8_MFMA_PEAK_TOPS = 5000.0                   # dense int8 MFMA (MI355X_MICROARCH.md: about 2x the 2.5 PFLOP/s bf16 rate)
 FP4_MFMA_PEAK_TOPS = 10000.0                   # dense FP4 / FP6 MFMA (MI355X_MICROARCH.md: about 10 PF; v_mfma_scale_f32_32x32x64_f8f6f4)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 SQ_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.csv")
 PMC_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_hbm_traffic.csv")
 STAMP_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_source_stamp.txt")
@@ -202,6 +202,21 @@ def sq_counters(kernel):
     return float(r["waves_per_launch"]), float(r["valu_insts_per_wave"]), float(r.get("valu_busy_cycles_per_wave") or 0.0)
 
 
+def sq_profiled(kernel):
+    """What the committed SQ pass says about the kernel AS PROFILED (numerator and denominator from the same launches, nothing
+    of this run's timing in it): wave occupancy (mean resident waves per SIMD over the launch: sum of the waves' lifetimes /
+    (1024 SIMDs x GRBM_GUI_ACTIVE / 8)) and the vector pipes' busy share, calibrated against pmc_calib_valu_kernel -- a kernel
+    that keeps every vector pipe busy by construction -- instead of a cycles-per-instruction constant (tools/sq_summary.py)."""
+    r = _profile_row(SQ_PROFILE, kernel, "valu_insts_per_wave")
+    if r is None or not r.get("occupancy_waves_per_simd"):
+        return None
+    out = {"occupancy_waves_per_simd": float(r["occupancy_waves_per_simd"])}
+    if r.get("valu_busy_frac"):
+        out["valu_busy_frac"] = float(r["valu_busy_frac"])
+        out["valu_busy_calibrated"] = r.get("calibrated") == "1"
+    return out
+
+
 SIMDS, CLOCK_GHZ = 256 * 4, 2.4
 
 
@@ -224,13 +239,21 @@ def arithmetic_view(kernel, units, ms_per_launch, full_batch):
         view["valu_issue"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU wave-instructions/s",
                               "frac": ginst / VALU_PEAK_GINST, "waves_per_launch": waves, "valu_insts_per_wave": insts,
                               "source": os.path.relpath(SQ_PROFILE, ROOT)}
-        if busy > 0:
-            # rocprof's VALUBusy: cycles the launch's vector instructions occupy the SIMDs' vector pipes / pipe cycles available
+        prof = sq_profiled(kernel)
+        if prof and "valu_busy_frac" in prof:
+            # the share of the chip's vector-pipe time the kernel's instructions fill, as profiled: SQ_ACTIVE_INST_VALU per
+            # GRBM_GUI_ACTIVE relative to the same ratio of a kernel whose pipes never idle (no clock, no cycles-per-instruction
+            # constant, nothing of this run's timing: cannot exceed 1 by construction, so nothing is clamped)
+            view["valu_busy"] = {"frac": prof["valu_busy_frac"], "calibrated": prof["valu_busy_calibrated"],
+                                 "what": "SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE of the kernel over the same ratio of pmc_calib_valu_kernel "
+                                         "(eight waves per SIMD of independent v_fma_f32: vector pipes busy throughout), one rocprofv3 pass"}
+        elif busy > 0:
             frac = waves * busy / (SIMDS * t * CLOCK_GHZ * 1e9)
-            view["valu_busy"] = {"frac": frac, "valu_busy_cycles_per_wave": busy,
-                                 "what": "SQ_ACTIVE_INST_VALU x 4 summed over the launch's waves / (1024 SIMDs x launch time x 2.4 GHz): "
-                                         "the share of the chip's vector-pipe time this kernel's instruction mix occupies (f64 and packed "
-                                         "instructions hold the pipe longer than the 2 cycles the issue rate assumes)"}
+            view["valu_busy"] = {"frac": frac, "calibrated": False, "valu_busy_cycles_per_wave": busy,
+                                 "what": "UNCALIBRATED: SQ_ACTIVE_INST_VALU x 4 summed over the launch's waves / (1024 SIMDs x this run's "
+                                         "launch time x 2.4 GHz)"}
+        if prof:
+            view["occupancy_waves_per_simd"] = prof["occupancy_waves_per_simd"]
     return view or None
 
 
@@ -630,6 +653,10 @@ def main():
     ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
                     help="pairs per process for the all-host-cores CPU figure (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--alone", action="store_true",
+                    help="for rocprofv3 passes: every kernel of a step on ONE stream, nothing beside it (k-d build, blur and generator in "
+                         "line), so that a traced kernel's duration is its own -- the arrangement of the per-kernel HIP-event pass; use with "
+                         "--in-flight 1")
     ap.add_argument("--solver", default="exact", choices=["exact", "gram"],
                     help="gram = the opt-in MFMA / normal-matrix 8-point solver (VSLAM_OPT_RANSAC_SOLVER 1): NOT bit-exact, "
                          "never the headline number; the line is labelled")
@@ -759,9 +786,13 @@ def main():
         b = torch.empty_like(a)
         ctx.debug_stream_copy(a, b, 4)
         ctx.debug_stream_copy(a, b, 16)
+        ctx.debug_valu_calib()       # a kernel with the vector pipes 100 % busy: calibrates SQ_ACTIVE_INST_VALU (tools/sq_summary.py)
         ctx.synchronize()
         del a, b
 
+    if args.alone:   # per-kernel event timing on = the library keeps the whole step on the main stream
+        for c_ in pipe.contexts:
+            c_.prof_enable(True)
     # set-up, not steps: every context allocates its workspaces on its first batch (0.1 s each) and RCCL builds its channels on
     # a communicator's first collective (seconds) -- one untimed pass per context keeps both out of the steps whatever W is
     for k in range(n_slots):
@@ -918,22 +949,18 @@ def main():
         kernels = kernel_table(rep, psteps, w, h, K, H, m_prelim, P)
         top = kernels[0]
         full_batch = args.workload == "C3" and P == WORKLOADS["C3"][4]   # the shape the committed counter passes ran
-        clamped = []
         if full_batch:   # every kernel of the step against the vector-pipe and HBM ceilings, where this build's counter rows exist
             for k in kernels:
                 sq = sq_counters(k["kernel"])
                 t_ = k["ms_per_launch"] * 1e-3
                 if sq and t_ > 0:
                     k["valu_issue_frac"] = sq[0] * sq[1] / t_ / 1e9 / VALU_PEAK_GINST
-                    if sq[2] > 0:
-                        # counters per wave come from the committed profile (a property of the build), the launch time from this
-                        # run at a nominal 2.4 GHz: the quotient can come out a few per cent above 1 for a kernel that keeps the
-                        # pipe full.  A fraction is clamped to 1 and the raw quotient kept beside it.
-                        raw = sq[0] * sq[2] / (SIMDS * t_ * CLOCK_GHZ * 1e9)
-                        k["valu_busy_frac"] = min(1.0, raw)
-                        if raw > 1.0:
-                            k["valu_busy_frac_unclamped"] = raw
-                            clamped.append(k["kernel"])
+                prof = sq_profiled(k["kernel"])
+                if prof:
+                    k["occupancy_waves_per_simd"] = prof["occupancy_waves_per_simd"]
+                    if "valu_busy_frac" in prof:
+                        k["valu_busy_frac"] = prof["valu_busy_frac"]
+                        k["valu_busy_calibrated"] = prof["valu_busy_calibrated"]
                 tr = pmc_traffic(k["kernel"])
                 if tr is not None:
                     k["hbm_traffic_bytes_per_launch"] = tr
@@ -944,9 +971,6 @@ def main():
         mean_kp = float(n_kp.mean())
         by_name = {k["kernel"]: k for k in kernels}
         av = arithmetic_view(top["kernel"], units_of(top["kernel"], w, h, H, P, m_prelim, mean_kp), top["ms_per_launch"], full_batch)
-        if av and "valu_busy" in av and av["valu_busy"]["frac"] > 1.0:
-            av["valu_busy"]["frac_unclamped"] = av["valu_busy"]["frac"]
-            av["valu_busy"]["frac"] = 1.0
         # The dominant kernel (ransac_solve or min_eigen) is held by the vector pipe, not by bandwidth.  Two
         # fractions at the top level: `frac` = the vector-instruction issue rate -- waves x instructions per wave (committed
         # SQ counters of this build) / this run's launch time, against the chip's 1228.8 G wave-instructions/s: how busy the
@@ -963,7 +987,8 @@ def main():
                                          f"({vi['source']}) / {top['ms_per_launch']:.4f} ms / 1e6 = achieved; peak = 1024 SIMDs x 2.4 GHz / 2 "
                                          "cycles per wave instruction; frac_algorithmic = flops.frac (counted flop per hypothesis x "
                                          "hypotheses per launch / launch time / 157.3 TFLOP/s)",
-                                  "valu_busy": av.get("valu_busy"), "hbm": hbm_view, "flops": flops or None}
+                                  "valu_busy": av.get("valu_busy"), "occupancy_waves_per_simd": av.get("occupancy_waves_per_simd"),
+                                  "hbm": hbm_view, "flops": flops or None}
         else:
             result["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS,
@@ -988,7 +1013,8 @@ def main():
                                           "avg_launch_ms": st["ms_per_launch"]}
         result["counter_profiles"] = {"tag": PROFILE_TAG, "match_this_build": counters_current(),
                                       "dominant_kernel_rows_match": counters_current(top["kernel"]),
-                                      "valu_busy_clamped_to_1": clamped,
+                                      "occupancy": "kernels[*].occupancy_waves_per_simd = mean resident waves per SIMD while the kernel runs (8 = the "
+                                                   "hardware's limit), from SQ_WAVE_CYCLES and GRBM_GUI_ACTIVE of the committed pass",
                                       "note": "traffic / valu_issue / valu_busy come from the committed rocprofv3 PMC summaries and are "
                                               "omitted (null) for a kernel whose source file, or the shared headers, changed since"}
         result["kernels"] = kernels

@@ -162,6 +162,10 @@ int vslam_prof_get(vslam_ctx *ctx, int i, char *name, int name_cap, double *tota
 /* profiling aid: a plain streaming copy of `bytes` (multiple of 16) with 4 or 16 bytes per lane, so
  * rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count per access width */
 int vslam_debug_stream_copy(vslam_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int bytes_per_lane);
+/* profiling aid: a kernel that keeps every SIMD's vector pipe busy for its whole duration (8 waves per SIMD of independent
+ * v_fma_f32), so that rocprofv3's SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE ratio that means "vector pipe 100 % busy" is measured
+ * rather than assumed (tools/sq_summary.py) */
+int vslam_debug_valu_calib(vslam_ctx *ctx);
 
 /* ----------------------------------------------------------------- matching */
 /* Replaces match_features' front half, src/Frame.cpp:83-94:

@@ -22,7 +22,7 @@ ERRORS = {-1: "VSLAM_ERR_INVALID", -2: "VSLAM_ERR_HIP", -3: "VSLAM_ERR_NO_DEVICE
 SYMBOLS = [
     "vslam_ctx_create", "vslam_ctx_make_current", "vslam_ctx_destroy", "vslam_ctx_set_stream", "vslam_ctx_set_option", "vslam_ctx_synchronize", "vslam_ctx_wait",
     "vslam_last_error", "vslam_ctx_workspace_bytes", "vslam_version", "vslam_brief_pattern_31", "vslam_dev_alloc", "vslam_dev_free", "vslam_copy_h2d",
-    "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
+    "vslam_copy_d2h", "vslam_debug_stream_copy", "vslam_debug_valu_calib", "vslam_prof_enable", "vslam_prof_reset", "vslam_prof_count", "vslam_prof_get",
     "vslam_match_knn2_ratio", "vslam_ransac_sets", "vslam_ransac_fundamental", "vslam_ransac_solve",
     "vslam_ransac_evaluate", "vslam_kdtree_build",
     "vslam_kdtree_radius", "vslam_kdtree_nearest", "vslam_kdtree_cell_table", "vslam_extract_features", "vslam_extract_features_grid", "vslam_triangulate_points", "vslam_frontend_pairs_pose", "vslam_pipeline_batches_redone", "vslam_corner_stats", "vslam_bgr2gray", "vslam_min_eigen",
@@ -165,6 +165,9 @@ class Context:
             self._check(self.lib.vslam_prof_get(self.handle, C.c_int(i), name, C.c_int(128), C.byref(ms), C.byref(cnt)))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    def debug_valu_calib(self):
+        self._check(self.lib.vslam_debug_valu_calib(self.handle))
 
     def debug_stream_copy(self, src, dst, bytes_per_lane):
         self._check(self.lib.vslam_debug_stream_copy(self.handle, _ptr(src), _ptr(dst), C.c_size_t(src.numel() * src.element_size()),

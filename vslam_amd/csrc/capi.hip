@@ -148,7 +148,39 @@ __global__ __launch_bounds__(256) void pmc_calib_copy16_kernel(const uint4 *__re
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// A kernel of KNOWN vector-pipe occupancy, to calibrate rocprofv3's SQ_ACTIVE_INST_VALU the way the copies above calibrate
+// FETCH_SIZE: eight waves on every SIMD, each issuing `iters` x 16 independent v_fma_f32 and next to nothing else.  By
+// construction the vector pipes are busy for the whole launch, so (SQ_ACTIVE_INST_VALU of this kernel) / (its GRBM_GUI_ACTIVE)
+// is the counter ratio that means "100 %" -- tools/sq_summary.py divides every other kernel's ratio by it.
+__global__ __launch_bounds__(256) void pmc_calib_valu_kernel(float *__restrict__ out, float seed, int iters) {
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i] = seed + (float)i + (float)threadIdx.x;
+    const float c = seed * 0.999f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(c));
+    }
+    float acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += a[i];
+    if (acc == 12345.678f) out[0] = acc;   // never true: keeps the chain alive
+}
+
 extern "C" {
+
+int vslam_debug_valu_calib(vslam_ctx *ctx) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    float *out = nullptr;
+    int rc = vs_arena_get(ctx, "ctx.valu_calib", 256, (void **)&out);
+    if (rc) return rc;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    VsProfScope ps(ctx, "pmc_calib_valu_kernel");
+    pmc_calib_valu_kernel<<<cus * 8, 256, 0, ctx->stream>>>(out, 1.25f, 4000);   // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
 
 int vslam_debug_stream_copy(vslam_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int bytes_per_lane) {
     if (!ctx || !d_src || !d_dst || (bytes_per_lane != 4 && bytes_per_lane != 16) || bytes % 16) return VSLAM_ERR_INVALID;
