@@ -89,7 +89,22 @@ FP32_PEAK_TFLOPS = 157.3                       # FMA counted as 2: 256 CUs x 4 S
 INT32_PEAK_TOPS = FP32_PEAK_TFLOPS / 2.0       # one 32-bit integer op per lane and clock
 INT8_MFMA_PEAK_TOPS = 5000.0                   # dense int8 MFMA (MI355X_MICROARCH.md: about 2x the 2.5 PFLOP/s bf16 rate)
 FP4_MFMA_PEAK_TOPS = 10000.0                   # dense FP4 / FP6 MFMA (MI355X_MICROARCH.md: about 10 PF; v_mfma_scale_f32_32x32x64_f8f6f4)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s the chip can issue
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # G wave-instructions / s at the nominal 2 cycles per wave64 instruction (spec peak)
+
+
+def valu_issue_ceiling():
+    """The MEASURED issue ceiling (round 6): cycles a SIMD needs per plain vector instruction with eight waves of independent
+    v_fma_f32 to choose from (tools/sq_summary.py, pmc_calib_valu_kernel in the committed SQ pass) -> G wave-instructions/s at
+    2.4 GHz.  About 3.9 cycles, i.e. half the nominal rate: the spec's FP32 figure needs the packed forms."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters_calibration.json")
+    try:
+        with open(path) as fh:
+            c = json.load(fh)
+        cyc = float(c["cycles_per_valu_instruction_per_simd"])
+        return {"cycles_per_valu_instruction_per_simd": cyc, "G_wave_instructions_per_s_at_2.4GHz": SIMDS * CLOCK_GHZ / cyc,
+                "source": os.path.relpath(path, ROOT)}
+    except (OSError, ValueError, KeyError):
+        return None
 PROFILE_TAG = "r06"
 SQ_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.csv")
 PMC_PROFILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_hbm_traffic.csv")
@@ -239,6 +254,10 @@ def arithmetic_view(kernel, units, ms_per_launch, full_batch):
         view["valu_issue"] = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU wave-instructions/s",
                               "frac": ginst / VALU_PEAK_GINST, "waves_per_launch": waves, "valu_insts_per_wave": insts,
                               "source": os.path.relpath(SQ_PROFILE, ROOT)}
+        ceil = valu_issue_ceiling()
+        if ceil:
+            view["valu_issue"]["measured_ceiling"] = ceil
+            view["valu_issue"]["frac_of_measured_ceiling"] = ginst / ceil["G_wave_instructions_per_s_at_2.4GHz"]
         prof = sq_profiled(kernel)
         if prof and "valu_busy_frac" in prof:
             # the share of the chip's vector-pipe time the kernel's instructions fill, as profiled: SQ_ACTIVE_INST_VALU per

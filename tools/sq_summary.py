@@ -69,6 +69,15 @@ def main(src, dst):
         w.writerows(rows)
     print(open(dst).read())
     if full:
+        import json
+        with open(os.path.splitext(dst)[0] + "_calibration.json", "w") as o:
+            json.dump({"kernel": "pmc_calib_valu_kernel: 8 waves per SIMD, independent v_fma_f32 only",
+                       "sq_active_inst_valu_per_grbm_gui_active_at_full_pipes": full,
+                       "nominal_ratio_4_cycles_per_quad_cycle_1024_simds_8_xcds": SIMDS / (8 * 4.0),
+                       "valu_insts_per_wave": cal["SQ_INSTS_VALU"] / cal["SQ_WAVES"],
+                       "cycles_per_valu_instruction_per_simd": cal["GRBM_GUI_ACTIVE"] / 8 * SIMDS / cal["SQ_INSTS_VALU"],
+                       "what": "a SIMD issues one plain (non-packed) wave64 vector instruction about every 3.9 shader cycles even with "
+                               "eight waves to choose from: the ceiling a kernel's vector-instruction issue rate is held against"}, o, indent=1)
         print(f"calibration: pmc_calib_valu_kernel has SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE = {full:.4f} "
               f"(= {full * 8 * 4 / SIMDS:.3f} of the nominal '4 cycles per quad-cycle on 1024 SIMDs'); "
               f"its {cal['SQ_INSTS_VALU'] / cal['SQ_WAVES']:.0f} vector instructions per wave took "
