@@ -1168,6 +1168,91 @@ def main():
                     del frames
                 regimes[kind] = entry
             result["data_regimes"] = regimes
+
+            # ---- the SURVEY 8(f) rows at batch scale: the resident pose chain (vslam_frontend_pairs_pose = the step + extract_Rt +
+            # triangulate + reprojection filter, src/vslam.cpp:82-88,120-125,186-251) and the map-association block
+            # (src/vslam.cpp:129-161) on the batch's own results, one context; checked against the oracle on a few pairs
+            def pose_and_association():
+                Kmat = np.array([[525.0, 0, w // 2], [0, 525.0, h // 2], [0, 0, 1]], np.float32)   # src/vslam.cpp:32
+                po = ctx.frontend_pairs_pose(s0.bgr, P, K, ca, sa, pat, s0.seeds, H, thr, Kmat)
+                for _ in range(2):
+                    ctx.frontend_pairs_pose(s0.bgr, P, K, ca, sa, pat, s0.seeds, H, thr, Kmat, out=po)
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    ctx.frontend_pairs_pose(s0.bgr, P, K, ca, sa, pat, s0.seeds, H, thr, Kmat, out=po)
+                ctx.synchronize()
+                ms_pose = (time.perf_counter() - t1) / 10 * 1e3
+                ms_plain, _ = timed_single(ctx, s0.bgr, P, K, H, s0.seeds)
+                ctx.prof_enable(True)
+                ctx.prof_reset()
+                ctx.frontend_pairs_pose(s0.bgr, P, K, ca, sa, pat, s0.seeds, H, thr, Kmat, out=po)
+                rep2 = ctx.prof_report()
+                ctx.prof_enable(False)
+                stage = {nm: rep2[nm][0] / max(rep2[nm][1], 1) for nm in ("pose_from_F_kernel", "triangulate_kernel", "reproj_filter_kernel") if nm in rep2}
+                hp = {k_: v_.cpu().numpy() for k_, v_ in po.items()}
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from oracle_lib import Oracle
+                o_ = Oracle()
+                bits = lambda a_: np.ascontiguousarray(a_, np.float32).view(np.uint32)
+                c1 = np.c_[Kmat, np.zeros(3, np.float32)]
+                bad_p = []
+                for b_ in range(min(P, 8)):
+                    Rr, tr_ = o_.extract_Rt(hp["F"][b_], Kmat)
+                    c2r = o_.camera_matrix(Kmat, Rr, tr_)
+                    kk = int(hp["best"][b_, 3])
+                    mm = hp["matches"][b_, :kk]
+                    p1_, p2_ = hp["xy"][b_][mm[:, 0]], hp["xy"][P + b_][mm[:, 1]]
+                    ref = o_.triangulate(p1_, p2_, c1, c2r)
+                    kept, err = o_.reprojection_filter(ref, p1_, p2_, c1, c2r, np.full(kk, -1, np.int32), 4.0)
+                    ok_ = (np.array_equal(bits(hp["R"][b_]), bits(Rr.reshape(9))) and np.array_equal(bits(hp["t"][b_]), bits(tr_))
+                           and np.array_equal(bits(hp["c2"][b_]), bits(c2r.reshape(12))) and np.array_equal(bits(hp["points4d"][b_, :kk]), bits(ref))
+                           and int(hp["n_inliers"][b_]) == len(kept) and np.array_equal(hp["inlier_idx"][b_, :len(kept)], kept)
+                           and float(hp["error"][b_]) == err)
+                    if not ok_:
+                        bad_p.append(b_)
+                entry = {"what": "vslam_frontend_pairs_pose on the timed batch, one context: the step + extract_Rt + triangulate + reprojection filter, nothing leaving the device",
+                         "ms_per_step": ms_pose, "ms_per_step_without_the_pose_stages": ms_plain, "pose_stages_ms": ms_pose - ms_plain,
+                         "kernels_ms_per_launch": stage, "mean_reprojection_inliers": float(hp["n_inliers"].mean()),
+                         "parity_in_bench": {"pairs": min(P, 8), "bit_exact": not bad_p,
+                                             "checked": "R, t, c2, the triangulated points (as uint32), the reprojection filter's index list and error sum vs the oracle"}}
+                # association: every pair's triangulated points as the map, one observation each (the matched keypoint of the FIRST
+                # frame), searched for in the SECOND frame's tree with the loop's radius 2 and threshold 64
+                Mp = K
+                mp_ = po["points4d"]                                     # (P, K, 4), rows beyond a pair's inliers are zero
+                n_map = po["best"][:, 3].contiguous().to(torch.int32)
+                offs = torch.arange(Mp + 1, dtype=torch.int32, device=dev).repeat(P, 1).contiguous()   # one observation per map point
+                idx1 = po["matches"][:, :, 0].long().clamp(0, K - 1)
+                od = torch.gather(po["desc"][:P], 1, idx1[:, :, None].expand(P, K, 32)).contiguous()
+                ids_all = torch.full((12, P, K), -1, dtype=torch.int32, device=dev)   # map_point_ids is in / out: a fresh set per call
+                claim = torch.full((P, Mp), -3, dtype=torch.int32, device=dev)
+                nodes2, xy2, desc2, n2 = po["nodes"][P:].contiguous(), po["xy"][P:].contiguous(), po["desc"][P:].contiguous(), po["n"][P:].contiguous()
+                torch.cuda.synchronize(dev)
+                ctx.associate(mp_, n_map, po["c2"], w, h, nodes2, xy2, desc2, n2, offs, od, ids_all[11], claim=claim)
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                for i_ in range(10):
+                    ctx.associate(mp_, n_map, po["c2"], w, h, nodes2, xy2, desc2, n2, offs, od, ids_all[i_], claim=claim)
+                ctx.synchronize()
+                ms_assoc = (time.perf_counter() - t1) / 10 * 1e3
+                hc, hid = claim.cpu().numpy(), ids_all[9].cpu().numpy()
+                bad_a = []
+                for b_ in range(min(P, 4)):
+                    kk, nk = int(hp["best"][b_, 3]), int(hp["n"][P + b_])
+                    ref_ids, ref_claim = o_.associate(hp["points4d"][b_, :kk], hp["c2"][b_], w, h, hp["nodes"][P + b_, :nk], hp["xy"][P + b_, :nk],
+                                                      hp["desc"][P + b_, :nk], np.arange(kk + 1, dtype=np.int32), od[b_, :max(kk, 1)].cpu().numpy(),
+                                                      np.full(nk, -1, np.int32))
+                    if not (np.array_equal(hc[b_, :kk], ref_claim) and np.array_equal(hid[b_, :nk], ref_ids)):
+                        bad_a.append(b_)
+                entry["association"] = {"what": "vslam_associate_map_points: each pair's triangulated inliers as map points (one observation each), radius 2, threshold 64",
+                                        "ms_per_batch": ms_assoc, "map_points_per_pair": float(n_map.float().mean()),
+                                        "claimed_per_pair": float((claim >= 0).float().sum(1).mean()),
+                                        "parity_in_bench": {"pairs": min(P, 4), "bit_exact": not bad_a}}
+                return entry, bool(bad_p or bad_a)
+            pc, pc_bad = pose_and_association()
+            result["pose_chain"] = pc
+            if pc_bad:
+                exit_code = 3
             others = {}
             for wl in sorted(WORKLOADS):   # each in a process of its own (see child): headline arrangement, own per-kernel pass
                 if wl == args.workload:

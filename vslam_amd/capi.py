@@ -413,11 +413,13 @@ class Context:
                                                        C.c_float(thr_sq), _ptr(idx), _ptr(n), _ptr(err)))
         return idx, n, err
 
-    def associate(self, map_points, n_map, c2, w, h, nodes, xy, desc, n, obs_offsets, obs_desc, ids, radius=2.0, thr=64):
+    def associate(self, map_points, n_map, c2, w, h, nodes, xy, desc, n, obs_offsets, obs_desc, ids, radius=2.0, thr=64, claim=None):
         torch = self.torch
         B, Mp, _ = map_points.shape
         Kp = xy.shape[1]
-        claim = torch.full((B, Mp), -3, dtype=torch.int32, device=xy.device)
+        if claim is None:
+            claim = torch.full((B, Mp), -3, dtype=torch.int32, device=xy.device)
+            self._ready()
         self._check(self.lib.vslam_associate_map_points(
             self.handle, _ptr(map_points), _ptr(n_map), C.c_int(B), C.c_int(Mp), _ptr(c2), C.c_int(w), C.c_int(h), _ptr(nodes),
             _ptr(xy), _ptr(desc), _ptr(n), C.c_int(Kp), _ptr(obs_offsets), _ptr(obs_desc), C.c_int(obs_desc.shape[1]),
