@@ -486,6 +486,10 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
 
     for (int y0 = 0; y0 < rh; y0 += L.R) {   // strip = inner rows [y0, y0 + rows)
         const int rows = min(L.R, rh - y0);
+        for (int id = tid; id < rows * L.CPR; id += 256) {   // the strip's chunk masks start empty (candidates or them in)
+            L.mask5[id] = 0ull;
+            L.mask20[id] = 0ull;
+        }
         // 1. source tile: level rows 31 + y0 - 4 .. (rows + 8 of them), columns 27 .. lw - 28 (rw + 8), as (unaligned) dwords,
         //    eight loads in flight per lane (a dword may reach up to 3 bytes past the tile's last column: still inside the level's row)
         {
@@ -554,37 +558,64 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
             }
         }
         __syncthreads();
-        // 3. non-max suppression; a ballot mask per chunk of 64 pixels and detector, score histogram of the threshold-20 survivors
+        // 3.-5. non-max suppression, per-chunk counts, ordered writes.  Every pixel with M > 5 is on the candidate list (unless
+        //    the list overflowed), so all three are driven by the list -- a few per cent of the pixels -- instead of walking every
+        //    64-pixel chunk: a surviving candidate sets its bit in its chunk's mask (LDS atomic or), the counts are the masks'
+        //    popcounts, and a survivor's slot is its chunk's prefix plus the rank of its bit: raster order whatever order the
+        //    candidates were listed in.
         const int nc = rows * L.CPR;
-        for (int id = wave; id < nc; id += 4) {
-            const int r = div_magic(id, mC), c = id - r * L.CPR;
-            const int x = c * 64 + lane;
-            const uint8_t *m = L.M + (r + 1) * L.MW + x + 1;
-            const int v = x < rw ? (int)m[0] : 0;
-            bool keep = false;
-            if (v > kFastMin) {
+        const bool listed = L.tot[2] <= L.ccap;   // (uniform; read after the barrier that closed the list)
+        if (listed) {
+            const int nc2 = L.tot[2];
+            for (int j = tid; j < nc2; j += 256) {
+                const int am = L.cand[j];
+                const int r = div_magic(am, mMW), cc = am - r * L.MW;
+                if (r < 1 || r > rows || cc < 1 || cc > rw) continue;   // the ring only serves as neighbours
+                const uint8_t *m = L.M + am;
+                const int v = m[0];
+                if (v <= kFastMin) continue;
                 const int nb = max(max(max3i(m[-L.MW - 1], m[-L.MW], m[-L.MW + 1]), max3i(m[L.MW - 1], m[L.MW], m[L.MW + 1])),
                                    max((int)m[-1], (int)m[1]));
-                keep = v > nb;
+                if (v > nb) {
+                    const int id = (r - 1) * L.CPR + ((cc - 1) >> 6);
+                    const unsigned long long bit = 1ull << ((cc - 1) & 63);
+                    atomicOr(&L.mask5[id], bit);
+                    if (v > kThr[0]) {
+                        atomicOr(&L.mask20[id], bit);
+                        atomicAdd(&L.hist[v], 1);
+                    }
+                }
             }
-            const bool keep20 = keep && v > kThr[0];
-            const unsigned long long b5 = __ballot(keep), b20 = __ballot(keep20);
-            if (keep20) atomicAdd(&L.hist[v], 1);
-            if (lane == 0) {
-                L.mask5[id] = b5;
-                L.mask20[id] = b20;
-                L.cnt5[id] = (int)__popcll(b5);
-                L.cnt20[id] = (int)__popcll(b20);
+        } else {
+            for (int id = wave; id < nc; id += 4) {
+                const int r = div_magic(id, mC), c = id - r * L.CPR;
+                const int x = c * 64 + lane;
+                const uint8_t *m = L.M + (r + 1) * L.MW + x + 1;
+                const int v = x < rw ? (int)m[0] : 0;
+                bool keep = false;
+                if (v > kFastMin) {
+                    const int nb = max(max(max3i(m[-L.MW - 1], m[-L.MW], m[-L.MW + 1]), max3i(m[L.MW - 1], m[L.MW], m[L.MW + 1])),
+                                       max((int)m[-1], (int)m[1]));
+                    keep = v > nb;
+                }
+                const bool keep20 = keep && v > kThr[0];
+                const unsigned long long b5 = __ballot(keep), b20 = __ballot(keep20);
+                if (keep20) atomicAdd(&L.hist[v], 1);
+                if (lane == 0) {
+                    L.mask5[id] = b5;
+                    L.mask20[id] = b20;
+                }
             }
         }
         __syncthreads();
-        // 4. exclusive scan of the chunk counts (wave 0: threshold 5, wave 1: threshold 20), running totals carried in LDS
+        // exclusive scan of the chunk counts (wave 0: threshold 5, wave 1: threshold 20), running totals carried in LDS
         if (wave < 2) {
             int *cnt = wave == 0 ? L.cnt5 : L.cnt20;
+            const unsigned long long *msk = wave == 0 ? L.mask5 : L.mask20;
             int base = L.tot[wave];
             for (int j0 = 0; j0 < nc; j0 += 64) {
                 const int j = j0 + lane;
-                const int v = j < nc ? cnt[j] : 0;
+                const int v = j < nc ? (int)__popcll(msk[j]) : 0;
                 int inc = v;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -595,26 +626,47 @@ __global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, in
                 base += __shfl(inc, 63, 64);
             }
             if (lane == 0) L.tot[wave] = base;
-        } else if (tid == 128) {
-            L.tot[2] = 0;   // the next strip's candidate count (this strip's was last read two barriers ago)
         }
         __syncthreads();
-        // 5. ordered writes
-        for (int id = wave; id < nc; id += 4) {
-            const int r = div_magic(id, mC), c = id - r * L.CPR;
-            const int x = c * 64 + lane;
-            const unsigned long long b5 = L.mask5[id], b20 = L.mask20[id];
-            if ((b5 >> lane) & 1ull) {
-                const uint32_t e = ((uint32_t)((y0 + r) * rw + x) << 8) | (uint32_t)L.M[(r + 1) * L.MW + x + 1];
-                const int p5 = L.cnt5[id] + (int)__popcll(b5 & lt);
-                if (p5 < cap) list5[p5] = e;
-                if ((b20 >> lane) & 1ull) {
-                    const int p20 = L.cnt20[id] + (int)__popcll(b20 & lt);
-                    if (p20 < cap) list20[p20] = e;
+        // ordered writes
+        if (listed) {
+            const int nc2 = L.tot[2];
+            for (int j = tid; j < nc2; j += 256) {
+                const int am = L.cand[j];
+                const int r = div_magic(am, mMW), cc = am - r * L.MW;
+                if (r < 1 || r > rows || cc < 1 || cc > rw) continue;
+                const int id = (r - 1) * L.CPR + ((cc - 1) >> 6), bitpos = (cc - 1) & 63;
+                const unsigned long long b5 = L.mask5[id];
+                if ((b5 >> bitpos) & 1ull) {
+                    const unsigned long long below = (1ull << bitpos) - 1ull;
+                    const uint32_t e = ((uint32_t)((y0 + r - 1) * rw + (cc - 1)) << 8) | (uint32_t)L.M[am];
+                    const int p5 = L.cnt5[id] + (int)__popcll(b5 & below);
+                    if (p5 < cap) list5[p5] = e;
+                    const unsigned long long b20 = L.mask20[id];
+                    if ((b20 >> bitpos) & 1ull) {
+                        const int p20 = L.cnt20[id] + (int)__popcll(b20 & below);
+                        if (p20 < cap) list20[p20] = e;
+                    }
+                }
+            }
+        } else {
+            for (int id = wave; id < nc; id += 4) {
+                const int r = div_magic(id, mC), c = id - r * L.CPR;
+                const int x = c * 64 + lane;
+                const unsigned long long b5 = L.mask5[id], b20 = L.mask20[id];
+                if ((b5 >> lane) & 1ull) {
+                    const uint32_t e = ((uint32_t)((y0 + r) * rw + x) << 8) | (uint32_t)L.M[(r + 1) * L.MW + x + 1];
+                    const int p5 = L.cnt5[id] + (int)__popcll(b5 & lt);
+                    if (p5 < cap) list5[p5] = e;
+                    if ((b20 >> lane) & 1ull) {
+                        const int p20 = L.cnt20[id] + (int)__popcll(b20 & lt);
+                        if (p20 < cap) list20[p20] = e;
+                    }
                 }
             }
         }
-        // (the next strip's first barrier stands between these reads of M / masks / counts and their next writes)
+        __syncthreads();
+        if (tid == 0) L.tot[2] = 0;   // the next strip's candidate count
     }
     __syncthreads();
     if (wave == 0) {
