@@ -436,6 +436,17 @@ def grid_workload(args):
         pipe.commit(t)
         sl.used += 1
 
+    if args.pmc_calibrate:   # the known-size copies and the busy-pipe kernel the counter summaries calibrate against
+        a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
+        b_ = torch.empty_like(a_)
+        ctx.debug_stream_copy(a_, b_, 4)
+        ctx.debug_stream_copy(a_, b_, 16)
+        ctx.debug_valu_calib()
+        ctx.synchronize()
+        del a_, b_
+    if args.alone:
+        for c_ in pipe.contexts:
+            c_.prof_enable(True)
     for k in range(n_slots):
         step(k)
     pipe.drain()

@@ -1077,9 +1077,16 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, uint
                                                        const float4 *__restrict__ kps, const int32_t *__restrict__ n_arr,
                                                        int kp_cap, const int8_t *__restrict__ pattern,
                                                        const int32_t *__restrict__ pat_radius, uint8_t *__restrict__ desc,
-                                                       float *__restrict__ out_xy, float *__restrict__ out_angle_octave) {
-    const int f = blockIdx.y, tid = threadIdx.x;
-    const int kp = blockIdx.x * 8 + (tid >> 5), byte = tid & 31;
+                                                       float *__restrict__ out_xy, float *__restrict__ out_angle_octave, int frames,
+                                                       int per_frame) {
+    // all workgroups of a frame on one XCD: its gray image, blurred image and pyramids (a few MB) then stay in that XCD's L2
+    // while the frame's keypoints gather from them (dealt round-robin, every XCD would stream every frame: 3.4 KB of HBM
+    // traffic per keypoint measured)
+    int f, blk;
+    vs_xcd_item_block(blockIdx.x, per_frame, f, blk);
+    if (f >= frames) return;
+    const int tid = threadIdx.x;
+    const int kp = blk * 8 + (tid >> 5), byte = tid & 31;
     // the lane's eight pattern entries ((x1, y1, x2, y2) as int8 x 4 per bit), the frame's count and the keypoint record are
     // independent loads: all in flight before the first use (the record of a slot past the count is never used)
     const int4 pq0 = reinterpret_cast<const int4 *>(pattern)[byte * 2], pq1 = reinterpret_cast<const int4 *>(pattern)[byte * 2 + 1];
@@ -1364,8 +1371,9 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
                                                G.flh[l] + 6, 3, G.flh[l] + 3)))
                 return rc;
         pattern_radius_kernel<<<1, 512, 0, st>>>(pattern, pat_r);
-        orb_desc_kernel<<<dim3(vs_div_up(kp_cap, 8), frames), 256, 0, st>>>(G, U, (uint32_t)gbytes, images, blurred, fpyr, fkp, n_out,
-                                                                            kp_cap, pattern, pat_r, desc, xy, angle_octave);
+        const int per_frame = vs_div_up(kp_cap, 8);
+        orb_desc_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, st>>>(G, U, (uint32_t)gbytes, images, blurred, fpyr, fkp, n_out, kp_cap,
+                                                                        pattern, pat_r, desc, xy, angle_octave, frames, per_frame);
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
