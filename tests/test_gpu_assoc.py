@@ -70,3 +70,41 @@ def test_association_bit_exact(ctx, oracle):
         assert np.array_equal(got_ids[b, :k], ref_ids), b
         total += int((ref_claim >= 0).sum())
     assert total > 300, "scenario should produce associations"
+
+
+def test_association_edge_cases(ctx, oracle):
+    """No map points; map points without observations (distance u32_max: never accepted); everything out of view; every map
+    point projecting onto the same keypoint (the lowest map index claims it, the others find it taken)."""
+    w, h = 320, 240
+    rng = np.random.default_rng(9)
+    kp = np.unique(np.rint(np.stack([rng.uniform(0, w - 1, 300), rng.uniform(0, h - 1, 300)], 1)), axis=0).astype(np.float32)
+    rng.shuffle(kp)
+    n_kp = len(kp)
+    desc = rng.integers(0, 256, (n_kp, 32), dtype=np.uint8)
+    nodes = oracle.kdtree_build_frame(kp)
+    c2 = np.array([[525, 0, w // 2, 0], [0, 525, h // 2, 0], [0, 0, 1, 0]], np.float32)       # K [I | 0]
+    Kinv = lambda px, z: np.array([(px[0] - w // 2) / 525.0 * z, (px[1] - h // 2) / 525.0 * z, z, 1.0], np.float32)
+    same = np.stack([Kinv(kp[5] + np.array([0.25, -0.5], np.float32), 3.0 + 0.1 * i) for i in range(6)])
+    cases = {
+        "empty map": (np.zeros((0, 4), np.float32), np.zeros(1, np.int32), np.zeros((1, 32), np.uint8)),
+        "no observations": (np.stack([Kinv(kp[i], 4.0) for i in range(8)]), np.zeros(9, np.int32), np.zeros((1, 32), np.uint8)),
+        "out of view": (np.stack([Kinv(kp[i] + 5000, 4.0) for i in range(8)]), np.arange(9, dtype=np.int32), np.repeat(desc[:8], 1, 0)),
+        "behind one keypoint": (same, np.arange(7, dtype=np.int32), np.repeat(desc[5:6], 6, 0)),
+    }
+    for name, (mp, offs, od) in cases.items():
+        ids = np.full(n_kp, -1, np.int32)
+        B, Mp, Os = 1, max(len(mp), 1), len(od)
+        mpb = np.zeros((B, Mp, 4), np.float32); mpb[0, :len(mp)] = mp
+        offb = np.zeros((B, Mp + 1), np.int32); offb[0, :len(offs)] = offs; offb[0, len(offs):] = offs[-1]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        d_ids = t(ids[None])
+        claim = ctx.associate(t(mpb), t(np.array([len(mp)], np.int32)), t(c2.reshape(1, 12)), w, h, t(nodes[None]), t(kp[None]), t(desc[None]),
+                              t(np.array([n_kp], np.int32)), t(offb), t(od[None]), d_ids)
+        ctx.synchronize()
+        ref_ids, ref_claim = oracle.associate(mp, c2, w, h, nodes, kp, desc, offs, od, ids)
+        assert np.array_equal(claim.cpu().numpy()[0, :len(mp)], ref_claim), name
+        assert np.array_equal(d_ids.cpu().numpy()[0], ref_ids), name
+        if name == "behind one keypoint":
+            assert ref_claim[0] == 5 and (ref_claim[1:] == -1).all()
+        elif name != "empty map":
+            assert (ref_claim == -1).all(), name

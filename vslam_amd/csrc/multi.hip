@@ -383,7 +383,26 @@ struct vslam_comm {
     ncclComm_t comm = nullptr;
     int world = 0, rank = 0;
     int device = 0;   // the device of the context it was made on: RCCL calls want it current
+    // One communicator may serve several contexts of its device (a pipeline's batches in flight, each on its own stream).  Its
+    // collectives then follow one another in issue order whatever stream they are on: each waits for the event recorded behind
+    // the one before it, so no two of them are ever in progress at once -- nothing is left to how RCCL orders them internally.
+    hipEvent_t last = nullptr;
+    hipStream_t last_stream = nullptr;
 };
+
+// in front of a collective on `stream`: behind the communicator's previous one if that went to another stream
+static hipError_t comm_order_before(vslam_comm *c, hipStream_t stream) {
+    if (c->last && c->last_stream != stream) return hipStreamWaitEvent(stream, c->last, 0);
+    return hipSuccess;
+}
+static hipError_t comm_order_after(vslam_comm *c, hipStream_t stream) {
+    if (!c->last) {
+        const hipError_t e = hipEventCreateWithFlags(&c->last, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    c->last_stream = stream;
+    return hipEventRecord(c->last, stream);
+}
 
 extern "C" {
 
@@ -429,6 +448,7 @@ int vslam_comm_destroy(vslam_comm *c) {
         (void)hipSetDevice(c->device);
         rccl().destroy(c->comm);
     }
+    if (c->last) (void)hipEventDestroy(c->last);
     delete c;
     return VSLAM_OK;
 }
@@ -447,11 +467,13 @@ int vslam_gather_records(vslam_ctx *ctx, vslam_comm *comm, const int32_t *d_reco
     VS_REQUIRE(ctx, comm && comm->comm && d_records && d_all && words_per_rank > 0, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, comm->device == ctx->device, VSLAM_ERR_INVALID);
     VS_HIP(ctx, hipSetDevice(ctx->device));
+    VS_HIP(ctx, comm_order_before(comm, ctx->stream));
     const ncclResult_t rc = rccl().all_gather(d_records, d_all, words_per_rank, ncclInt32, comm->comm, ctx->stream);
     if (rc != ncclSuccess) {
         ctx->err = std::string("ncclAllGather: ") + rccl().err_string(rc);
         return VSLAM_ERR_COMM;
     }
+    VS_HIP(ctx, comm_order_after(comm, ctx->stream));
     return VSLAM_OK;
 }
 
@@ -474,6 +496,7 @@ int vslam_gather_records_v(vslam_ctx *ctx, vslam_comm *comm, const int32_t *d_re
     if (receiver && h_words[me])   // the own block does not travel
         VS_HIP(ctx, hipMemcpyAsync(d_all + my_off, d_records, 4 * h_words[me], hipMemcpyDeviceToDevice, ctx->stream));
     if (world == 1) return VSLAM_OK;
+    VS_HIP(ctx, comm_order_before(comm, ctx->stream));
     ncclResult_t rc = r.group_start();
     size_t off = 0;
     for (int q = 0; q < world && rc == ncclSuccess; q++) {
@@ -489,6 +512,7 @@ int vslam_gather_records_v(vslam_ctx *ctx, vslam_comm *comm, const int32_t *d_re
         ctx->err = std::string("vslam_gather_records_v (ncclSend / ncclRecv): ") + r.err_string(rc);
         return VSLAM_ERR_COMM;
     }
+    VS_HIP(ctx, comm_order_after(comm, ctx->stream));
     return VSLAM_OK;
 }
 
