@@ -1049,6 +1049,15 @@ def main():
                                               "omitted (null) for a kernel whose source file, or the shared headers, changed since"}
         result["kernels"] = kernels
         result["profile_pass_ms_per_step"] = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels)
+        busy_ms = sum(k["valu_busy_frac"] * k["ms_per_launch"] * k["launches_per_step"] for k in kernels if "valu_busy_frac" in k)
+        if busy_ms > 0:
+            # The step against the ceiling that binds it: every kernel's launch time weighted by the share of the chip's vector-pipe
+            # time it fills (calibrated, from the committed SQ pass) = the time the step's vector instructions need on a chip whose
+            # pipes never idle; divided by the step's wall time with batches in flight.  The path is arithmetic-bound:
+            # this, not an HBM fraction, says how close the whole step runs to what its instruction stream allows.
+            result["step_vector_pipe"] = {"busy_ms_per_step": busy_ms, "ms_per_step": ms_step, "frac": busy_ms / ms_step,
+                                          "what": "sum over the step's kernels of (calibrated vector-pipe share x launch time) / wall time "
+                                                  "per step with the batches in flight"}
 
     # ---- the oracle on the timed batches' own bytes: parity of what was timed -- a share from EVERY context -- and the CPU baseline
     if rank == 0:
