@@ -19,3 +19,8 @@ def test_matcher_on_random_ragged_batches(ctx, ctx_exp, oracle):
 def test_ransac_kernels_on_random_and_degenerate_inputs(ctx, oracle):
     import fuzz_ransac
     assert fuzz_ransac.run(ctx, oracle, seed=20261005, cases=400) == 400
+
+
+def test_grid_extractor_on_random_shapes_grids_and_content(ctx, oracle):
+    import fuzz_grid
+    assert fuzz_grid.run(ctx, oracle, seed=20261008, cases=60) == 60
