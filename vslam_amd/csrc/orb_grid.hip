@@ -235,18 +235,6 @@ __global__ __launch_bounds__(256) void resize_tables_kernel(Geom G, uint32_t *__
     }
 }
 
-// One output pixel from rows r0 / r1 of the source; x0 = the source column that r0[0] / r1[0] hold
-__device__ __forceinline__ uint32_t resize_px(const uint8_t *r0, const uint8_t *r1, int x0, int sw, uint32_t xt, uint32_t y0c,
-                                              uint32_t y1c) {
-    const int xo = (int)(xt & 0xffffu);
-    const uint32_t x1c = xt >> 16, x0c = 256u - x1c;
-    const int xb = min(xo + 1, sw - 1);
-    const uint32_t h0 = (uint32_t)r0[xo - x0] * x0c + (uint32_t)r0[xb - x0] * x1c;
-    const uint32_t h1 = (uint32_t)r1[xo - x0] * x0c + (uint32_t)r1[xb - x0] * x1c;
-    const uint32_t v = h0 * y0c + h1 * y1c;
-    return (v + (1u << 15)) >> 16;
-}
-
 // the index set {reflect101(t, n) : a <= t <= b} is the interval [lo, hi]
 __device__ __forceinline__ void reflect_range(int a, int b, int n, int &lo, int &hi) {
     const int ra = reflect101(a, n), rb = reflect101(b, n);
@@ -255,10 +243,11 @@ __device__ __forceinline__ void reflect_range(int a, int b, int n, int &lo, int 
 }
 
 // Level l of every frame's pyramid (kFrame: with its reflect margin) or of every cell's pyramid from level l - 1.  A workgroup
-// makes a 64 x 32 tile, a lane 4 pixels x 2 rows.  The source pixels a tile touches form a box of about 83 x 45; it is
-// fetched as (unaligned) dwords into LDS and the four taps per pixel are LDS byte reads: per-lane byte gathers from global
-// memory cost a wave 16 address cycles each, and the per-lane coefficient look-ups are shared by the lane's rows.
-constexpr int kRTW = 64, kRTH = 32, kRBW = 112, kRBH = 48;   // tile; box capacity (row pitch kRBW bytes)
+// makes a 64 x 64 tile, a lane 4 pixels x 4 rows: the x-side of the interpolation (tap offsets, coefficients) is formed once per
+// lane and serves its four rows.  The source pixels a tile touches form a box of about 83 x 83; it is fetched as (unaligned)
+// dwords into LDS and the four taps per pixel are LDS byte reads: per-lane byte gathers from global memory cost a wave 16
+// address cycles each.  The kernel is held by its vector instructions (0.76 of the pipes at 43 per pixel in the 2-row form).
+constexpr int kRTW = 64, kRTH = 64, kRPR = 4, kRBW = 112, kRBH = 88;   // tile; rows per lane; box capacity (row pitch kRBW bytes)
 
 template <bool kFrame>
 __device__ __forceinline__ void pyr_resize_tile(const Geom &G, int l, int block, int tiles_x, int tiles_per_img, uint32_t *box,
@@ -287,15 +276,19 @@ __device__ __forceinline__ void pyr_resize_tile(const Geom &G, int l, int block,
         D = cpyr + (size_t)img * G.cunit + G.coff[l];
     }
     const int out_w4 = os >> 2;
-    // this lane: dword column gx of the stored rows gy0, gy0 + 1; image coordinates differ by the margin
-    const int gx = tx * (kRTW / 4) + g, gy0 = ty * kRTH + 2 * rg;
-    const bool mine = gx < out_w4 && gy0 < out_h, two = gy0 + 1 < out_h;
+    // this lane: dword column gx of the stored rows gy0 .. gy0 + 3; image coordinates differ by the margin
+    const int gx = tx * (kRTW / 4) + g, gy0 = ty * kRTH + kRPR * rg;
+    const bool mine = gx < out_w4 && gy0 < out_h;
     // per-lane coefficients first: these loads and the box loads below are then in flight together
-    uint32_t yt[2] = {0, 0}, xt[4] = {0, 0, 0, 0};
+    uint32_t yt[kRPR], xt[4];
+#pragma unroll
+    for (int j = 0; j < kRPR; j++) yt[j] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) xt[k] = 0;
     if (mine) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int gy = two ? gy0 + j : gy0;
+        for (int j = 0; j < kRPR; j++) {
+            const int gy = min(gy0 + j, out_h - 1);
             yt[j] = tab[tY + (kFrame ? reflect101(gy - my, lh) : gy)];
         }
 #pragma unroll
@@ -335,21 +328,41 @@ __device__ __forceinline__ void pyr_resize_tile(const Geom &G, int l, int block,
     }
     __syncthreads();
     if (!mine) return;
+    // x side, once for the lane's rows: tap offsets relative to the row base, second-tap offsets, coefficients
+    int xa_[4], xb_[4];
+    uint32_t x0c[4], x1c[4];
+    const int xbase = staged ? bx0 : 0;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        if (j == 1 && !two) break;
+    for (int k = 0; k < 4; k++) {
+        const int xo = (int)(xt[k] & 0xffffu);
+        x1c[k] = xt[k] >> 16;
+        x0c[k] = 256u - x1c[k];
+        xa_[k] = xo - xbase;
+        xb_[k] = min(xo + 1, sw - 1) - xbase;
+    }
+    const uint8_t *bb = reinterpret_cast<const uint8_t *>(box);
+#pragma unroll
+    for (int j = 0; j < kRPR; j++) {
+        if (gy0 + j >= out_h) break;
         const int yo = (int)(yt[j] & 0xffffu), yb = min(yo + 1, sh - 1);
         const uint32_t y1c = yt[j] >> 16, y0c = 256u - y1c;
         uint32_t out = 0;
         if (staged) {   // two code paths, not one pointer: LDS reads stay LDS reads (and no LDS offset ever goes negative)
-            const uint8_t *bb = reinterpret_cast<const uint8_t *>(box);
             const uint8_t *r0 = bb + (yo - by0) * kRBW, *r1 = bb + (yb - by0) * kRBW;
 #pragma unroll
-            for (int k = 0; k < 4; k++) out |= resize_px(r0, r1, bx0, sw, xt[k], y0c, y1c) << (8 * k);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t h0 = (uint32_t)r0[xa_[k]] * x0c[k] + (uint32_t)r0[xb_[k]] * x1c[k];
+                const uint32_t h1 = (uint32_t)r1[xa_[k]] * x0c[k] + (uint32_t)r1[xb_[k]] * x1c[k];
+                out |= ((h0 * y0c + h1 * y1c + (1u << 15)) >> 16) << (8 * k);
+            }
         } else {
             const uint8_t *r0 = S + (size_t)yo * ss, *r1 = S + (size_t)yb * ss;
 #pragma unroll
-            for (int k = 0; k < 4; k++) out |= resize_px(r0, r1, 0, sw, xt[k], y0c, y1c) << (8 * k);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t h0 = (uint32_t)r0[xa_[k]] * x0c[k] + (uint32_t)r0[xb_[k]] * x1c[k];
+                const uint32_t h1 = (uint32_t)r1[xa_[k]] * x0c[k] + (uint32_t)r1[xb_[k]] * x1c[k];
+                out |= ((h0 * y0c + h1 * y1c + (1u << 15)) >> 16) << (8 * k);
+            }
         }
         *reinterpret_cast<uint32_t *>(D + (size_t)(gy0 + j) * os + 4 * gx) = out;
     }
