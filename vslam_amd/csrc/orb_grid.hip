@@ -1062,6 +1062,9 @@ __device__ __forceinline__ void sincos_deg_pinned(float angle_deg, float &s_out,
     c_out = (float)c;
 }
 
+// the descriptor kernel's LDS patch: sampling discs of up to this radius (ORB's table: 20), row pitch, bytes per half wave
+constexpr int kPatchR = 24, kPatchPitch = 56, kPatchBytes = (2 * kPatchR + 1) * kPatchPitch;
+
 // largest distance of a pattern point from the patch centre, rounded up, + 1: no rotated and rounded sample lies farther out
 __global__ __launch_bounds__(512) void pattern_radius_kernel(const int8_t *__restrict__ pattern, int32_t *__restrict__ radius) {
     __shared__ int s_max;
@@ -1095,6 +1098,7 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, uint
     // all workgroups of a frame on one XCD: its gray image, blurred image and pyramids (a few MB) then stay in that XCD's L2
     // while the frame's keypoints gather from them (dealt round-robin, every XCD would stream every frame: 3.4 KB of HBM
     // traffic per keypoint measured)
+    __shared__ __align__(16) uint8_t s_patch[8 * kPatchBytes];
     int f, blk;
     vs_xcd_item_block(blockIdx.x, per_frame, f, blk);
     if (f >= frames) return;
@@ -1163,7 +1167,39 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, uint
     // offset of the frame level's pixel (0, 0): in `blurred`, and (levels >= 1) of the unblurred level in fpyr
     const uint32_t lbase = l == 0 ? (uint32_t)f * (uint32_t)(G.w * G.h) : gbytes + (uint32_t)f * (uint32_t)G.fframe + (uint32_t)(fo + 3 * fs + 4);
     uint32_t val = 0;
-    if (cx - R >= 0 && cx + R < lw && cy - R >= 0 && cy + R < lh) {
+    const bool inside = cx - R >= 0 && cx + R < lw && cy - R >= 0 && cy + R < lh;
+    if (inside && R <= kPatchR) {
+        // The sampling disc as a (2R + 1)^2 patch in LDS, one per half wave: the half fetches it as (unaligned) dwords row by row --
+        // a dozen loads per lane, consecutive lanes on consecutive addresses -- and the 16 samples of a lane are LDS byte reads;
+        // the same 16 as per-lane byte gathers from global memory cost the wave 16 address cycles each.
+        const int half = (tid >> 5) & 7;
+        uint8_t *patch = s_patch + half * kPatchBytes;
+        const int side = 2 * R + 1, dpr = (side + 3) >> 2;          // dwords per patch row
+        const uint32_t org = lbase + (uint32_t)(cy - R) * (uint32_t)fs + (uint32_t)(cx - R);
+        const uint32_t mD = 0xffffffffu / (uint32_t)dpr + 1u;
+        const int nd = side * dpr;
+        for (int i = byte; i < nd; i += 32) {
+            const int r = (int)__umulhi((uint32_t)i, mD), cdw = i - r * dpr;
+            uint32_t v;
+            __builtin_memcpy(&v, blurred + org + (uint32_t)(r * fs + 4 * cdw), 4);
+            reinterpret_cast<uint32_t *>(patch)[r * (kPatchPitch / 4) + cdw] = v;
+        }
+        vs_sel::wave_sync_lds();
+        const uint8_t *pc = patch + R * kPatchPitch + R;
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const int pp = pat8[bit];
+            int t[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float fx = (float)(int8_t)(pp >> (16 * e)), fy = (float)(int8_t)(pp >> (16 * e + 8));
+                const float a1 = fx * a, a2 = fy * b, b1 = fx * b, b2 = fy * a;
+                const float rx = a1 - a2, ry = b1 + b2;
+                t[e] = pc[(int)rintf(ry) * kPatchPitch + (int)rintf(rx)];
+            }
+            val |= (uint32_t)(t[0] < t[1]) << bit;
+        }
+    } else if (inside) {
         const uint32_t cbl = lbase + (uint32_t)cy * (uint32_t)fs + (uint32_t)cx;
 #pragma unroll
         for (int bit = 0; bit < 8; bit++) {
