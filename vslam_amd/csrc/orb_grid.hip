@@ -461,7 +461,7 @@ __host__ __device__ inline int fast_strip_rows(int rw, int bytes) {
 // One workgroup per (unit, level); blocks are level-major so the large levels start first.
 // lists [unit][t][slot] hold (raster index in the inner region) << 8 | M; cnt0 [unit][t][8] their lengths;
 // c1_20 [unit][8] = length of the threshold-20 list after the first retainBest (from the score histogram).
-__global__ __launch_bounds__(256) void fast_collect_kernel(Geom G, int units, int lds_bytes, const uint8_t *__restrict__ gray,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void fast_collect_kernel(Geom G, int units, int lds_bytes, const uint8_t *__restrict__ gray,
                                                            const uint8_t *__restrict__ cpyr, uint32_t *__restrict__ lists,
                                                            int32_t *__restrict__ cnt0, int32_t *__restrict__ c1_20) {
     extern __shared__ __align__(16) unsigned char smem[];
