@@ -108,3 +108,53 @@ def test_association_edge_cases(ctx, oracle):
             assert ref_claim[0] == 5 and (ref_claim[1:] == -1).all()
         elif name != "empty map":
             assert (ref_claim == -1).all(), name
+
+
+@pytest.mark.parametrize("radius,fill", [(2.0, 0.0), (2.05, 0.3), (2.05, 0.7)])
+def test_association_long_claim_chains(ctx, oracle, radius, fill):
+    """Keypoints on a one-pixel lattice, every descriptor acceptable, several map points per keypoint: each map point lists
+    9-13 hits and most of them are contended, so the claims cascade (a map point loses its first hits to lower indices and
+    takes a later one, which a higher index then finds taken). The assignment must still be the sequential loop's."""
+    w, h = 160, 120
+    rng = np.random.default_rng(int(radius * 100) + int(fill * 100))
+    gx, gy = np.meshgrid(np.arange(20, 60), np.arange(30, 70))
+    kp = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    rng.shuffle(kp)
+    n_kp = len(kp)
+    proto = rng.integers(0, 256, 32, dtype=np.uint8)
+    desc = np.repeat(proto[None], n_kp, 0)
+    desc[:, 0] ^= rng.integers(0, 256, n_kp, dtype=np.uint8)              # <= 8 bits from the prototype
+    nodes = oracle.kdtree_build_frame(kp)
+    c2 = np.array([[525, 0, w // 2, 0], [0, 525, h // 2, 0], [0, 0, 1, 0]], np.float32)
+    items = []
+    for n_map in (4000, 700, 64, 1):
+        px = np.stack([rng.uniform(18, 62, n_map), rng.uniform(28, 72, n_map)], 1)
+        z = rng.uniform(2, 6, n_map)
+        mp = np.stack([(px[:, 0] - w // 2) / 525.0 * z, (px[:, 1] - h // 2) / 525.0 * z, z, np.ones(n_map)], 1).astype(np.float32)
+        offs = np.arange(n_map + 1, dtype=np.int32)
+        od = np.repeat(proto[None], n_map, 0)
+        ids = np.full(n_kp, -1, np.int32)
+        ids[rng.random(n_kp) < fill] = 7
+        items.append((mp, offs, od, ids))
+    B = len(items); Mp = max(len(i[0]) for i in items)
+    mpb = np.zeros((B, Mp, 4), np.float32); offb = np.zeros((B, Mp + 1), np.int32); odb = np.zeros((B, Mp, 32), np.uint8)
+    idb = np.full((B, n_kp), -1, np.int32); nm = np.zeros(B, np.int32)
+    for b, (mp, offs, od, ids) in enumerate(items):
+        m = len(mp)
+        mpb[b, :m], offb[b, :m + 1], odb[b, :m], idb[b], nm[b] = mp, offs, od, ids, m
+        offb[b, m + 1:] = offs[-1]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rep = lambda a: t(np.repeat(a[None], B, 0))
+    d_ids = t(idb)
+    claim = ctx.associate(t(mpb), t(nm), rep(c2.reshape(12)), w, h, rep(nodes), rep(kp), rep(desc), t(np.full(B, n_kp, np.int32)),
+                          t(offb), t(odb), d_ids, radius=radius)
+    ctx.synchronize()
+    claim, got = claim.cpu().numpy(), d_ids.cpu().numpy()
+    later = 0
+    for b, (mp, offs, od, ids) in enumerate(items):
+        ref_ids, ref_claim = oracle.associate(mp, c2, w, h, nodes, kp, desc, offs, od, ids, radius=radius)
+        assert np.array_equal(claim[b, :len(mp)], ref_claim), b
+        assert np.array_equal(got[b], ref_ids), b
+        later += int((ref_claim >= 0).sum())
+    free = int((items[0][3] < 0).sum())
+    assert (claim[0, :4000] >= 0).sum() > 0.9 * free, "the big item should use up nearly every free keypoint"

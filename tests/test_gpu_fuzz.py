@@ -24,3 +24,8 @@ def test_ransac_kernels_on_random_and_degenerate_inputs(ctx, oracle):
 def test_grid_extractor_on_random_shapes_grids_and_content(ctx, oracle):
     import fuzz_grid
     assert fuzz_grid.run(ctx, oracle, seed=20261008, cases=60) == 60
+
+
+def test_fuzz_assoc_slice(ctx, oracle):
+    import fuzz_assoc
+    assert fuzz_assoc.run(ctx, oracle, seed=20261009, cases=40) == 40

@@ -10,9 +10,8 @@
 //                            GEMM_2_T), tree walk in visit order, min-Hamming per hit; emits the
 //                            ordered list of ACCEPTABLE hits (distance under threshold).
 //   assoc_resolve_kernel     the reference loop is sequential (a claim hides the keypoint from later
-//                            map points), so one wave per item walks the map points in order; the 64
-//                            candidate lists of a chunk are fetched in parallel, the claims themselves
-//                            go through an LDS bitmask lane by lane, skipping lanes with nothing to claim.
+//                            map points); one workgroup per item reaches the same assignment in a few
+//                            parallel rounds (see the kernel's comment for why the result is identical).
 #include "ctx.h"
 
 namespace {
@@ -98,58 +97,91 @@ __global__ __launch_bounds__(kAT) void assoc_candidates_kernel(
     cand_cnt[(size_t)b * map_stride + i] = cnt < kCandCap ? cnt : kCandCap;
 }
 
-__global__ __launch_bounds__(64) void assoc_resolve_kernel(const int32_t *__restrict__ n_map, int map_stride,
-                                                           const int32_t *__restrict__ n_kp, int kp_stride,
-                                                           const int32_t *__restrict__ cand,
-                                                           const int32_t *__restrict__ cand_cnt,
-                                                           int32_t *__restrict__ map_point_ids, int32_t *__restrict__ claim) {
-    extern __shared__ uint32_t taken[];   // one bit per keypoint: assigned before or claimed so far
-    const int b = blockIdx.x, lane = threadIdx.x;
+constexpr int kRT = 256;   // threads of assoc_resolve_kernel: one workgroup per item
+
+// The reference loop is sequential: map point i takes the first acceptable hit no earlier map point holds.
+// The same assignment falls out of rounds that are parallel inside. U = map points still undecided,
+// taken = keypoints assigned before or by a decided claim, owner[k] = the lowest index in U that lists k
+// among its free hits. A map point whose first free hit k has owner[k] == itself is decided: every
+// lower-indexed map point that lists k is decided already and did not take it, and every hit it skipped
+// is held by a lower index (a higher index can never be decided on a keypoint a lower undecided one
+// lists). A map point with no free hit left is decided as unassociated, since `taken` only grows. The
+// lowest index in U is always decided, so the rounds end; on real maps two or three rounds settle
+// everything where the one-at-a-time walk needed one step per map point.
+__global__ __launch_bounds__(kRT) void assoc_resolve_kernel(const int32_t *__restrict__ n_map, int map_stride,
+                                                            const int32_t *__restrict__ n_kp, int kp_stride,
+                                                            const int32_t *__restrict__ cand,
+                                                            const int32_t *__restrict__ cand_cnt,
+                                                            int32_t *__restrict__ map_point_ids, int32_t *__restrict__ claim) {
+    extern __shared__ uint32_t lds[];
+    const int words = (kp_stride + 31) / 32;
+    uint32_t *taken = lds;            // one bit per keypoint
+    int32_t *owner = reinterpret_cast<int32_t *>(lds + ((words + 1) & ~1));   // one entry per keypoint
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n = n_map[b], nk = n_kp[b];
     int32_t *ids = map_point_ids + (size_t)b * kp_stride;
-    const int words = (kp_stride + 31) / 32;
-    for (int wd = lane; wd < words; wd += 64) {
-        uint32_t bits = 0;
-        for (int k = 0; k < 32; k++) {
-            const int idx = wd * 32 + k;
-            if (idx < nk && ids[idx] >= 0) bits |= 1u << k;   // `if (frame.map_point_ids[idx] >= 0) continue`
+    int32_t *mine = claim + (size_t)b * map_stride;
+    const int32_t *cnts = cand_cnt + (size_t)b * map_stride;
+    const int4 *lists = reinterpret_cast<const int4 *>(cand + (size_t)b * map_stride * kCandCap);
+    constexpr int32_t kUndecided = -2, kNobody = 0x7FFFFFFF;
+
+    for (int base = 0; base < words * 32; base += kRT) {   // `if (frame.map_point_ids[idx] >= 0) continue`
+        const int idx = base + tid;
+        const unsigned long long set = __ballot(idx < nk && ids[idx] >= 0);
+        if (lane == 0) {
+            const int wd = (base + (tid & ~63)) >> 5;
+            if (wd < words) taken[wd] = (uint32_t)set;
+            if (wd + 1 < words) taken[wd + 1] = (uint32_t)(set >> 32);
         }
-        taken[wd] = bits;
+        if (idx < kp_stride) owner[idx] = kNobody;
     }
+    for (int i = tid; i < n; i += kRT) mine[i] = cnts[i] > 0 ? kUndecided : -1;
     __syncthreads();
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        int cnt = 0;
-        int32_t my[kCandCap];
-        if (i < n) {
-            cnt = cand_cnt[(size_t)b * map_stride + i];
-            const int32_t *src = cand + ((size_t)b * map_stride + i) * kCandCap;
+
+    for (;;) {
+        for (int i = tid; i < n; i += kRT) {   // lowest undecided index per free keypoint
+            if (mine[i] != kUndecided) continue;
+            const int cnt = cnts[i];
+            int4 q[kCandCap / 4];
 #pragma unroll
-            for (int k = 0; k < kCandCap; k++) my[k] = k < cnt ? src[k] : -1;
-        }
-        int mine = -1;
-        unsigned long long todo = __ballot(cnt > 0);
-        while (todo) {   // map points in index order; only those with something to claim
-            const int l = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            if (lane == l) {
+            for (int k = 0; k < kCandCap / 4; k++) q[k] = lists[(size_t)i * (kCandCap / 4) + k];
+            const int32_t *c = reinterpret_cast<const int32_t *>(q);
 #pragma unroll
-                for (int k = 0; k < kCandCap; k++) {
-                    const int idx = my[k];
-                    if (idx < 0 || mine >= 0) continue;
-                    const uint32_t bit = 1u << (idx & 31);
-                    if (!(taken[idx >> 5] & bit)) {
-                        taken[idx >> 5] |= bit;
-                        mine = idx;
-                    }
-                }
+            for (int k = 0; k < kCandCap; k++) {
+                if (k >= cnt) continue;
+                const int idx = c[k];
+                if (!(taken[idx >> 5] & (1u << (idx & 31)))) atomicMin(&owner[idx], i);
             }
-            __syncthreads();   // single-wave workgroup: orders lane l's LDS update before lane l+1's read
         }
-        if (i < n) {
-            claim[(size_t)b * map_stride + i] = mine;
-            if (mine >= 0) ids[mine] = i;   // frame.map_point_ids[idx] = i, src/vslam.cpp:154
+        __syncthreads();
+        int undecided = 0;
+        for (int i = tid; i < n; i += kRT) {
+            if (mine[i] != kUndecided) continue;
+            const int cnt = cnts[i];
+            int4 q[kCandCap / 4];
+#pragma unroll
+            for (int k = 0; k < kCandCap / 4; k++) q[k] = lists[(size_t)i * (kCandCap / 4) + k];
+            const int32_t *c = reinterpret_cast<const int32_t *>(q);
+            int first = -1;
+#pragma unroll
+            for (int k = 0; k < kCandCap; k++) {
+                if (k >= cnt || first >= 0) continue;
+                const int idx = c[k];
+                if (!(taken[idx >> 5] & (1u << (idx & 31)))) first = idx;
+            }
+            if (first < 0) {
+                mine[i] = -1;
+            } else if (owner[first] == i) {
+                atomicOr(&taken[first >> 5], 1u << (first & 31));
+                mine[i] = first;
+                ids[first] = i;   // frame.map_point_ids[idx] = i, src/vslam.cpp:154
+            } else {
+                undecided = 1;
+            }
         }
+        if (!__syncthreads_or(undecided)) break;
+        for (int idx = tid; idx < kp_stride; idx += kRT) owner[idx] = kNobody;   // owners are per round
+        __syncthreads();
     }
 }
 
@@ -176,8 +208,9 @@ int vs_launch_associate(vslam_ctx *ctx, const float *map_points, const int32_t *
     }
     {
         VsProfScope ps(ctx, "assoc_resolve_kernel");
-        const size_t lds = sizeof(uint32_t) * (size_t)((kp_stride + 31) / 32);
-        assoc_resolve_kernel<<<batch, 64, lds, ctx->stream>>>(n_map, map_stride, n_kp, kp_stride, cand, cand_cnt, map_point_ids,
+        const size_t words = (size_t)((kp_stride + 31) / 32);
+        const size_t lds = sizeof(uint32_t) * (((words + 1) & ~(size_t)1) + (size_t)kp_stride);
+        assoc_resolve_kernel<<<batch, kRT, lds, ctx->stream>>>(n_map, map_stride, n_kp, kp_stride, cand, cand_cnt, map_point_ids,
                                                               claim);
     }
     VS_HIP(ctx, hipGetLastError());
