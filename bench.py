@@ -1274,7 +1274,7 @@ def main():
                     if not (np.array_equal(hc[b_, :kk], ref_claim) and np.array_equal(hid[b_, :nk], ref_ids)):
                         bad_a.append(b_)
                 entry["association"] = {"what": "vslam_associate_map_points: each pair's triangulated inliers as map points (one observation each), radius 2, threshold 64",
-                                        "ms_per_batch": ms_assoc, "kernels_ms_per_launch": {nm: rep3[nm][0] / max(rep3[nm][1], 1) for nm in rep3},
+                                        "ms_per_batch": ms_assoc, "kernels_ms_per_launch": {nm: rep3[nm][0] / max(rep3[nm][1], 1) for nm in rep3 if rep3[nm][1] > 0},
                                         "map_points_per_pair": float(n_map.float().mean()),
                                         "claimed_per_pair": float((claim >= 0).float().sum(1).mean()),
                                         "parity_in_bench": {"pairs": min(P, 4), "bit_exact": not bad_a}}
