@@ -33,6 +33,7 @@ __global__ __launch_bounds__(kAT) void assoc_candidates_kernel(
     const uint8_t *__restrict__ obs_desc, int obs_stride, float radius, uint32_t dist_threshold,
     int32_t *__restrict__ cand, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ errflag) {
     __shared__ uint32_t stack[kAStack * kAT];
+    __shared__ int32_t stack_idx[kAStack * kAT];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int i = blockIdx.x * kAT + tid;
     if (i >= n_map[b]) return;
@@ -57,20 +58,29 @@ __global__ __launch_bounds__(kAT) void assoc_candidates_kernel(
         const uint8_t *OD = obs_desc + (size_t)b * obs_stride * VSLAM_DESC_BYTES;
         const int o0 = OO[i], o1 = OO[i + 1];
         const float radius_sq = radius * radius;
+        // A visit costs one memory round trip, not two: the children's positions follow from (pos, len) alone, so their
+        // point indices are fetched beside the node's own point and travel on the stack with the entries.
         int sp = 0;
-        if (n > 0) stack[(sp++) * kAT + tid] = 0u | ((uint32_t)n << 15);
+        if (n > 0) {
+            stack[tid] = 0u | ((uint32_t)n << 15);
+            stack_idx[tid] = T[0];
+            sp = 1;
+        }
         while (sp > 0) {
-            const uint32_t e = stack[(--sp) * kAT + tid];
+            --sp;
+            const uint32_t e = stack[sp * kAT + tid];
+            const int idx = stack_idx[sp * kAT + tid];
             const int pos = (int)(e & 0x7FFFu), len = (int)((e >> 15) & 0x7FFFu), axis = (int)(e >> 30);
-            const int idx = T[pos];
+            const int nl = len / 2, nr = len - nl - 1;
+            const int il = nl > 0 ? T[pos + 1] : 0, ir = nr > 0 ? T[pos + 1 + nl] : 0;
             const float2 pt = Pt[idx];
             const float split = (axis == 0 ? qx : qy) - (axis == 0 ? pt.x : pt.y);
-            const int nl = len / 2, nr = len - nl - 1;
             const uint32_t nax = (uint32_t)(1 - axis) << 30;
             const uint32_t le = (uint32_t)(pos + 1) | ((uint32_t)nl << 15) | nax;
             const uint32_t re = (uint32_t)(pos + 1 + nl) | ((uint32_t)nr << 15) | nax;
             const float abs_split = (split > 0) ? split : -split;
-            if (abs_split <= radius) {
+            const bool both = abs_split <= radius;
+            if (both) {
                 const float dx = qx - pt.x, dy = qy - pt.y;
                 if (dx * dx + dy * dy < radius_sq) {
                     uint32_t mn = 0xFFFFFFFFu;   // orb_distance: min over the stored observations
@@ -85,12 +95,16 @@ __global__ __launch_bounds__(kAT) void assoc_candidates_kernel(
                         cnt++;
                     }
                 }
-                if (nr > 0) stack[(sp++) * kAT + tid] = re;
-                if (nl > 0) stack[(sp++) * kAT + tid] = le;
-            } else if (split < 0) {
-                if (nl > 0) stack[(sp++) * kAT + tid] = le;
-            } else {
-                if (nr > 0) stack[(sp++) * kAT + tid] = re;
+            }
+            if ((both || !(split < 0)) && nr > 0) {   // left is visited first: it goes on the stack last
+                stack[sp * kAT + tid] = re;
+                stack_idx[sp * kAT + tid] = ir;
+                sp++;
+            }
+            if ((both || split < 0) && nl > 0) {
+                stack[sp * kAT + tid] = le;
+                stack_idx[sp * kAT + tid] = il;
+                sp++;
             }
         }
     }
