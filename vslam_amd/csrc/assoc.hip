@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kAT) void assoc_candidates_kernel(
     int cnt = 0;
     int32_t *out = cand + ((size_t)b * map_stride + i) * kCandCap;
     if (qx >= 0 && qx < (float)img_w && qy >= 0 && qy < (float)img_h) {
-        const int n = n_kp[b];
+        const int n = min(n_kp[b], kp_stride);
         const float2 *Pt = reinterpret_cast<const float2 *>(xy) + (size_t)b * kp_stride;
         const int32_t *T = nodes + (size_t)b * kp_stride;
         const uint8_t *D = desc + (size_t)b * kp_stride * VSLAM_DESC_BYTES;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kRT) void assoc_resolve_kernel(const int32_t *__res
     uint32_t *taken = lds;            // one bit per keypoint
     int32_t *owner = reinterpret_cast<int32_t *>(lds + ((words + 1) & ~1));   // one entry per keypoint
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int n = n_map[b], nk = n_kp[b];
+    const int n = min(n_map[b], map_stride), nk = min(n_kp[b], kp_stride);   // a count beyond its stride would reach into the next item
     int32_t *ids = map_point_ids + (size_t)b * kp_stride;
     int32_t *mine = claim + (size_t)b * map_stride;
     const int32_t *cnts = cand_cnt + (size_t)b * map_stride;
