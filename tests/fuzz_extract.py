@@ -67,7 +67,7 @@ def run(ctx, o, seed, cases=None, seconds=None):
                 rd, keep = o.orb_describe(bl[f], pts[f], ca, sa, pat)
                 assert no[f] == len(keep) and np.array_equal(de[f, :len(keep)], rd), ("descriptors", w, h, f)
         if w >= 4 and h >= 4 and rng.random() < 0.5:
-            # the whole of extract_features from 3-byte rows (cvtColor inside the detector when the rows are dword-aligned,
+            # the whole of extract_features from 3-byte rows (cvtColor inside the detector when the width is a multiple of 4,
             # a launch of its own otherwise): colours whose gray values are the content above plus a colour cast, rows
             # with random padding
             cast = rng.integers(-40, 41, (n, h, w, 3))

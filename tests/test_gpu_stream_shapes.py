@@ -89,12 +89,16 @@ def test_describe_other_rotations_and_wide_patterns(ctx, oracle, angle_deg, scal
         assert np.array_equal(desc[f, :len(keep)], rd), f
 
 
-# The detector's first kernel is cvtColor as well when the rows are dword-aligned (response.hip: the BGR form of
+# The detector's first kernel is cvtColor as well for widths that are a multiple of 4 (response.hip: the BGR form of
 # min_eigen_tiered_kernel): strips that end inside / at / beyond the image, one-strip and many-strip widths, heights of one
 # and several row segments (a segment's first rows convert rows of the segment above again), padded rows, and rows whose
-# padding breaks the alignment (cvtColor then is a launch of its own).
+# padding breaks the alignment (unaligned 12-byte loads in the same kernel).
 BGR_SHAPES = [(64, 64, 0), (252, 140, 0), (256, 91, 0), (260, 136, 4), (264, 181, 0), (516, 271, 8), (772, 96, 0), (1028, 70, 0),
-              (1924, 75, 0), (260, 136, 2), (516, 100, 1)]
+              (1924, 75, 0), (260, 136, 2), (516, 100, 1),
+              # widths that are no multiple of 4: gray / blurred planes with padded rows (mirrored tail), the last column in
+              # every position of a lane's four pixels, in the first lane of a strip of its own (257, 1281) and in the last (255)
+              (65, 64, 0), (253, 140, 0), (254, 91, 0), (255, 70, 0), (257, 136, 0), (258, 100, 3), (259, 181, 0), (515, 271, 0),
+              (1277, 96, 0), (1278, 75, 1), (1279, 70, 0), (1281, 70, 0)]
 
 
 @pytest.mark.parametrize("w,h,pad", BGR_SHAPES)

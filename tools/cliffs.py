@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """The documented performance cliffs, timed: layouts and content that leave the fast paths.
 One context, one batch after the other, 64 pairs of about 1280 x 720, 2000 keypoints, 4096 hypotheses.
-  * width not a multiple of 4: the plain whole-image corner pipeline and the per-keypoint descriptor kernel;
-  * rows not dword-aligned (row stride 3 w + 1): bgr2gray as a launch of its own in front of the gray-input detector;
+  * width not a multiple of 4: until round 6 the plain whole-image corner pipeline and the per-keypoint descriptor kernel,
+    now padded internal rows (vslam_ctx::img_pitch) under the same kernels;
+  * rows not dword-aligned (row stride 3 w + 1): until round 6 bgr2gray as a launch of its own in front of the gray-input
+    detector, now the fused detector on unaligned loads;
   * noise frames: every frame overflows the bounded corner lists; up to the pool's sets are redone from whole-image scratch,
     beyond that the call fails with VSLAM_ERR_CAPACITY and has to be repeated with VSLAM_OPT_CORNER_LIST_CAP = -1.
     python tools/cliffs.py"""

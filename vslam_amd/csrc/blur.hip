@@ -188,6 +188,13 @@ int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VS_REQUIRE(ctx, gray && out, VSLAM_ERR_INVALID);
     VS_REQUIRE(ctx, frames > 0 && w >= 4 && h >= 4, VSLAM_ERR_INVALID);
     VsProfScope ps(ctx, "gaussian7_kernel");
+    if (vs_pitch(ctx, w) != w) {
+        // Padded rows (vslam_ctx::img_pitch): at least three mirrored columns follow column w - 1, which is all a 7-tap row
+        // filter with BORDER_REFLECT_101 reads past it, so the padded plane filtered as an image of `pitch` columns holds the
+        // image's result in its first w columns (its own mirroring happens at column pitch - 1, three or more columns away).
+        w = vs_pitch(ctx, w);
+        VS_REQUIRE(ctx, w % 4 == 0, VSLAM_ERR_INVALID);
+    }
     if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
         const int strips = vs_div_up(w, 256);
         const int segs = vs_stream_segments(h, frames, strips);

@@ -417,6 +417,11 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
     static const bool patch_form = VS_EXPERIMENT_ENV("VSLAM_RBRIEF_PATCH") != nullptr;
     int tw = kTW, th = kTH;
     if (const char *e = VS_EXPERIMENT_ENV("VSLAM_RBRIEF_TILE")) sscanf(e, "%dx%d", &tw, &th);   // A/B timing
+    // Rows of the blurred plane may be longer than the image is wide (vslam_ctx::img_pitch: a mirrored tail nobody samples,
+    // keypoints keep 31 pixels from the image's border).  The kernels address and tile the plane by its rows, `wl`; only the
+    // border rule below sees the image's width.
+    const int w_img = w;
+    w = vs_pitch(ctx, w);
     while (vs_div_up(w, tw) * vs_div_up(h, th) > kTilesMax) {
         tw *= 2;
         th *= 2;
@@ -434,7 +439,7 @@ int vs_launch_orb_describe(vslam_ctx *ctx, const uint8_t *blurred, int frames, i
     }
     {
         VsProfScope ps(ctx, "keypoint_border_kernel");
-        keypoint_border_kernel<<<frames, kKT, 0, ctx->stream>>>(xy_in, n_in, kp_stride, w, h, xy_out, n_out, tw, th, tiles_x, ntiles,
+        keypoint_border_kernel<<<frames, kKT, 0, ctx->stream>>>(xy_in, n_in, kp_stride, w_img, h, xy_out, n_out, tw, th, tiles_x, ntiles,
                                                                 tile_start, tile_kp);
     }
     {

@@ -653,7 +653,7 @@ int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int
 // an error return in between, the next call would otherwise skip work it needs.  Cleared on every exit.
 struct VsTableGuard {
     vslam_ctx *c;
-    ~VsTableGuard() { c->rbrief_table_ready = false; c->fork_after_eigen = false; }
+    ~VsTableGuard() { c->rbrief_table_ready = false; c->fork_after_eigen = false; c->img_pitch = 0; }
 };
 struct VsPrefetchGuard {
     vslam_ctx *c;
@@ -675,7 +675,13 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
         params = &with_table;
     }
     VS_REQUIRE(ctx, params->max_corners > 0 && params->max_corners <= kp_stride, VSLAM_ERR_INVALID);
-    const size_t px = (size_t)frames * width * height;
+    // A width that is no multiple of 4 leaves the dword kernels (two-tier detector, streaming blur, tile-staged descriptors)
+    // without aligned rows.  The internal gray and blurred planes then get rows of a multiple of 16 bytes, at least 3 longer
+    // than the image is wide, the tail holding the row's BORDER_REFLECT_101 continuation (written by cvtColor): the same
+    // kernels run on those rows and what they produce below column `width` is what the image alone would give
+    // (blur.hip, response.hip: the one place that needs a correction is the sign of a mirrored x-derivative).
+    if (width % 4 != 0 && width >= 64) ctx->img_pitch = (width + 3 + 15) & ~15;
+    const size_t px = (size_t)frames * vs_pitch(ctx, width) * height;
     uint8_t *gray = nullptr, *blur = nullptr;
     float *xy_det = nullptr;
     int32_t *n_det = nullptr;
@@ -705,7 +711,7 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
         // waves arrive: queued at the head of the auxiliary stream instead (round 5, tools/ab_lib.py, same process,
         // alternating) the blur starts at the fork and the step is unchanged with one batch in flight (2.950 vs 2.950 ms) and
         // SLOWER with three (2.764 -> 2.800 ms on the hard data, 2.604 -> 2.664 on the easy data).
-        if (overlap && width % 4 == 0)
+        if (overlap && vs_pitch(ctx, width) % 4 == 0)
             rc = vs_launch_rbrief_rotate(ctx, params->d_pattern, params->cos_a, params->sin_a);
         if (rc == VSLAM_OK)
             rc = vs_launch_gaussian7(ctx, gray, frames, width, height, blur);                            // ORB::compute

@@ -55,6 +55,9 @@ struct vslam_ctx {
     bool sets_prefetch = true;  // VSLAM_SETS_PREFETCH: the raw mt19937 outputs generated ahead of time on the auxiliary stream
     bool fork_after_eigen = false;   // transient: good_features records ev_fork once the response kernel is queued
     bool rbrief_table_ready = false; // transient: the rotated rBRIEF table of the coming describe call is already queued
+    int img_pitch = 0;               // transient (vslam_extract_features): bytes per row of the call's internal gray / blurred planes when that is
+                                     // not the width -- a width that is no multiple of 4 gets rows of a multiple of 16 bytes whose tail holds the
+                                     // REFLECT_101 continuation of the row, so that the dword kernels take it; 0: rows are `width` bytes
     int ransac_min_matches = VSLAM_SET_SIZE;   // VSLAM_OPT_RANSAC_MIN_MATCHES
     int ransac_min_items = VSLAM_SET_SIZE;     // VSLAM_OPT_RANSAC_MIN_ITEMS: indices drawn per 8-wide set
     int ransac_solver = 0;                      // VSLAM_OPT_RANSAC_SOLVER: 0 exact Jacobi replay, 1 Gram / MFMA (not bit-exact)
@@ -124,6 +127,8 @@ struct VsProfScope {
 };
 
 static inline int vs_div_up(int a, int b) { return (a + b - 1) / b; }
+// bytes per row of the internal gray / blurred planes of the running extract call (vslam_ctx::img_pitch)
+static inline int vs_pitch(const vslam_ctx *ctx, int w) { return ctx->img_pitch > 0 ? ctx->img_pitch : w; }
 
 // A/B switches (slower kernel variants, stream arrangements, tile shapes measured and not chosen) exist only in the
 // EXPERIMENTS build of the library (-DVSLAM_EXPERIMENTS -> libvslam_amd_exp.so, which tools/ab_*.py and the variant tests load

@@ -40,6 +40,35 @@ __global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t *__restrict
     }
 }
 
+// The same conversion into rows of `pitch` >= w + 3 bytes (pitch % 4 == 0): columns [w, pitch) hold the row's
+// BORDER_REFLECT_101 continuation (column w + k = column w - 2 - k), which is what a filter reading past the last column
+// would be handed.  For widths that are no multiple of 4: the dword kernels downstream run on the padded rows and what they
+// produce for the columns below w is what they would produce for the image alone.  One lane = 4 output bytes.
+__global__ __launch_bounds__(256) void bgr2gray_padded_kernel(const uint8_t *__restrict__ bgr, int w, int h, int stride,
+                                                              uint8_t *__restrict__ gray, int pitch) {
+    const int f = blockIdx.y;
+    const int qpr = pitch >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * h) return;
+    const int y = q / qpr, x = (q - y * qpr) * 4;
+    const uint8_t *row = bgr + ((size_t)f * h + y) * stride;
+    uint32_t out;
+    if (x + 3 < w) {   // twelve bytes of four whole pixels, wherever they start
+        uint32_t d[3];
+        __builtin_memcpy(d, row + 3 * x, 12);
+        const uint32_t a = d[0], b = d[1], c = d[2];   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        out = gray_of(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF) | (gray_of(a >> 24, b & 0xFF, (b >> 8) & 0xFF) << 8) |
+              (gray_of((b >> 16) & 0xFF, b >> 24, c & 0xFF) << 16) | (gray_of((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24) << 24);
+    } else {
+        out = 0;
+        for (int i = 0; i < 4; i++) {
+            const int sx = reflect101(x + i, w);
+            out |= gray_of(row[3 * sx], row[3 * sx + 1], row[3 * sx + 2]) << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(gray + ((size_t)f * h + y) * pitch + x) = out;
+}
+
 }  // namespace
 
 int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, int h, int stride,
@@ -49,6 +78,14 @@ int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, in
     const int aligned = (stride % 4 == 0) && (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(bgr) & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && (((size_t)h * stride) % 4 == 0);
     VsProfScope ps(ctx, "bgr2gray_kernel");
+    const int pitch = vs_pitch(ctx, w);
+    if (pitch != w) {   // padded rows (vslam_ctx::img_pitch)
+        VS_REQUIRE(ctx, pitch % 4 == 0 && pitch >= w + 3 && pitch - w < w - 1 && (reinterpret_cast<uintptr_t>(gray) & 3) == 0, VSLAM_ERR_INVALID);
+        dim3 pgrid(vs_div_up((pitch / 4) * h, 256), frames);
+        bgr2gray_padded_kernel<<<pgrid, 256, 0, ctx->stream>>>(bgr, w, h, stride, gray, pitch);
+        VS_HIP(ctx, hipGetLastError());
+        return VSLAM_OK;
+    }
     dim3 grid(vs_div_up(((w + 3) / 4) * h, 256 * kGrayIter), frames);
     bgr2gray_kernel<<<grid, 256, 0, ctx->stream>>>(bgr, w, h, stride, gray, aligned);
     VS_HIP(ctx, hipGetLastError());

@@ -104,11 +104,12 @@ __device__ __forceinline__ float min_eigen_from_sums(double Sxx, double Sxy, dou
 
 // A pixel whose 5x5 gray window lies inside the image (2 <= x < w - 2, 2 <= y < h - 2): float Sobel with the scale
 // folded into the smoothing taps, products, horizontal sums then vertical in double.
-__device__ __forceinline__ float min_eigen_exact_interior(const uint8_t *src, int w, int x, int y, float k0, float k1) {
+// (`pitch` = bytes per row of src; `w` = the image's width)
+__device__ __forceinline__ float min_eigen_exact_interior(const uint8_t *src, int pitch, int x, int y, float k0, float k1) {
     float g[5][5];
 #pragma unroll
     for (int r = 0; r < 5; r++) {
-        const uint8_t *p = src + (size_t)(y - 2 + r) * w + (x - 2);
+        const uint8_t *p = src + (size_t)(y - 2 + r) * pitch + (x - 2);
         uint32_t d;
         __builtin_memcpy(&d, p, 4);
         g[r][0] = cvt_ubyte<0>(d); g[r][1] = cvt_ubyte<1>(d); g[r][2] = cvt_ubyte<2>(d); g[r][3] = cvt_ubyte<3>(d);
@@ -147,7 +148,7 @@ __device__ __forceinline__ float min_eigen_exact_interior(const uint8_t *src, in
 
 // Any pixel: the box filter's BORDER_REFLECT_101 on product coordinates, the Sobel's on gray coordinates.  Rolled
 // loops on purpose (rare path, small code); the sums accumulate in the oracle's order.
-__device__ __forceinline__ float min_eigen_exact_border(const uint8_t *src, int w, int h, int x, int y, float k0, float k1) {
+__device__ __forceinline__ float min_eigen_exact_border(const uint8_t *src, int pitch, int w, int h, int x, int y, float k0, float k1) {
     double Sxx = 0, Sxy = 0, Syy = 0;
 #pragma nounroll
     for (int r = 0; r < 3; r++) {
@@ -159,7 +160,7 @@ __device__ __forceinline__ float min_eigen_exact_border(const uint8_t *src, int 
             float hx[3], rr[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const uint8_t *row = src + (size_t)reflect101(py - 1 + k, h) * w;
+                const uint8_t *row = src + (size_t)reflect101(py - 1 + k, h) * pitch;
                 const float gm = (float)row[xm], g0 = (float)row[px], gp = (float)row[xp];
                 hx[k] = gp - gm;
                 const float a = g0 * k0;
@@ -183,9 +184,9 @@ __device__ __forceinline__ float min_eigen_exact_border(const uint8_t *src, int 
     return min_eigen_from_sums(Sxx, Sxy, Syy);
 }
 
-__device__ __forceinline__ float min_eigen_exact(const uint8_t *src, int w, int h, int x, int y, float k0, float k1) {
-    if (x >= 2 && x < w - 2 && y >= 2 && y < h - 2) return min_eigen_exact_interior(src, w, x, y, k0, k1);
-    return min_eigen_exact_border(src, w, h, x, y, k0, k1);
+__device__ __forceinline__ float min_eigen_exact(const uint8_t *src, int pitch, int w, int h, int x, int y, float k0, float k1) {
+    if (x >= 2 && x < w - 2 && y >= 2 && y < h - 2) return min_eigen_exact_interior(src, pitch, x, y, k0, k1);
+    return min_eigen_exact_border(src, pitch, w, h, x, y, k0, k1);
 }
 
 }  // namespace

@@ -19,22 +19,29 @@ constexpr int kETW = 64, kETH = 16;   // output tile
 constexpr int kGW = kETW + 4, kGH = kETH + 4;   // gray tile (halo 2)
 constexpr int kHW = kETW + 2;                   // hx / R / cov width (halo 1)
 
-__global__ __launch_bounds__(kET) void min_eigen_kernel(const uint8_t *__restrict__ gray, int w, int h,
+// `pitch` = bytes per gray row (eig rows are w floats).  With pool.count set, blockIdx.z is a slot of the corner pipeline's
+// fallback pool, as in min_eigen_v4_kernel below.
+__global__ __launch_bounds__(kET) void min_eigen_kernel(const uint8_t *__restrict__ gray, int w, int h, int pitch,
                                                         float *__restrict__ eig,
-                                                        uint32_t *__restrict__ frame_max) {
+                                                        uint32_t *__restrict__ frame_max, const VsCornerPool pool) {
     __shared__ uint8_t G[kGH][kGW];
     __shared__ float HX[kGH][kHW], RR[kGH][kHW];
     __shared__ float CXX[kETH + 2][kHW], CXY[kETH + 2][kHW], CYY[kETH + 2][kHW];
     __shared__ uint32_t s_max;
-    const int f = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int f = blockIdx.z, fin = f;   // f: where the outputs go; fin: the frame read
+    if (pool.count) {
+        if (f >= vs_pool_used(pool)) return;
+        fin = pool.frame[f];
+    }
     const int x0 = blockIdx.x * kETW, y0 = blockIdx.y * kETH;
-    const uint8_t *src = gray + (size_t)f * w * h;
+    const uint8_t *src = gray + (size_t)fin * pitch * h;
     if (tid == 0) s_max = 0;
 
     // gray tile at raw coordinates [x0-2, x0+TW+2) x [y0-2, y0+TH+2), REFLECT_101 filled
     for (int i = tid; i < kGH * kGW; i += kET) {
         const int r = i / kGW, c = i - r * kGW;
-        G[r][c] = src[(size_t)reflect101(y0 - 2 + r, h) * w + reflect101(x0 - 2 + c, w)];
+        G[r][c] = src[(size_t)reflect101(y0 - 2 + r, h) * pitch + reflect101(x0 - 2 + c, w)];
     }
     __syncthreads();
 
@@ -340,14 +347,15 @@ struct TierArgs {
     uint32_t *count;
     size_t cap;
     int w, h, ys, ye, x, steps;
-    int bstride;                     // BGR input: bytes per row of src
+    int bstride;                     // bytes per row of src (the gray form's rows may be longer than w: vslam_ctx::img_pitch)
     uint8_t *gout;                   // BGR input: this frame's gray image (written for the rows [ys, ye))
     const uint32_t *halo;            // BGR input, LDS: per row of the wave's segment the gray pixels left / right of the strip
     uint32_t voff_l, voff_c, voff_r;
     bool edge, left_fix, right_fix, own_lane;
+    unsigned long long own;          // owned lanes
+    bool flip2, flip3, flip4;        // padded gray rows (w % 4 != 0): this lane's column 2 / 3 / 4 of six is the image's column w
     unsigned long long cand_ok[4];   // lanes whose pixel i is an owned candidate position (1 <= x < w - 1)
     unsigned long long bord[4];      // lanes whose pixel i is an owned first / last column
-    unsigned long long own;          // owned lanes
     float thrU;                      // lower bound of the final threshold, U units (-inf: none yet)
     float lowU;                      // certified lower bound of the frame maximum, U units
     float qf;                        // quality level, a hair low
@@ -449,7 +457,7 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
     g[6] = cvt_ubyte<0>(d2); g[7] = cvt_ubyte<1>(d2);
     if constexpr (!BGR) {   // prefetch two rows ahead into the slot just consumed (see the other form above)
         const int tn = t + 2 < a.steps ? t + 2 : a.steps - 1;
-        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.w;
+        const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + tn, a.h) * a.bstride;
         uint32_t ol = a.voff_l, oc = a.voff_c, orr = a.voff_r;
         asm volatile("" : "+v"(ol), "+v"(oc), "+v"(orr) : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]));
         st.raw[P][0] = *reinterpret_cast<const uint32_t *>(rowp + ol);
@@ -479,9 +487,17 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
 #pragma unroll
     for (int c = 0; c < 6; c++) dx[c] = st.q[Q][c] + st.q[P][c];   // hx(p-1) + 2 hx(p) + hx(p+1)
     float dx0 = dx[0], dx5 = dx[5];   // for the xy products only: a mirrored column changes that product's sign
+    float dx2 = dx[2], dx3 = dx[3], dx4 = dx[4];
     if (a.edge) {
         if (a.left_fix) dx0 = -dx0;
         if (a.right_fix) dx5 = -dx5;
+        // Padded rows: the bytes behind the last column are the row's mirror image, so column w of the derivatives is the
+        // mirrored column w - 2 (the one the box filter's own REFLECT_101 asks for at column w - 1) up to the sign of dx.
+        if constexpr (!BGR) {   // (the BGR form takes packed rows only: nothing of this in its code)
+            if (a.flip2) dx2 = -dx2;
+            if (a.flip3) dx3 = -dx3;
+            if (a.flip4) dx4 = -dx4;
+        }
     }
     float (&r)[12] = st.X[P];
     const float (&rp)[12] = st.X[Q];
@@ -491,11 +507,11 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
         r[1] = (a1 + a2) + a3;
         r[2] = __builtin_fmaf(dx[4], dx[4], a2 + a3);
         r[3] = __builtin_fmaf(dx[5], dx[5], __builtin_fmaf(dx[4], dx[4], a3));
-        const float b1 = dx[1] * dy[1], b2 = dx[2] * dy[2], b3 = dx[3] * dy[3];
+        const float b1 = dx[1] * dy[1], b2 = dx2 * dy[2], b3 = dx3 * dy[3];
         r[4] = __builtin_fmaf(dx0, dy[0], b1) + b2;
         r[5] = (b1 + b2) + b3;
-        r[6] = __builtin_fmaf(dx[4], dy[4], b2 + b3);
-        r[7] = __builtin_fmaf(dx5, dy[5], __builtin_fmaf(dx[4], dy[4], b3));
+        r[6] = __builtin_fmaf(dx4, dy[4], b2 + b3);
+        r[7] = __builtin_fmaf(dx5, dy[5], __builtin_fmaf(dx4, dy[4], b3));
         const float c1 = dy[1] * dy[1], c2 = dy[2] * dy[2], c3 = dy[3] * dy[3];
         r[8] = __builtin_fmaf(dy[0], dy[0], c1) + c2;
         r[9] = (c1 + c2) + c3;
@@ -531,7 +547,14 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
             const float tm = max3_nonan(st.trm[P], st.trm[Q], trn);
             const float m2 = __builtin_fmaf(kTierSqrt, __builtin_amdgcn_sqrtf(tm), __builtin_fmaf(kTierLin, tm, kTierAbs));
             const float (&v)[4] = st.ctr[Q];
-            st.lanelow = max3_nonan(st.lanelow, max3_nonan(v[0], v[1], v[2]) - m2, v[3] - m2);
+            if (!BGR && a.edge) {   // a lane across the last column (padded rows): its pixels behind the image certify nothing
+                float vin[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) vin[i] = (((a.cand_ok[i] | a.bord[i]) >> lane) & 1ull) ? v[i] : -__builtin_inff();
+                st.lanelow = max3_nonan(st.lanelow, max3_nonan(vin[0], vin[1], vin[2]) - m2, vin[3] - m2);
+            } else {
+                st.lanelow = max3_nonan(st.lanelow, max3_nonan(v[0], v[1], v[2]) - m2, v[3] - m2);
+            }
             const bool brow = ty == 0 || ty == a.h - 1;   // uniform
             if (brow) tier_tighten(a, st.lanelow, lane);   // this row's pixels only count for the maximum: know it first
 #pragma unroll
@@ -544,7 +567,7 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
                     bal = __builtin_amdgcn_fcmpf(vp, m8, 3) & a.cand_ok[i];   // 3 = ordered >=
                     if (a.edge && (i == 0 || i == 3)) bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & a.bord[i];
                 } else {
-                    bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & a.own;
+                    bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & (BGR ? a.own : (a.cand_ok[i] | a.bord[i]));   // the lane's pixels inside the image
                 }
                 const unsigned long long both = bal | bmax;
                 if (both) {
@@ -578,7 +601,8 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
 // Tier 1: U~ for every pixel; the possible pixels go to list[f][0 .. counts[f]) as raw entries (image_common.h; the
 // upper bound in units of c0); low_max[f] collects the certified lower bound of the frame maximum (ordered float, same
 // units) that the waves share, hist[f][] counts the entries by upper bound.
-// BGR: `src` is the 3-byte image (bstride bytes per row, rows and base dword-aligned) and the kernel is cvtColor as well:
+// BGR: `src` is the 3-byte image (bstride bytes per row; rows that do not start on a dword cost nothing measurable: the lane's
+// 12 bytes are one unaligned global_load_dwordx3) and the kernel is cvtColor as well:
 // it forms the gray rows it needs from the lane's own 12 bytes, hands the neighbour pixels across lanes, and writes the
 // rows it owns to gray_out for the stages that follow (blur, exact tier) — bgr2gray's 0.30 ms of pure HBM time are paid
 // here as ≈ 25 vector instructions per row on top of 225, while the kernel's loads wait behind its arithmetic anyway.
@@ -604,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     a.steps = a.ye - a.ys + 6;
     a.w = w;
     a.h = h;
-    a.src = src + (size_t)f * h * (BGR ? (size_t)bstride : (size_t)w);
+    a.src = src + (size_t)f * h * (size_t)bstride;
     a.bstride = bstride;
     a.gout = BGR ? gray_out + (size_t)f * w * h : nullptr;
     a.queue = queue[wave];
@@ -625,13 +649,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     a.edge = x0 == 0 || x0 + kSW + 4 > w;
     a.left_fix = a.x == 0;
     a.right_fix = a.x + 4 == w;
-    const int xc = a.x < 0 ? 0 : (a.x > w - 4 ? w - 4 : a.x);
+    a.flip2 = w - a.x == 1;   // (never with w % 4 == 0)
+    a.flip3 = w - a.x == 2;
+    a.flip4 = w - a.x == 3;
+    const int lw = BGR ? w : bstride;   // what a row holds: the gray form's rows may carry a mirrored tail
+    const int xc = a.x < 0 ? 0 : (a.x > lw - 4 ? lw - 4 : a.x);
     if constexpr (BGR) {   // the lane's 12 bytes
         a.voff_c = (uint32_t)(3 * xc);
     } else {
         a.voff_c = (uint32_t)xc;
         a.voff_l = (uint32_t)(xc - 4 < 0 ? 0 : xc - 4);
-        a.voff_r = (uint32_t)(xc + 4 > w - 4 ? w - 4 : xc + 4);
+        a.voff_r = (uint32_t)(xc + 4 > lw - 4 ? lw - 4 : xc + 4);
     }
     if constexpr (BGR) {
         // The two gray pixels on either side of the strip, for every row this wave will visit: 4 x steps <= 576 pixels, up to
@@ -678,7 +706,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const uint32_t *vp = reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
             st.raw[k][0] = vp[0]; st.raw[k][1] = vp[1]; st.raw[k][2] = vp[2];
         } else {
-            const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * w;
+            const uint8_t *rowp = a.src + (size_t)reflect101(a.ys - 3 + k, h) * bstride;
             st.raw[k][0] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_l);
             st.raw[k][1] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_c);
             st.raw[k][2] = *reinterpret_cast<const uint32_t *>(rowp + a.voff_r);
@@ -737,7 +765,7 @@ struct ExactWave {
     unsigned long long *out;
     uint32_t *out_count;
     size_t cap;
-    int w, h;
+    int w, h, pitch;   // pitch: bytes per row of src
     float k0, k1;
     int q1n, q2n, kqn;
     float emax;   // per lane
@@ -815,9 +843,9 @@ __device__ __forceinline__ void exact_rounds(ExactWave &x, int lane, bool all) {
         }
         const bool inner = px >= 2 && px < x.w - 2 && py >= 2 && py < x.h - 2;
         float e = ninf;
-        if (have && inner) e = min_eigen_exact_interior(x.src, x.w, px, py, x.k0, x.k1);
+        if (have && inner) e = min_eigen_exact_interior(x.src, x.pitch, px, py, x.k0, x.k1);
         if (__builtin_expect(__any(have && !inner), 0)) {   // rare: pixels whose window leaves the image
-            if (have && !inner) e = min_eigen_exact_border(x.src, x.w, x.h, px, py, x.k0, x.k1);
+            if (have && !inner) e = min_eigen_exact_border(x.src, x.pitch, x.w, x.h, px, py, x.k0, x.k1);
         }
         x.emax = e > x.emax ? e : x.emax;   // e = -inf where there was nothing to evaluate
         if (mode == 1) {
@@ -843,7 +871,7 @@ __device__ __forceinline__ void exact_rounds(ExactWave &x, int lane, bool all) {
     if (all) exact_flush_keys(x, lane);
 }
 
-__global__ __launch_bounds__(256) void corner_exact_kernel(const uint8_t *__restrict__ gray, int w, int h,
+__global__ __launch_bounds__(256) void corner_exact_kernel(const uint8_t *__restrict__ gray, int w, int h, int pitch,
                                                            const unsigned long long *__restrict__ list,
                                                            const uint32_t *__restrict__ counts, size_t cap,
                                                            const uint32_t *__restrict__ hist, const uint32_t *__restrict__ low_max,
@@ -899,7 +927,8 @@ __global__ __launch_bounds__(256) void corner_exact_kernel(const uint8_t *__rest
     }
 
     ExactWave x;
-    x.src = gray + (size_t)f * w * h;
+    x.src = gray + (size_t)f * pitch * h;
+    x.pitch = pitch;
     x.lds = &lds[wave];
     x.out = keys2 + (size_t)f * cap;
     x.out_count = count2 + f;
@@ -1015,12 +1044,12 @@ int vs_launch_min_eigen(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, 
     VS_REQUIRE(ctx, frames > 0 && w >= 3 && h >= 3, VSLAM_ERR_INVALID);
     if (frame_max_bits) VS_HIP(ctx, hipMemsetAsync(frame_max_bits, 0, sizeof(uint32_t) * (size_t)frames, ctx->stream));
     VsProfScope ps(ctx, "min_eigen_kernel");
-    if (w % 4 == 0 && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && ((reinterpret_cast<uintptr_t>(eig) & 15) == 0)) {
+    if (w % 4 == 0 && vs_pitch(ctx, w) == w && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0) && ((reinterpret_cast<uintptr_t>(eig) & 15) == 0)) {
         dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), frames);
         min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits, VsCornerPool{});
     } else {
         dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), frames);
-        min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, eig, frame_max_bits);
+        min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, vs_pitch(ctx, w), eig, frame_max_bits, VsCornerPool{});
     }
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;
@@ -1038,12 +1067,13 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
                                   unsigned long long *keys2, size_t key_cap, uint32_t n_safe, int *raw_list,
                                   const VsBgrSource *bgr) {
     int rc;
-    const bool fused = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
+    const int gp = vs_pitch(ctx, w);   // bytes per gray row: w, or longer with a mirrored tail (vslam_ctx::img_pitch)
+    const bool fused = (gp % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
     *raw_list = fused ? 1 : 0;
-    // the gray image has not been formed yet (bgr != nullptr): the two-tier detector does it on the way when the rows
-    // are dword-aligned, a cvtColor launch in front otherwise
+    // the gray image has not been formed yet (bgr != nullptr): the two-tier detector does it on the way for packed gray
+    // rows (width % 4 == 0, any row stride of the source), a cvtColor launch in front writes padded rows otherwise
     static const char *const nofuse = VS_EXPERIMENT_ENV("VSLAM_NO_GRAY_FUSION");
-    const bool from_bgr = bgr && fused && !nofuse && bgr->stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr->data) & 3) == 0 &&
+    const bool from_bgr = bgr && fused && gp == w && !nofuse &&
                           vs_div_up(h, vs_stream_segments(h, frames, vs_div_up(w, kSW))) + 6 <= kTierMaxSteps;
     if (bgr && !from_bgr)
         if ((rc = vs_launch_bgr2gray(ctx, bgr->data, frames, w, h, bgr->stride, const_cast<uint8_t *>(gray)))) return rc;
@@ -1064,7 +1094,7 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
             const int seg_rows = vs_div_up(h, segs);
             const int per_frame = strips * vs_div_up(segs, 4);
             min_eigen_tiered_kernel<false><<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
-                gray, 0, nullptr, w, h, c.low, c.hist, quality, keys, c.counts, key_cap, seg_rows, frames, strips, per_frame);
+                gray, gp, nullptr, w, h, c.low, c.hist, quality, keys, c.counts, key_cap, seg_rows, frames, strips, per_frame);
         }
         // A frame whose maximum response is not positive has no corners (its threshold max * quality lies at or above
         // every response, THRESH_TOZERO clears the image and zeros are not corners); the selection's exact threshold
@@ -1086,8 +1116,13 @@ int vs_launch_response_candidates(vslam_ctx *ctx, const uint8_t *gray, int frame
 // is empty (two launches of a few thousand idle workgroups).
 int vs_launch_pool_candidates(vslam_ctx *ctx, const uint8_t *gray, int w, int h, double quality, const VsCornerPool &pool) {
     VsProfScope ps(ctx, "corner_rerun_kernels");
-    dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), pool.slots);
-    min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, pool.eig, pool.fmax, pool);
+    if (vs_pitch(ctx, w) != w) {   // padded gray rows: the any-width kernel reads them
+        dim3 grid(vs_div_up(w, kETW), vs_div_up(h, kETH), pool.slots);
+        min_eigen_kernel<<<grid, kET, 0, ctx->stream>>>(gray, w, h, vs_pitch(ctx, w), pool.eig, pool.fmax, pool);
+    } else {
+        dim3 grid(vs_div_up(w, kE4W), vs_div_up(h, kE4H), pool.slots);
+        min_eigen_v4_kernel<<<grid, 256, 0, ctx->stream>>>(gray, w, h, pool.eig, pool.fmax, pool);
+    }
     const int rows = vs_div_up(h, kCTH);
     dim3 grid2(vs_div_up(w, kCTW), rows < 4 ? rows : 4, pool.slots);
     corner_candidates_kernel<<<grid2, kCT, 0, ctx->stream>>>(pool.eig, w, h, pool.fmax, quality, pool.keys, pool.counts, pool.key_cap, pool);
@@ -1103,7 +1138,7 @@ int vs_launch_corner_exact(vslam_ctx *ctx, const uint8_t *gray, int frames, int 
     static const char *const pf_env = VS_EXPERIMENT_ENV("VSLAM_CORNER_EXACT_WGS");
     const int per_frame = pf_env ? atoi(pf_env) : 4;
     corner_exact_kernel<<<vs_xcd_grid(frames, per_frame), 256, 0, ctx->stream>>>(
-        gray, w, h, keys, c.counts, key_cap, c.hist, c.low, n_safe, keys2, mode == 0 ? c.count2 : c.count3, c.fmax, c.cutkey,
+        gray, w, h, vs_pitch(ctx, w), keys, c.counts, key_cap, c.hist, c.low, n_safe, keys2, mode == 0 ? c.count2 : c.count3, c.fmax, c.cutkey,
         c.need, mode, frames, per_frame);
     VS_HIP(ctx, hipGetLastError());
     return VSLAM_OK;

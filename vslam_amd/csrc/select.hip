@@ -838,7 +838,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     uint8_t *state = nullptr;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int rc;
-    // The two-tier detector (width % 4 == 0, the usual case) keeps BOUNDED per-frame lists: the detector lists about
+    // The two-tier detector (gray rows of a multiple of 4 bytes: width % 4 == 0, or padded rows) keeps BOUNDED per-frame lists: the detector lists about
     // 10 x max_corners pixels on image data, so 16 x max_corners + 4096 entries hold a frame's list with room to spare
     // (VSLAM_OPT_CORNER_LIST_CAP: another bound; -1: the whole image, which nothing can overflow).  A frame that does
     // overflow it (response plateaus, noise: every interior pixel can be listed), or whose selection needs per-pixel maps
@@ -846,7 +846,7 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     // exact pipeline (pass 2 below): results never depend on the bound.  Should more frames of one call need the pool
     // than it has slots, those frames get no corners and vslam_ctx_synchronize reports VSLAM_ERR_CAPACITY.
     // Other widths run the plain pipeline on whole-image buffers for every frame, as before.
-    const bool two_tier = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
+    const bool two_tier = (vs_pitch(ctx, w) % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);   // (as vs_launch_response_candidates decides)
     size_t key_cap = px;
     if (two_tier && ctx->corner_list_cap >= 0) {
         const size_t want = ctx->corner_list_cap > 0 ? (size_t)ctx->corner_list_cap : 16 * (size_t)max_corners + 4096;
