@@ -48,6 +48,7 @@ constexpr int kThr[2] = {20, 5};  // list t = 0: fastThreshold 20, t = 1: the fa
 
 struct Geom {
     int w, h, cw, ch, ncols, nrows, cells;
+    int gp;    // bytes per row of the gray frame and its blurred twin: w, or (w % 4 != 0) a multiple of 16 >= w + 3 whose tail mirrors the row
     int nlv;   // levels that can hold keypoints: both sides of the cell's level > 62
     float scale[kMaxLevels];
     // cell pyramid: level 0 = window of the gray frame; levels 1..nlv-1 tight, row stride a multiple of 4
@@ -65,6 +66,7 @@ int make_geom(int w, int h, int nrows, int ncols, Geom &G) {
     G = Geom{};
     G.w = w;
     G.h = h;
+    G.gp = (w % 4 == 0 || w < 64) ? w : (w + 3 + 15) & ~15;
     G.ncols = ncols;
     G.nrows = nrows;
     G.cells = nrows * ncols;
@@ -88,10 +90,10 @@ int make_geom(int w, int h, int nrows, int ncols, Geom &G) {
     int co = 0, fo = 0, lo = 0, to = 0;
     G.loff[0] = 0;
     for (int l = 0; l < G.nlv; l++) {
-        G.cstride[l] = l == 0 ? w : (G.clw[l] + 3) & ~3;
+        G.cstride[l] = l == 0 ? G.gp : (G.clw[l] + 3) & ~3;
         G.coff[l] = co;
         if (l > 0) co += G.cstride[l] * G.clh[l];
-        G.fstride[l] = l == 0 ? w : ((G.flw[l] + 3) & ~3) + 8;
+        G.fstride[l] = l == 0 ? G.gp : ((G.flw[l] + 3) & ~3) + 8;
         G.foff[l] = fo;
         if (l > 0) fo += G.fstride[l] * (G.flh[l] + 6);
         // NMS survivors are isolated: at most ceil(rw / 2) * ceil(rh / 2) of them
@@ -138,7 +140,7 @@ __device__ __forceinline__ const uint8_t *cell_level(const Geom &G, const uint8_
     if (l == 0) {
         const int f = u / G.cells, c = u - f * G.cells;
         const int ci = c / G.nrows, cj = c - ci * G.nrows;
-        return gray + (size_t)f * G.w * G.h + (size_t)(cj * G.ch) * G.w + ci * G.cw;
+        return gray + (size_t)f * G.gp * G.h + (size_t)(cj * G.ch) * G.gp + ci * G.cw;
     }
     return cpyr + (size_t)u * G.cunit + G.coff[l];
 }
@@ -199,6 +201,38 @@ __global__ __launch_bounds__(256) void grid_outline_gray4_kernel(uint8_t *__rest
         }
     }
     *reinterpret_cast<uint32_t *>(gray + ((size_t)f * h + y) * w + x) = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+}
+
+// the same into gray rows of `gp` > w bytes (gp % 4 == 0) whose tail holds the row's BORDER_REFLECT_101 continuation -- of the
+// OUTLINED image, which is what the blur that reads past the last column is applied to (Geom::gp).  A lane = 4 gray bytes.
+__global__ __launch_bounds__(256) void grid_outline_gray_padded_kernel(uint8_t *__restrict__ bgr, int w, int h, int stride,
+                                                                       int cw, int ch, int ncols, int nrows,
+                                                                       uint8_t *__restrict__ gray, int gp) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int groups = gp >> 2;
+    if (i >= groups * h) return;
+    const int y = i / groups, x = (i - y * groups) * 4;
+    uint8_t *row = bgr + ((size_t)f * h + y) * stride;
+    const bool in_rows = y < ch * nrows;
+    const int cy = y % ch;
+    const bool row_line = cy == 0 || cy == ch - 1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int sx = reflect101(x + k, w);   // the column whose value lands here
+        const uint8_t *q = row + 3 * sx;
+        uint32_t g = gray_of(q[0], q[1], q[2]);
+        if (in_rows && sx < cw * ncols) {
+            const int cx = sx % cw;
+            if (row_line || cx == 0 || cx == cw - 1) {
+                g = 0;
+                if (x + k < w) row[3 * sx] = row[3 * sx + 1] = row[3 * sx + 2] = 0;   // the image's own pixel, once
+            }
+        }
+        out |= g << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(gray + ((size_t)f * h + y) * gp + x) = out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -265,7 +299,7 @@ __device__ __forceinline__ void pyr_resize_tile(const Geom &G, int l, int block,
         sw = G.flw[l - 1]; sh = G.flh[l - 1]; ss = G.fstride[l - 1];
         tX = G.tXF[l]; tY = G.tYF[l];
         out_h = lh + 6;
-        S = l == 1 ? gray + (size_t)img * G.w * G.h : fpyr + (size_t)img * G.fframe + G.foff[l - 1] + 3 * ss + 4;
+        S = l == 1 ? gray + (size_t)img * G.gp * G.h : fpyr + (size_t)img * G.fframe + G.foff[l - 1] + 3 * ss + 4;
         D = fpyr + (size_t)img * G.fframe + G.foff[l];
     } else {
         lw = G.clw[l]; lh = G.clh[l]; os = G.cstride[l];
@@ -1134,7 +1168,7 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, uint
         uint32_t cbase;   // offset of the cell level's pixel (0, 0) in `images`
         if (l == 0) {
             const int ci = c / G.nrows, cj = c - ci * G.nrows;
-            cbase = (uint32_t)f * (uint32_t)(G.w * G.h) + (uint32_t)(cj * G.ch) * (uint32_t)G.w + (uint32_t)(ci * G.cw);
+            cbase = (uint32_t)f * (uint32_t)(G.gp * G.h) + (uint32_t)(cj * G.ch) * (uint32_t)G.gp + (uint32_t)(ci * G.cw);
         } else {
             cbase = gbytes + (uint32_t)(f * G.cells + c) * (uint32_t)G.cunit + (uint32_t)co;
         }
@@ -1165,7 +1199,7 @@ __global__ __launch_bounds__(256) void orb_desc_kernel(Geom G, UmaxTable U, uint
     sincos_deg_pinned(angle, b, a);
     const int cx = (int)rintf(k4.x * scale), cy = (int)rintf(k4.y * scale);
     // offset of the frame level's pixel (0, 0): in `blurred`, and (levels >= 1) of the unblurred level in fpyr
-    const uint32_t lbase = l == 0 ? (uint32_t)f * (uint32_t)(G.w * G.h) : gbytes + (uint32_t)f * (uint32_t)G.fframe + (uint32_t)(fo + 3 * fs + 4);
+    const uint32_t lbase = l == 0 ? (uint32_t)f * (uint32_t)(G.gp * G.h) : gbytes + (uint32_t)f * (uint32_t)G.fframe + (uint32_t)(fo + 3 * fs + 4);
     uint32_t val = 0;
     const bool inside = cx - R >= 0 && cx + R < lw && cy - R >= 0 && cy + R < lh;
     if (inside && R <= kPatchR) {
@@ -1313,7 +1347,7 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
 
     // [gray frames | cell pyramids] and [blurred frames | blurred frame pyramids] are one allocation each: the descriptor kernel
     // addresses them with one base and 32-bit offsets
-    const size_t gbytes = ((size_t)frames * w * h + 16 + 255) & ~(size_t)255;   // + slack: rows are read as dwords
+    const size_t gbytes = ((size_t)frames * G.gp * h + 16 + 255) & ~(size_t)255;   // + slack: rows are read as dwords
     const size_t images_bytes = gbytes + (size_t)G.cunit * units + 16, blurred_bytes = gbytes + (size_t)G.fframe * frames + 16;
     VS_REQUIRE(ctx, images_bytes < (1ull << 32) && blurred_bytes < (1ull << 32), VSLAM_ERR_CAPACITY);
     uint8_t *images = nullptr, *blurred = nullptr;
@@ -1323,7 +1357,10 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
     uint8_t *gray = images, *cpyr = images + gbytes, *blur0 = blurred, *fblur = blurred + gbytes;
     {   // :32 outlines into the caller's image + gray of the result (ORB converts BGR ROIs to gray)
         VsProfScope ps(ctx, "grid_outline_gray_kernel");
-        if (w % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0)
+        if (G.gp != w)
+            grid_outline_gray_padded_kernel<<<dim3(vs_div_up((G.gp / 4) * h, 256), frames), 256, 0, st>>>(bgr, w, h, stride, G.cw, G.ch,
+                                                                                                          ncols, nrows, gray, G.gp);
+        else if (w % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0)
             grid_outline_gray4_kernel<<<dim3(vs_div_up((w / 4) * h, 256), frames), 256, 0, st>>>(bgr, w, h, stride, G.cw, G.ch, ncols,
                                                                                                  nrows, gray);
         else
@@ -1411,7 +1448,10 @@ int vs_launch_extract_grid(vslam_ctx *ctx, uint8_t *bgr, int frames, int w, int 
     {   // ORB::compute (:43): per-level blur of the outlined frame's pyramid, steered BRIEF
         VsProfScope ps(ctx, "orb_compute_kernels");
         if (w >= 4 && h >= 4) {
-            if ((rc = vs_launch_gaussian7(ctx, gray, frames, w, h, blur0))) return rc;
+            ctx->img_pitch = G.gp != w ? G.gp : 0;   // padded rows: the streaming blur takes them as they are (blur.hip)
+            rc = vs_launch_gaussian7(ctx, gray, frames, w, h, blur0);
+            ctx->img_pitch = 0;
+            if (rc) return rc;
         }
         // levels >= 1 as images of fstride x (lh + 6) bytes whose margins hold the reflect values: rows 3 .. lh + 2 through the
         // streaming blur (what it writes into the margin columns of fblur is never read)
