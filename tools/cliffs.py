@@ -101,6 +101,25 @@ ms, nk, nm = run(noise.reshape(2 * P, 720, 3 * 1280), 1280, 720, 3 * 1280, steps
 rows.append(("1280 x 720 noise, VSLAM_OPT_CORNER_LIST_CAP = -1 (whole-image lists)", ms, nk, nm))
 ms, nk, nm = run(base.reshape(2 * P, 720, 3 * 1280), 1280, 720, 3 * 1280)
 rows.append(("1280 x 720 image data, VSLAM_OPT_CORNER_LIST_CAP = -1", ms, nk, nm))
+ctx.set_option(ctx.OPT_CORNER_LIST_CAP, 0)
+odd = base[:, :, :1277].contiguous()
+ms, nk, nm = run(padded(odd, 3 * 1277 + 2), 1277, 720, 3 * 1277 + 2)
+rows.append(("1277 x 720, row stride 3 w + 2 (odd width AND unaligned rows)", ms, nk, nm))
+# the grid ORB/FAST extractor (src/Frame.cpp:16-51) alone, 64 frames, 4 x 4 cells: level 0 of its pyramids is the gray frame
+grid_rows = []
+pat = torch.from_numpy(synth.brief_pattern()).to(dev)
+for wg in (1280, 1278):
+    fr = base[:64, :, :wg].contiguous()
+    o_ = ctx.extract_features_grid(fr, 4, 4, pat, 8192)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        ctx.extract_features_grid(fr, 4, 4, pat, 8192, out=o_)
+    ctx.synchronize()
+    grid_rows.append((wg, (time.perf_counter() - t0) / 8 * 1e3, float(o_["n"].float().mean())))
 print(f"{P} pairs, {K} keypoints, {H} hypotheses, one context; ms per batch, x the fast path, keypoints / inlier matches per frame / pair")
 for name, ms, nk, nm in rows:
     print(f"  {name:72s} {ms:8.3f}  x{ms / rows[0][1]:5.2f}   {nk:7.1f} {nm:7.1f}")
+print("grid ORB/FAST extractor alone, 64 frames, 4 x 4 cells; ms per call, x the width-1280 call, keypoints per frame")
+for wg, ms, nk in grid_rows:
+    print(f"  {wg} x 720{'' if wg % 4 == 0 else ' (width not a multiple of 4)':40s} {ms:8.3f}  x{ms / grid_rows[0][1]:5.2f}   {nk:7.1f}")
