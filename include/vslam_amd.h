@@ -443,6 +443,14 @@ int vslam_pipeline_submit_pairs(vslam_pipeline *p, const uint8_t *d_bgr, int pai
                                 const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
                                 float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
                                 int32_t *d_matches, int32_t *d_best, float *d_F, int32_t *d_records, int64_t *ticket_out);
+/* vslam_frontend_pairs_pose as a ticket (h_K is copied; *pose is copied, the arrays it names are the caller's until the
+ * ticket has been waited for).  A batch that exhausts the corner pool is queued once more, pose stages included. */
+int vslam_pipeline_submit_pairs_pose(vslam_pipeline *p, const uint8_t *d_bgr, int pairs, int width, int height, int row_stride,
+                                     const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                                     float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                                     int32_t *d_matches, int32_t *d_best, float *d_F, const float *h_K,
+                                     const int32_t *d_map_point_ids, float reproj_threshold_sq, const vslam_pose_outputs *pose,
+                                     int32_t *d_records, int64_t *ticket_out);
 int vslam_pipeline_submit_sequence(vslam_pipeline *p, const uint8_t *d_bgr, int frames, int width, int height, int row_stride,
                                    const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
                                    float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,

@@ -284,3 +284,57 @@ def test_submitted_batch_that_exhausts_the_corner_pool_is_done_again(oracle):
         assert o["n"][0] == a["n"] and np.array_equal(o["xy"][0, :a["n"]], a["xy"]) and np.array_equal(o["desc"][0, :a["n"]], a["desc"])
     finally:
         pipe.close()
+
+
+def test_pose_chain_as_tickets(ctx):
+    """vslam_pipeline_submit_pairs_pose: every batch's pose outputs (R, t, c2, triangulated points, reprojection filter) equal the
+    same call on a single context, with three batches in flight and a queue longer than the pipeline; a batch that exhausts the
+    corner pool is done again, pose stages included."""
+    w, h, maxc, P = 320, 240, 300, 3
+    ca, sa = synth.keypoint_rotation()
+    Kmat = np.array([[525.0, 0, w // 2], [0, 525.0, h // 2], [0, 0, 1]], np.float32)
+    frames = [torch.from_numpy(synth.frames_numpy(900 + i, P, w, h)).cuda() for i in range(5)]
+    seeds = [torch.from_numpy((np.arange(P, dtype=np.int32) + 31 * i)).cuda() for i in range(5)]
+    refs = []
+    for fr, sd in zip(frames, seeds):
+        o = ctx.frontend_pairs_pose(fr, P, maxc, ca, sa, None, sd, HYP, THR, Kmat)
+        ctx.synchronize()
+        refs.append({k: v.cpu().numpy() for k, v in o.items()})
+    assert sum(int(r["n_inliers"].sum()) for r in refs) > 50, "the scenes should triangulate"
+
+    def same(out, ref, tag):   # what a batch defines: rows up to its counts (the buffers are reused by later tickets)
+        g = {k: v.cpu().numpy() for k, v in out.items()}
+        bits = lambda a: np.ascontiguousarray(a).view(np.uint8)
+        for k in ("n", "best", "F", "R", "t", "c2", "n_inliers", "error"):
+            assert np.array_equal(bits(g[k]), bits(ref[k])), (tag, k)
+        for f in range(2 * P):
+            n = int(ref["n"][f])
+            for k in ("xy", "desc", "nodes"):
+                assert np.array_equal(bits(g[k][f, :n]), bits(ref[k][f, :n])), (tag, k, f)
+        for b in range(P):
+            m, ni = int(ref["best"][b, 3]), int(ref["n_inliers"][b])
+            assert np.array_equal(g["matches"][b, :m], ref["matches"][b, :m]), (tag, "matches", b)
+            if ref["best"][b, 0] >= 0:
+                assert np.array_equal(bits(g["points4d"][b, :m]), bits(ref["points4d"][b, :m])), (tag, "points4d", b)
+                assert np.array_equal(g["inlier_idx"][b, :ni], ref["inlier_idx"][b, :ni]), (tag, "inlier_idx", b)
+
+    pipe = capi.Pipeline(0, 3)
+    try:
+        outs = [capi.Pipeline.alloc_pose_outputs(torch, 2 * P, P, maxc, frames[0].device) for _ in range(3)]
+        tickets = []
+        for i, (fr, sd) in enumerate(zip(frames, seeds)):
+            if i >= 3:
+                assert pipe.wait_status(tickets[i - 3])[0] == 0
+                same(outs[(i - 3) % 3], refs[i - 3], i - 3)
+            tickets.append(pipe.submit_pairs_pose(fr, P, maxc, ca, sa, None, sd, HYP, THR, Kmat, outs[i % 3]))
+        for i in (2, 3, 4):
+            assert pipe.wait_status(tickets[i])[0] == 0
+            same(outs[i % 3], refs[i], i)
+        # the overflow case: lists of 40 entries, every frame overflows, the pool holds fewer -> queued again, pose included
+        pipe.set_option(capi.Context.OPT_CORNER_LIST_CAP, 40)
+        t = pipe.submit_pairs_pose(frames[0], P, maxc, ca, sa, None, seeds[0], HYP, THR, Kmat, outs[0])
+        assert pipe.wait_status(t)[0] == 0
+        assert pipe.batches_redone() == 1      # six frames overflow, the pool of this batch holds four
+        same(outs[0], refs[0], "redone")
+    finally:
+        pipe.close()

@@ -33,7 +33,7 @@ SYMBOLS = [
     "vslam_shard_range", "vslam_multi_create", "vslam_multi_destroy", "vslam_multi_size", "vslam_multi_ctx", "vslam_multi_last_error",
     "vslam_multi_frontend_pairs", "vslam_multi_frontend_pairs_resident", "vslam_comm_info", "vslam_gather_records_v", "vslam_comm_unique_id", "vslam_comm_create", "vslam_comm_destroy", "vslam_gather_records",
     "vslam_pipeline_create", "vslam_pipeline_destroy", "vslam_pipeline_size", "vslam_pipeline_ctx", "vslam_pipeline_last_error",
-    "vslam_pipeline_set_option", "vslam_pipeline_acquire", "vslam_pipeline_commit", "vslam_pipeline_submit_pairs",
+    "vslam_pipeline_set_option", "vslam_pipeline_acquire", "vslam_pipeline_commit", "vslam_pipeline_submit_pairs", "vslam_pipeline_submit_pairs_pose",
     "vslam_pipeline_submit_sequence", "vslam_pipeline_poll", "vslam_pipeline_wait", "vslam_pipeline_drain",
 ]
 
@@ -682,6 +682,37 @@ class Pipeline:
             C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out.get("nodes")), _ptr(out["n"]),
             _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"]), _ptr(records), C.byref(t)))
         return t.value
+
+    def submit_pairs_pose(self, bgr, pairs, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, K, out, ids=None, thr_sq=4.0,
+                          records=None, kp_stride=None):
+        """vslam_pipeline_submit_pairs_pose: `out` = alloc_outputs(...) plus the pose arrays (alloc_pose_outputs)."""
+        import numpy as np
+        F, H, W, _ = bgr.shape
+        assert F == 2 * pairs
+        Kp = kp_stride or max_corners
+        p = self.contexts[0]._params(max_corners, cos_a, sin_a, pattern)
+        po = PoseOutputs(*(C.c_void_p(out[k].data_ptr()) for k in ("R", "t", "c2", "points4d", "inlier_idx", "n_inliers", "error")))
+        Kh = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+        t = C.c_int64()
+        self._check(self.lib.vslam_pipeline_submit_pairs_pose(
+            self.handle, _ptr(bgr), C.c_int(pairs), C.c_int(W), C.c_int(H), C.c_int(3 * W), C.byref(p), C.c_int(Kp), _ptr(seeds),
+            C.c_int(hyp), C.c_float(threshold), _ptr(out["xy"]), _ptr(out["desc"]), _ptr(out.get("nodes")), _ptr(out["n"]),
+            _ptr(out["matches"]), _ptr(out["best"]), _ptr(out["F"]), Kh.ctypes.data_as(C.c_void_p), _ptr(ids), C.c_float(thr_sq),
+            C.byref(po), _ptr(records), C.byref(t)))
+        return t.value
+
+    @staticmethod
+    def alloc_pose_outputs(torch, frames, pairs, K, device):
+        """alloc_outputs + the arrays of vslam_pose_outputs, ready for a context's own stream."""
+        out = Pipeline._alloc_outputs(torch, frames, pairs, K, device)
+        out.update(R=torch.zeros((pairs, 9), dtype=torch.float32, device=device), t=torch.zeros((pairs, 3), dtype=torch.float32, device=device),
+                   c2=torch.zeros((pairs, 12), dtype=torch.float32, device=device),
+                   points4d=torch.zeros((pairs, K, 4), dtype=torch.float32, device=device),
+                   inlier_idx=torch.zeros((pairs, K), dtype=torch.int32, device=device),
+                   n_inliers=torch.zeros((pairs,), dtype=torch.int32, device=device),
+                   error=torch.zeros((pairs,), dtype=torch.float64, device=device))
+        torch.cuda.current_stream(device).synchronize()
+        return out
 
     def submit_sequence(self, bgr, max_corners, cos_a, sin_a, pattern, seeds, hyp, threshold, out, records=None, kp_stride=None):
         F, H, W, _ = bgr.shape

@@ -22,7 +22,7 @@ namespace {
 // what vslam_pipeline_submit_pairs / _sequence queued for a ticket: enough to queue it again (the caller's buffers stay valid
 // until the ticket has been waited for)
 struct Submitted {
-    int kind = 0;   // 0: nothing recorded (a ticket built with acquire / commit), 1: pairs, 2: sequence
+    int kind = 0;   // 0: nothing recorded (a ticket built with acquire / commit), 1: pairs, 2: sequence, 3: pairs + pose chain
     const uint8_t *d_bgr = nullptr;
     int count = 0, width = 0, height = 0, row_stride = 0, kp_stride = 0, hyp = 0;
     vslam_extract_params params{};
@@ -32,6 +32,11 @@ struct Submitted {
     uint8_t *d_desc = nullptr;
     int32_t *d_nodes = nullptr, *d_n = nullptr, *d_matches = nullptr, *d_best = nullptr, *d_records = nullptr;
     float *d_F = nullptr;
+    // kind 3 (vslam_frontend_pairs_pose)
+    float K[9] = {};
+    const int32_t *d_map_point_ids = nullptr;
+    float reproj_threshold_sq = 0.f;
+    vslam_pose_outputs pose{};
 };
 struct Slot {
     vslam_ctx *ctx = nullptr;
@@ -91,11 +96,15 @@ int retire(vslam_pipeline *p, Slot &s) {
             int rc2 = q.kind == 1 ? vslam_frontend_pairs(s.ctx, q.d_bgr, q.count, q.width, q.height, q.row_stride, &q.params, q.kp_stride,
                                                           q.d_seeds, q.hyp, q.threshold, q.d_xy, q.d_desc, q.d_nodes, q.d_n, q.d_matches,
                                                           q.d_best, q.d_F)
+                      : q.kind == 3 ? vslam_frontend_pairs_pose(s.ctx, q.d_bgr, q.count, q.width, q.height, q.row_stride, &q.params,
+                                                                q.kp_stride, q.d_seeds, q.hyp, q.threshold, q.d_xy, q.d_desc, q.d_nodes,
+                                                                q.d_n, q.d_matches, q.d_best, q.d_F, q.K, q.d_map_point_ids,
+                                                                q.reproj_threshold_sq, &q.pose)
                                   : vslam_frontend_sequence(s.ctx, q.d_bgr, q.count, q.width, q.height, q.row_stride, &q.params,
                                                             q.kp_stride, q.d_seeds, q.hyp, q.threshold, q.d_xy, q.d_desc, q.d_nodes, q.d_n,
                                                             q.d_matches, q.d_best, q.d_F);
             if (rc2 == VSLAM_OK && q.d_records)
-                rc2 = vslam_pack_records(s.ctx, q.d_F, q.d_best, q.d_matches, q.kind == 1 ? q.count : q.count - 1, q.kp_stride, q.d_records);
+                rc2 = vslam_pack_records(s.ctx, q.d_F, q.d_best, q.d_matches, q.kind == 2 ? q.count - 1 : q.count, q.kp_stride, q.d_records);
             if (rc2 == VSLAM_OK) rc2 = vslam_ctx_synchronize(s.ctx);   // waits, reads and clears the word: the context is this slot's alone
             else (void)vslam_ctx_wait(s.ctx);
             s.ctx->corner_list_cap = cap;
@@ -273,6 +282,43 @@ int vslam_pipeline_submit_pairs(vslam_pipeline *p, const uint8_t *d_bgr, int pai
     // close the batch either way: whatever part of it was queued has to be waited for before the slot is used again (the
     // caller has the error in hand: it is not filed under the ticket as well)
     const int crc = commit_locked(p, t);
+    if (rc) {
+        p->err = std::string("ticket ") + std::to_string(t) + ": " + vslam_last_error(c);
+        return rc;
+    }
+    if (crc) return crc;
+    *ticket_out = t;
+    return VSLAM_OK;
+}
+
+// vslam_frontend_pairs_pose as a ticket: the step + extract_Rt + triangulate + reprojection filter on the slot's context; a batch
+// that exhausts the corner pool is queued once more like a submit_pairs batch, pose stages included.
+int vslam_pipeline_submit_pairs_pose(vslam_pipeline *p, const uint8_t *d_bgr, int pairs, int width, int height, int row_stride,
+                                     const vslam_extract_params *params, int kp_stride, const uint32_t *d_seeds, int hyp,
+                                     float threshold, float *d_xy, uint8_t *d_desc, int32_t *d_nodes, int32_t *d_n,
+                                     int32_t *d_matches, int32_t *d_best, float *d_F, const float *h_K,
+                                     const int32_t *d_map_point_ids, float reproj_threshold_sq, const vslam_pose_outputs *pose,
+                                     int32_t *d_records, int64_t *ticket_out) {
+    if (!p || !ticket_out || !h_K || !pose) return VSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(p->mu);
+    *ticket_out = -1;
+    vslam_ctx *c = nullptr;
+    int64_t t = -1;
+    int rc = acquire_locked(p, &c, &t);
+    if (rc) return rc;
+    rc = vslam_frontend_pairs_pose(c, d_bgr, pairs, width, height, row_stride, params, kp_stride, d_seeds, hyp, threshold, d_xy,
+                                   d_desc, d_nodes, d_n, d_matches, d_best, d_F, h_K, d_map_point_ids, reproj_threshold_sq, pose);
+    if (rc == VSLAM_OK && d_records) rc = vslam_pack_records(c, d_F, d_best, d_matches, pairs, kp_stride, d_records);
+    if (rc == VSLAM_OK && params) {
+        remember(p, t, 3, d_bgr, pairs, width, height, row_stride, *params, kp_stride, d_seeds, hyp, threshold, d_xy, d_desc, d_nodes, d_n,
+                 d_matches, d_best, d_F, d_records);
+        Submitted &q = p->slots[(size_t)(t % (int64_t)p->slots.size())].sub;
+        for (int i = 0; i < 9; i++) q.K[i] = h_K[i];   // the caller's array need not outlive the call
+        q.d_map_point_ids = d_map_point_ids;
+        q.reproj_threshold_sq = reproj_threshold_sq;
+        q.pose = *pose;
+    }
+    const int crc = commit_locked(p, t);   // (as in vslam_pipeline_submit_pairs)
     if (rc) {
         p->err = std::string("ticket ") + std::to_string(t) + ": " + vslam_last_error(c);
         return rc;
