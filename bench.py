@@ -40,6 +40,14 @@ WORKLOADS = {
 }
 SEED_INDEX = {"C2": 0, "C3": 1, "C5": 2, "C3g": 3}   # seeds of the BASELINE configs stay what they were before C3g existed
 GRID = (4, 4)
+
+
+def POSE_K(w, h):
+    """The reference's camera matrix for a w x h frame (src/vslam.cpp:32)."""
+    import numpy as np
+    return np.array([[525.0, 0, w // 2], [0, 525.0, h // 2], [0, 0, 1]], np.float32)
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -683,6 +691,9 @@ def main():
     ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
                     help="pairs per process for the all-host-cores CPU figure (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--pose", action="store_true",
+                    help="every step also runs the pose stages behind the path (vslam_frontend_pairs_pose: extract_Rt, triangulate, "
+                         "reprojection filter); the default run reports this arrangement under pose_chain.in_flight")
     ap.add_argument("--alone", action="store_true",
                     help="for rocprofv3 passes: every kernel of a step on ONE stream, nothing beside it (k-d build, blur and generator in "
                          "line), so that a traced kernel's duration is its own -- the arrangement of the per-kernel HIP-event pass; use with "
@@ -783,7 +794,7 @@ def main():
         sl.bgr = make_frames(seed + 1000 * rank + 7919 * s, P, w, h, dev)
         sl.seeds_np = shard.pair_seeds(seed, lo + s * world * P, hi + s * world * P)
         sl.seeds = torch.from_numpy(sl.seeds_np.view(np.int32)).to(dev)
-        sl.out = Pipeline.alloc_outputs(torch, 2 * P, P, K, dev)
+        sl.out = (Pipeline.alloc_pose_outputs if args.pose else Pipeline.alloc_outputs)(torch, 2 * P, P, K, dev)
         sl.rec = torch.zeros((P, words), dtype=torch.int32, device=dev) if multi else None
         sl.gathered = torch.zeros((world * P, words), dtype=torch.int32, device=dev) if multi else None
         sl.comm = comms[s % n_comms] if n_comms else None
@@ -799,7 +810,10 @@ def main():
         acquire waits for the batch that used the context n_slots steps ago)."""
         t, c = pipe.acquire()
         sl = slots[t % n_slots]      # the pipeline hands out context ticket % n: a slot's frames, outputs and communicator stay with ITS context
-        c.frontend_pairs(sl.bgr, P, K, ca, sa, pat, sl.seeds, H, thr, out=sl.out)
+        if args.pose:
+            c.frontend_pairs_pose(sl.bgr, P, K, ca, sa, pat, sl.seeds, H, thr, POSE_K(w, h), out=sl.out)
+        else:
+            c.frontend_pairs(sl.bgr, P, K, ca, sa, pat, sl.seeds, H, thr, out=sl.out)
         if multi:
             # the only exchange on the path: fixed-size per-pair result records to every rank, on this batch's own stream
             c.pack_records(sl.out["F"], sl.out["best"], sl.out["matches"], out=sl.rec)
@@ -897,7 +911,8 @@ def main():
             "dtype": "u8/f32/f64",
             "data": "synthetic (" + data_label + ")",
             "config": {"workload": f"{args.workload}: {w}x{h}, {K} keypoints, {H} hypotheses, batch {P} pairs per GPU, {data_label}",
-                       "pairs_per_gpu": P, "batches_in_flight": n_slots, "parallelism": par},
+                       "pairs_per_gpu": P, "batches_in_flight": n_slots, "parallelism": par,
+                       **({"pose_stages": "every step is vslam_frontend_pairs_pose (--pose)"} if args.pose else {})},
             "setup_steps": n_slots,   # untimed, before the warm-up: one batch per context (workspace allocation, RCCL channel set-up)
             "mean_keypoints": float(n_kp.mean()), "mean_inlier_matches": float(best[:, 3].mean()),
             "workspace_bytes": pipe.workspace_bytes(),   # the contexts' grow-only workspaces for this batch shape (inputs / outputs not counted)
@@ -1193,7 +1208,7 @@ def main():
             # triangulate + reprojection filter, src/vslam.cpp:82-88,120-125,186-251) and the map-association block
             # (src/vslam.cpp:129-161) on the batch's own results, one context; checked against the oracle on a few pairs
             def pose_and_association():
-                Kmat = np.array([[525.0, 0, w // 2], [0, 525.0, h // 2], [0, 0, 1]], np.float32)   # src/vslam.cpp:32
+                Kmat = POSE_K(w, h)
                 po = ctx.frontend_pairs_pose(s0.bgr, P, K, ca, sa, pat, s0.seeds, H, thr, Kmat)
                 for _ in range(2):
                     ctx.frontend_pairs_pose(s0.bgr, P, K, ca, sa, pat, s0.seeds, H, thr, Kmat, out=po)
@@ -1280,6 +1295,14 @@ def main():
                                         "parity_in_bench": {"pairs": min(P, 4), "bit_exact": not bad_a}}
                 return entry, bool(bad_p or bad_a)
             pc, pc_bad = pose_and_association()
+            cp = child(["--workload", args.workload, "--pairs", str(P), "--in-flight", str(n_slots), "--steps", "24", "--warmup", "4",
+                        "--no-profile-pass", "--cpu-pairs", "8", "--pose"])
+            if not child_parity_ok(cp):
+                exit_code = 3
+            pc["in_flight"] = ({k: v for k, v in cp.items() if k != "line"} if cp.get("failed") else
+                               {"contexts": n_slots, "ms_per_step": cp["ms_per_step"], "frame_pairs_per_s": cp["value"],
+                                "parity_in_bench": cp["parity_in_bench"]["bit_exact"],
+                                "what": "every step = vslam_frontend_pairs_pose, batches in flight as in the headline; a fresh process, 24 steps"})
             result["pose_chain"] = pc
             if pc_bad:
                 exit_code = 3
