@@ -1,6 +1,6 @@
 """Time the grid ORB/FAST extractor (extract_features(Frame&, nrows, ncols), src/Frame.cpp:16-51) alone:
 F frames of w x h through vslam_extract_features_grid, per-scope HIP-event times, ms per frame.
-  python tools/grid_bench.py [--frames 64] [--w 1280 --h 720] [--grid 4] [--steps 10] [--data hard|easy|noise]"""
+  python tools/grid_bench.py [--frames 64] [--w 1280 --h 720] [--grid 4] [--steps 10] [--data hard|easy|photo|noise]"""
 import argparse
 import json
 import os
@@ -28,6 +28,8 @@ def main():
     P = a.frames // 2
     if a.data == "noise":
         bgr = torch.randint(0, 256, (a.frames, a.h, a.w, 3), dtype=torch.uint8, device=dev)
+    elif a.data == "photo":   # windows of the four photographs of tests/golden/real_v1.npz under small camera motions
+        bgr = synth.frames_torch_photo(0x5EED0002, P, a.w, a.h, dev)
     else:
         mk = synth.frames_torch if a.data == "easy" else synth.frames_torch_hard
         bgr = mk(0x5EED0002, P, a.w, a.h, dev)
