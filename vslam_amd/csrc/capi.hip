@@ -611,6 +611,20 @@ int vslam_kdtree_cell_table(vslam_ctx *ctx, const int32_t *d_nodes, const float 
     return vs_launch_kdtree_cell_table(ctx, d_nodes, d_xy, d_n, batch, kp_stride, slots, d_table, d_ok);
 }
 
+// State that one entry point arms for a later stage of the same call (the rotated rBRIEF table queued ahead of the
+// description stage; the raw generator outputs queued ahead of vslam_match_features) must not outlive that call: on
+// an error return in between, the next call would otherwise skip work it needs.  Cleared on every exit.
+struct VsTableGuard {
+    vslam_ctx *c;
+    ~VsTableGuard() { c->rbrief_table_ready = false; c->fork_after_eigen = false; c->img_pitch = 0; }
+};
+struct VsPrefetchGuard {
+    vslam_ctx *c;
+    ~VsPrefetchGuard() { c->raw_seeds = nullptr; }
+};
+// rows for a width the dword kernels do not take as it is (vslam_ctx::img_pitch); 0: the width is fine (or too small to mirror)
+static inline int vs_padded_pitch(int width) { return (width % 4 != 0 && width >= 64) ? (width + 3 + 15) & ~15 : 0; }
+
 int vslam_bgr2gray(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
                    int row_stride, uint8_t *d_gray) {
     if (!ctx) return VSLAM_ERR_INVALID;
@@ -627,6 +641,15 @@ int vslam_good_features(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int w
                         int max_corners, double quality, double min_distance, int kp_stride,
                         float *d_xy, int32_t *d_n) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    if (d_gray && vs_padded_pitch(width) && frames > 0 && height > 0) {   // see vslam_extract_features: the caller's rows, copied into padded ones
+        VsTableGuard guard{ctx};
+        const int pitch = vs_padded_pitch(width);
+        uint8_t *padded = nullptr;
+        if (int rc = vs_arena_get(ctx, "stage.gray_padded", (size_t)frames * pitch * height, (void **)&padded)) return rc;
+        if (int rc = vs_launch_gray_pad(ctx, d_gray, frames, width, height, padded, pitch)) return rc;
+        ctx->img_pitch = pitch;
+        return vs_launch_good_features(ctx, padded, frames, width, height, max_corners, quality, min_distance, kp_stride, d_xy, d_n);
+    }
     return vs_launch_good_features(ctx, d_gray, frames, width, height, max_corners, quality,
                                    min_distance, kp_stride, d_xy, d_n);
 }
@@ -634,6 +657,17 @@ int vslam_good_features(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int w
 int vslam_gaussian7(vslam_ctx *ctx, const uint8_t *d_gray, int frames, int width, int height,
                     uint8_t *d_out) {
     if (!ctx) return VSLAM_ERR_INVALID;
+    if (d_gray && d_out && vs_padded_pitch(width) && frames > 0 && height >= 4) {
+        VsTableGuard guard{ctx};
+        const int pitch = vs_padded_pitch(width);
+        uint8_t *padded = nullptr, *blurred = nullptr;
+        if (int rc = vs_arena_get(ctx, "stage.gray_padded", (size_t)frames * pitch * height, (void **)&padded)) return rc;
+        if (int rc = vs_arena_get(ctx, "stage.blur_padded", (size_t)frames * pitch * height, (void **)&blurred)) return rc;
+        if (int rc = vs_launch_gray_pad(ctx, d_gray, frames, width, height, padded, pitch)) return rc;
+        ctx->img_pitch = pitch;
+        if (int rc = vs_launch_gaussian7(ctx, padded, frames, width, height, blurred)) return rc;
+        return vs_launch_gray_unpad(ctx, blurred, frames, width, height, pitch, d_out);
+    }
     return vs_launch_gaussian7(ctx, d_gray, frames, width, height, d_out);
 }
 
@@ -647,18 +681,6 @@ int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int
     return vs_launch_orb_describe(ctx, d_blurred, frames, width, height, d_xy_in, d_n_in, kp_stride,
                                   cos_a, sin_a, d_pattern, d_xy_out, d_desc, d_n_out);
 }
-
-// State that one entry point arms for a later stage of the same call (the rotated rBRIEF table queued ahead of the
-// description stage; the raw generator outputs queued ahead of vslam_match_features) must not outlive that call: on
-// an error return in between, the next call would otherwise skip work it needs.  Cleared on every exit.
-struct VsTableGuard {
-    vslam_ctx *c;
-    ~VsTableGuard() { c->rbrief_table_ready = false; c->fork_after_eigen = false; c->img_pitch = 0; }
-};
-struct VsPrefetchGuard {
-    vslam_ctx *c;
-    ~VsPrefetchGuard() { c->raw_seeds = nullptr; }
-};
 
 // extract_features(Frame&), src/Frame.cpp:53-80
 int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
@@ -680,7 +702,7 @@ int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int
     // than the image is wide, the tail holding the row's BORDER_REFLECT_101 continuation (written by cvtColor): the same
     // kernels run on those rows and what they produce below column `width` is what the image alone would give
     // (blur.hip, response.hip: the one place that needs a correction is the sign of a mirrored x-derivative).
-    if (width % 4 != 0 && width >= 64) ctx->img_pitch = (width + 3 + 15) & ~15;
+    ctx->img_pitch = vs_padded_pitch(width);
     const size_t px = (size_t)frames * vs_pitch(ctx, width) * height;
     uint8_t *gray = nullptr, *blur = nullptr;
     float *xy_det = nullptr;

@@ -252,6 +252,8 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
                             int max_corners, double quality, double min_distance, int kp_stride,
                             float *xy, int32_t *n, const VsBgrSource *bgr = nullptr);
 int vs_launch_gaussian7(vslam_ctx *ctx, const uint8_t *gray, int frames, int w, int h, uint8_t *out);
+int vs_launch_gray_pad(vslam_ctx *ctx, const uint8_t *src, int frames, int w, int h, uint8_t *dst, int pitch);
+int vs_launch_gray_unpad(vslam_ctx *ctx, const uint8_t *src, int frames, int w, int h, int pitch, uint8_t *dst);
 int vs_launch_gaussian7_rows(vslam_ctx *ctx, const uint8_t *src, uint8_t *dst, int frames, size_t frame_pitch, int w, int h,
                              int y_begin, int y_end);
 int vs_launch_rbrief_rotate(vslam_ctx *ctx, const int8_t *pattern, float ca, float sa);

@@ -69,7 +69,58 @@ __global__ __launch_bounds__(256) void bgr2gray_padded_kernel(const uint8_t *__r
     *reinterpret_cast<uint32_t *>(gray + ((size_t)f * h + y) * pitch + x) = out;
 }
 
+// A caller's gray image (rows of w bytes) into rows of `pitch` bytes with the mirrored tail, and the first w bytes of such rows
+// back into packed rows: what lets the stage-level entry points (vslam_good_features, vslam_gaussian7) use the dword kernels
+// for widths that are no multiple of 4.  A lane = 4 bytes of a padded row.
+__global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t *__restrict__ src, int w, int h, uint8_t *__restrict__ dst,
+                                                       int pitch) {
+    const int f = blockIdx.y;
+    const int qpr = pitch >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * h) return;
+    const int y = q / qpr, x = (q - y * qpr) * 4;
+    const uint8_t *row = src + ((size_t)f * h + y) * w;
+    uint32_t out;
+    if (x + 3 < w) {
+        __builtin_memcpy(&out, row + x, 4);
+    } else {
+        out = 0;
+        for (int i = 0; i < 4; i++) out |= (uint32_t)row[reflect101(x + i, w)] << (8 * i);
+    }
+    *reinterpret_cast<uint32_t *>(dst + ((size_t)f * h + y) * pitch + x) = out;
+}
+
+__global__ __launch_bounds__(256) void gray_unpad_kernel(const uint8_t *__restrict__ src, int w, int h, int pitch,
+                                                         uint8_t *__restrict__ dst) {
+    const int f = blockIdx.y;
+    const int qpr = (w + 3) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * h) return;
+    const int y = q / qpr, x = (q - y * qpr) * 4;
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(src + ((size_t)f * h + y) * pitch + x);
+    uint8_t *out = dst + ((size_t)f * h + y) * w + x;
+    if (x + 3 < w) {
+        __builtin_memcpy(out, &v, 4);
+    } else {
+        for (int i = 0; i < 4 && x + i < w; i++) out[i] = (uint8_t)(v >> (8 * i));
+    }
+}
+
 }  // namespace
+
+int vs_launch_gray_pad(vslam_ctx *ctx, const uint8_t *src, int frames, int w, int h, uint8_t *dst, int pitch) {
+    VS_REQUIRE(ctx, src && dst && frames > 0 && pitch % 4 == 0 && pitch >= w + 3 && pitch - w < w - 1, VSLAM_ERR_INVALID);
+    gray_pad_kernel<<<dim3(vs_div_up((pitch / 4) * h, 256), frames), 256, 0, ctx->stream>>>(src, w, h, dst, pitch);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+int vs_launch_gray_unpad(vslam_ctx *ctx, const uint8_t *src, int frames, int w, int h, int pitch, uint8_t *dst) {
+    VS_REQUIRE(ctx, src && dst && frames > 0 && pitch % 4 == 0 && pitch >= w, VSLAM_ERR_INVALID);
+    gray_unpad_kernel<<<dim3(vs_div_up(((w + 3) / 4) * h, 256), frames), 256, 0, ctx->stream>>>(src, w, h, pitch, dst);
+    VS_HIP(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
 
 int vs_launch_bgr2gray(vslam_ctx *ctx, const uint8_t *bgr, int frames, int w, int h, int stride,
                        uint8_t *gray) {
