@@ -1,5 +1,6 @@
 // cv::GaussianBlur 7x7, sigma 2, 8-bit fixed point, as ORB::compute applies it before sampling (reference:
-// src/Frame.cpp:68) for gfx950: gaussian7_stream_kernel (width % 4 == 0) and gaussian7_kernel (any width).
+// src/Frame.cpp:68) for gfx950: gaussian7_stream_kernel (rows of a multiple of 4 bytes: width % 4 == 0, or padded rows with a
+// mirrored tail, vslam_ctx::img_pitch) and gaussian7_kernel (any width).
 #include "image_common.h"
 
 namespace {

@@ -1,8 +1,11 @@
 // Shi-Tomasi corner response (cv::cornerMinEigenVal inside cv::goodFeaturesToTrack, reference: src/Frame.cpp:61)
 // and the 3x3-local-maximum candidates for gfx950.
-//   min_eigen_stream_kernel   the front-end path: response + candidates in one streaming pass (width % 4 == 0)
-//   min_eigen_v4_kernel       response only, tiled (vslam_min_eigen, width % 4 == 0)
-//   min_eigen_kernel          response only, any width
+//   min_eigen_tiered_kernel   the front-end path, tier 1: a certified bound of the response for every pixel + the list of pixels
+//                             that can matter, one streaming pass (BGR form: cvtColor inside; gray form: rows of a multiple of 4
+//                             bytes, i.e. width % 4 == 0 or padded rows with a mirrored tail, vslam_ctx::img_pitch)
+//   corner_exact_kernel       tier 2: the oracle's arithmetic for the listed pixels
+//   min_eigen_v4_kernel       response only, tiled (vslam_min_eigen, the pool's rerun; width % 4 == 0)
+//   min_eigen_kernel          response only, any width and row pitch
 //   corner_candidates_kernel  threshold + 3x3 maxima over a stored response map (any width)
 // The arithmetic follows the oracle (oracle/vso_extract.cpp) operation for operation; float steps are written so
 // that no contraction or reassociation can occur (-ffp-contract=off).  What bounds the response kernels is VALU

@@ -845,7 +845,8 @@ int vs_launch_good_features(vslam_ctx *ctx, const uint8_t *gray, int frames, int
     // (its rank window outgrew LDS), is filed in a small pool of whole-image scratch and redone from scratch by the plain
     // exact pipeline (pass 2 below): results never depend on the bound.  Should more frames of one call need the pool
     // than it has slots, those frames get no corners and vslam_ctx_synchronize reports VSLAM_ERR_CAPACITY.
-    // Other widths run the plain pipeline on whole-image buffers for every frame, as before.
+    // Gray rows that are no multiple of 4 bytes (a caller's packed image of such a width that nobody padded: widths below 64)
+    // run the plain pipeline on whole-image buffers for every frame.
     const bool two_tier = (vs_pitch(ctx, w) % 4 == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);   // (as vs_launch_response_candidates decides)
     size_t key_cap = px;
     if (two_tier && ctx->corner_list_cap >= 0) {
