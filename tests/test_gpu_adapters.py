@@ -13,14 +13,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpp_surfaces_match_oracle(oracle, tmp_path):
+@pytest.mark.parametrize("w,h", [(320, 240), (323, 241)])   # (a width the device pads internally: rows with a mirrored tail)
+def test_cpp_surfaces_match_oracle(oracle, tmp_path, w, h):
     from vslam_amd import build
     build.build_host()
     exe = str(tmp_path / "adapter_demo")
     subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "native", "adapter_demo.cpp"),
                     "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "vslam_amd"), "-lvslam_host", "-lvslam_amd",
                     "-Wl,-rpath," + os.path.join(ROOT, "vslam_amd")], check=True)
-    w, h, maxc, H, seed = 320, 240, 400, 96, 4242
+    maxc, H, seed = 400, 96, 4242
     bgr = synth.frames_numpy(61, 1, w, h)
     pat = synth.brief_pattern()
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
