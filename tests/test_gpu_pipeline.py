@@ -338,3 +338,15 @@ def test_pose_chain_as_tickets(ctx):
         same(outs[0], refs[0], "redone")
     finally:
         pipe.close()
+
+
+def test_the_python_pose_chain_example_runs():
+    """examples/pose_chain.py: pose tickets on a pipeline, then the association block, end to end."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "pose_chain.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert sum(ln.startswith("batch ") for ln in lines) == 12 and sum(ln.startswith("association, pair") for ln in lines) == 4, r.stdout
+    found = [int(ln.split(",")[-1].split()[0]) for ln in lines if ln.startswith("association")]
+    assert max(found) > 10, r.stdout          # the shifted scenes triangulate and their points find their keypoints again
