@@ -69,6 +69,46 @@ def test_photographs_at_other_settings_equal_the_oracle(ctx, oracle, real, maxc,
             assert np.array_equal(o["F"][i].view(np.uint32), np.asarray(r["F"], np.float32).view(np.uint32)), i
 
 
+@pytest.mark.parametrize("w,h", [(1241, 376), (1226, 370), (723, 481)])
+def test_photographic_windows_of_widths_the_device_pads(ctx, oracle, w, h):
+    """Windows of the photographs at frame sizes whose width is no multiple of 4 (the first two are the KITTI odometry sizes): the
+    device gives its gray / blurred planes padded rows with a mirrored tail and runs the dword kernels on them; the grid extractor
+    does the same with level 0 of its pyramids.  Everything equals the oracle on the same bytes."""
+    P, maxc, hyp = 2, 1500, 128
+    dev = torch.device("cuda", 0)
+    bgr_t = synth.frames_torch_photo(77 + w, P, w, h, dev)
+    bgr = bgr_t.cpu().numpy()
+    pat = synth.brief_pattern()
+    ca, sa = synth.keypoint_rotation()
+    seeds = torch.arange(7, 7 + P, dtype=torch.int32).cuda()
+    out = ctx.frontend_pairs(bgr_t, P, maxc, ca, sa, None, seeds, hyp, 10.0)
+    ctx.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    for i in range(P):
+        fa = oracle.extract_features(bgr[i], maxc, ca, sa, pat)
+        fb = oracle.extract_features(bgr[P + i], maxc, ca, sa, pat)
+        assert fa["n"] > 200, "the window should hold corners"
+        for f, r in ((i, fa), (P + i, fb)):
+            assert o["n"][f] == r["n"], (w, h, f)
+            assert np.array_equal(o["xy"][f, :r["n"]], r["xy"]) and np.array_equal(o["desc"][f, :r["n"]], r["desc"]), (w, h, f)
+            assert np.array_equal(o["nodes"][f, :r["n"]], r["nodes"]), (w, h, f)
+        r = oracle.match_features(fa["xy"], fa["desc"], fb["xy"], fb["desc"], 7 + i, hyp, 10.0)
+        k = len(r["matches"])
+        assert o["best"][i, 3] == k and np.array_equal(o["matches"][i, :k], r["matches"]), (w, h, i)
+        if r["rc"] == 0:
+            assert np.array_equal(o["F"][i].view(np.uint32), np.asarray(r["F"], np.float32).view(np.uint32)), (w, h, i)
+    # the grid extractor on the first frame (it outlines the cells into the image it is given: a copy)
+    work = bgr_t[:1].clone()
+    g = ctx.extract_features_grid(work, 3, 4, torch.from_numpy(pat).cuda(), 8192)
+    ctx.synchronize()
+    ref_img, xy, desc, ao = oracle.extract_features_grid(bgr[0], 3, 4, pat)
+    n = int(g["n"][0])
+    assert n == len(xy) and np.array_equal(work[0].cpu().numpy(), ref_img), (w, h)
+    assert np.array_equal(g["xy"][0, :n].cpu().numpy().view(np.uint32), xy.view(np.uint32)), (w, h)
+    assert np.array_equal(g["desc"][0, :n].cpu().numpy(), desc), (w, h)
+    assert np.array_equal(g["angle_octave"][0, :n].cpu().numpy().view(np.uint32), ao.view(np.uint32)), (w, h)
+
+
 def test_stage_outputs_on_photographs(ctx, oracle, real):
     """cvtColor, the response image, the blur -- whole images compared, not only what survives the selection."""
     _, bgr = real
