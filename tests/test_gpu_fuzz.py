@@ -1,4 +1,4 @@
-"""Fixed slices of the randomised parity runs (tests/fuzz_extract.py, tests/fuzz_match.py, tests/fuzz_ransac.py)."""
+"""Fixed slices of the randomised parity runs (tests/fuzz_extract.py, fuzz_match.py, fuzz_ransac.py, fuzz_grid.py, fuzz_assoc.py, fuzz_pose.py)."""
 import pytest
 
 import fuzz_extract
@@ -29,3 +29,8 @@ def test_grid_extractor_on_random_shapes_grids_and_content(ctx, oracle):
 def test_fuzz_assoc_slice(ctx, oracle):
     import fuzz_assoc
     assert fuzz_assoc.run(ctx, oracle, seed=20261009, cases=40) == 40
+
+
+def test_fuzz_pose_slice(ctx, oracle):
+    import fuzz_pose
+    assert fuzz_pose.run(ctx, oracle, seed=20261010, cases=60) == 60

@@ -9,7 +9,7 @@ cd $R
 python3 -c "import sys, json; sys.path.insert(0, '.'); import bench; print(json.dumps(bench.source_stamp(), indent=1))" > $O/source_stamp.txt
 SEED=$(( $(date +%s) % 100000 ))
 echo "seed base $SEED, $SECS s per fuzzer" > $O/summary.txt
-for f in extract match ransac grid assoc; do
+for f in extract match ransac grid assoc pose; do
   timeout -k 10 $((SECS + 120)) python3 tests/fuzz_$f.py $((SEED + 1)) $SECS > $O/fuzz_$f.log 2>&1 || { echo "fuzz_$f FAILED" >> $O/summary.txt; tail -5 $O/fuzz_$f.log >> $O/summary.txt; exit 1; }
   echo "fuzz_$f: $(grep -v amdgpu.ids $O/fuzz_$f.log | tail -2 | tr "\n" ";")" >> $O/summary.txt
   SEED=$((SEED + 7))
