@@ -691,6 +691,9 @@ def main():
     ap.add_argument("--cpu-all-cores-pairs", type=int, default=24,
                     help="pairs per process for the all-host-cores CPU figure (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--width", type=int, default=0,
+                    help="frame width instead of the workload's (e.g. 1278: a width that is no multiple of 4 runs on padded internal rows); "
+                         "the default run reports one such shape under other_shapes")
     ap.add_argument("--pose", action="store_true",
                     help="every step also runs the pose stages behind the path (vslam_frontend_pairs_pose: extract_Rt, triangulate, "
                          "reprojection filter); the default run reports this arrangement under pose_chain.in_flight")
@@ -760,6 +763,8 @@ def main():
     w, h, K, H, P = WORKLOADS[args.workload]
     if args.pairs:
         P = args.pairs
+    if args.width:
+        w = args.width
     thr = 10.0                                    # RansacFilter rf(8, 100, 10), src/vslam.cpp:19
     seed = 0x5EED0000 + SEED_INDEX[args.workload]
     n_slots = max(1, min(16, args.in_flight))
@@ -993,7 +998,7 @@ def main():
         m_prelim = M   # inlier matches; preliminary matches are >= this
         kernels = kernel_table(rep, psteps, w, h, K, H, m_prelim, P)
         top = kernels[0]
-        full_batch = args.workload == "C3" and P == WORKLOADS["C3"][4]   # the shape the committed counter passes ran
+        full_batch = args.workload == "C3" and P == WORKLOADS["C3"][4] and not args.width   # the shape the committed counter passes ran
         if full_batch:   # every kernel of the step against the vector-pipe and HBM ceilings, where this build's counter rows exist
             for k in kernels:
                 sq = sq_counters(k["kernel"])
@@ -1338,6 +1343,18 @@ def main():
                     entry["cpu_baseline"] = c.get("cpu_baseline")
                 others[wl] = entry
             result["other_workloads"] = others
+            # a frame width that is no multiple of 4 (padded internal rows under the same kernels): headline arrangement, own parity check
+            wodd = w - 2
+            cw = child(["--workload", args.workload, "--pairs", str(P), "--width", str(wodd), "--in-flight", str(n_slots), "--steps", "24",
+                        "--warmup", "4", "--no-profile-pass", "--cpu-pairs", "8"])
+            if not child_parity_ok(cw):
+                exit_code = 3
+            result["other_shapes"] = {f"{wodd}x{h}": ({k: v for k, v in cw.items() if k != "line"} if cw.get("failed") else
+                                                     {"ms_per_step": cw["ms_per_step"], "frame_pairs_per_s": cw["value"], "batches_in_flight": n_slots,
+                                                      "x_the_headline_step": cw["ms_per_step"] / ms_step,
+                                                      "mean_keypoints": cw["mean_keypoints"], "parity_in_bench": cw["parity_in_bench"],
+                                                      "what": "the same workload at a width that is no multiple of 4: cvtColor writes gray rows of a "
+                                                              "multiple of 16 bytes with a mirrored tail and the same kernels run on them; a fresh process"})}
         except Exception as e:   # a secondary measurement must not cost the headline its line
             import traceback
             result["extras_error"] = {"error": repr(e), "traceback_tail": traceback.format_exc()[-800:]}

@@ -130,3 +130,35 @@ def test_extract_from_bgr_on_seams(ctx, oracle, w, h, pad):
         assert np.array_equal(out["xy"][f, :k], r["xy"]), (w, h, pad, f)
         assert np.array_equal(out["desc"][f, :k], r["desc"]), (w, h, pad, f)
         assert np.array_equal(out["nodes"][f, :k], r["nodes"]), (w, h, pad, f)
+
+
+@pytest.mark.parametrize("w,h", [(509, 77), (510, 77), (511, 77), (1277, 96), (257, 64), (258, 70), (259, 64), (512, 77)])
+def test_detected_corners_before_the_border_filter(ctx_exp, oracle, w, h):
+    """The corners goodFeaturesToTrack returns, in rank order, BEFORE ORB::compute drops the ones within 31 pixels of the border
+    (vslam_debug_detect, experiments build): what extract_features' own outputs cannot show -- corners in the first and last
+    columns' neighbourhood, where the padded rows of an odd width (mirrored tail, a lane across the last column) and the strip
+    seams live.  Budget above the corner count (nothing is truncated away), and below it (rank order matters); twice over, the
+    second time on workspaces the first left dirty; one frame whose strongest response lies ON the last column."""
+    rng = np.random.default_rng(77 + w + h)
+    bgr = rng.integers(0, 256, (4, h, w, 3), dtype=np.uint8)
+    for f in range(3):
+        for _ in range(max(1, w * h // 500)):
+            x, y = rng.integers(0, w), rng.integers(0, h)
+            bgr[f, y:y + rng.integers(2, 12), x:x + rng.integers(2, 12)] = rng.integers(0, 256, 3)
+    bgr[3] = 100                                                     # a flat frame with one small pattern in its last three columns
+    patch = np.array([[255, 0, 0], [0, 0, 255], [255, 255, 0], [0, 0, 0], [255, 0, 0], [0, 255, 255]], np.uint8)
+    bgr[3, h // 2 - 3:h // 2 + 3, w - 3:] = patch[:, :, None]
+    e3 = oracle.min_eigen(oracle.bgr2gray(bgr[3]))
+    assert np.unravel_index(np.argmax(e3), e3.shape)[1] == w - 1, "the frame's strongest response should lie on the last column"
+    t = torch.from_numpy(bgr).cuda()
+    gray = [oracle.bgr2gray(bgr[f]) for f in range(4)]
+    for maxc in (4000, 150):
+        for rep in range(2):
+            xy, n = ctx_exp.debug_detect(t, maxc)
+            ctx_exp.synchronize()
+            xy, n = xy.cpu().numpy(), n.cpu().numpy()
+            for f in range(4):
+                ref = oracle.good_features(gray[f], maxc)
+                assert n[f] == len(ref), (w, h, maxc, rep, f, n[f], len(ref))
+                assert np.array_equal(xy[f, :n[f]], ref), (w, h, maxc, rep, f)
+    assert len(oracle.good_features(gray[3], 4000)) > 0

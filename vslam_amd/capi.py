@@ -166,6 +166,20 @@ class Context:
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
 
+    def debug_detect(self, bgr, max_corners, width=None):
+        """(experiments build only) cvtColor + goodFeaturesToTrack from the 3-byte image: the corners BEFORE the descriptor stage's
+        border filter, in rank order -- (xy (F, max_corners, 2), n (F,))."""
+        torch = self.torch
+        F, H = bgr.shape[0], bgr.shape[1]
+        W = width if width is not None else bgr.shape[2]
+        stride = bgr.shape[2] * (bgr.shape[3] if bgr.dim() == 4 else 1)
+        xy = torch.zeros((F, max_corners, 2), dtype=torch.float32, device=bgr.device)
+        n = torch.zeros((F,), dtype=torch.int32, device=bgr.device)
+        self._ready()
+        self._check(self.lib.vslam_debug_detect(self.handle, _ptr(bgr), C.c_int(F), C.c_int(W), C.c_int(H), C.c_int(stride),
+                                                C.c_int(max_corners), C.c_int(max_corners), _ptr(xy), _ptr(n)))
+        return xy, n
+
     def debug_valu_calib(self):
         self._check(self.lib.vslam_debug_valu_calib(self.handle))
 

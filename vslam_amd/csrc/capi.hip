@@ -682,6 +682,21 @@ int vslam_orb_describe(vslam_ctx *ctx, const uint8_t *d_blurred, int frames, int
                                   cos_a, sin_a, d_pattern, d_xy_out, d_desc, d_n_out);
 }
 
+#ifdef VSLAM_EXPERIMENTS
+// (experiments build only) the detection half of vslam_extract_features by itself: cvtColor + goodFeaturesToTrack from the 3-byte
+// image, the corners BEFORE ORB::compute's border filter -- what a parity hunt near the image border needs to look at
+int vslam_debug_detect(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height, int row_stride, int max_corners,
+                       int kp_stride, float *d_xy, int32_t *d_n) {
+    if (!ctx) return VSLAM_ERR_INVALID;
+    VsTableGuard table_guard{ctx};
+    ctx->img_pitch = vs_padded_pitch(width);
+    uint8_t *gray = nullptr;
+    if (int rc = vs_arena_get(ctx, "extract.gray", (size_t)frames * vs_pitch(ctx, width) * height, (void **)&gray)) return rc;
+    const VsBgrSource src{d_bgr, row_stride};
+    return vs_launch_good_features(ctx, gray, frames, width, height, max_corners, 0.01, 3.0, kp_stride, d_xy, d_n, &src);
+}
+#endif
+
 // extract_features(Frame&), src/Frame.cpp:53-80
 int vslam_extract_features(vslam_ctx *ctx, const uint8_t *d_bgr, int frames, int width, int height,
                            int row_stride, const vslam_extract_params *params, int kp_stride,

@@ -568,7 +568,9 @@ __device__ __forceinline__ void tier_step(TierState &st, TierArgs &a, int t, int
                 unsigned long long bal = 0ull, bmax = 0ull;
                 if (!brow) {
                     bal = __builtin_amdgcn_fcmpf(vp, m8, 3) & a.cand_ok[i];   // 3 = ordered >=
-                    if (a.edge && (i == 0 || i == 3)) bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & a.bord[i];
+                    // (first / last column of the image: pixel 0 / 3 of a lane when w % 4 == 0; with padded rows -- the gray form only --
+                    // the last column can be any of a lane's four)
+                    if (a.edge && (!BGR || i == 0 || i == 3)) bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & a.bord[i];
                 } else {
                     bmax = __builtin_amdgcn_fcmpf(vp, a.lowU, 3) & (BGR ? a.own : (a.cand_ok[i] | a.bord[i]));   // the lane's pixels inside the image
                 }
